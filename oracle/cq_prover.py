@@ -1,0 +1,359 @@
+"""TEST INFRASTRUCTURE ONLY -- CPU oracle restating `create_proof` for CQ-only circuits.
+
+Follows `halo2_proofs/src/plonk/prover.rs:51-779` for a constraint system that has
+advice columns and static (CQ) lookups only -- no gates, fixed/instance columns,
+permutations or legacy lookups (exactly the shape of the reference's one CQ
+end-to-end test, `halo2_proofs/tests/my_test.rs`).  Sub-arguments:
+`plonk/static_lookup/prover.rs`, `plonk/vanishing/prover.rs`,
+`plonk/evaluation.rs:533-548`, `poly/kzg/multiopen/gwc/prover.rs`, `transcript.rs`.
+
+Parity status: the arithmetic underneath is pinned by the reference's KATs
+(`oracle/bn254.py`); the proof byte stream itself is "parity unpinned" against
+the Rust prover (no golden proof exists in the reference: its test draws from
+OsRng, my_test.rs:221) and is instead checked by the verifier-side identities
+in `tests/test_oracle_prover.py`.
+"""
+from __future__ import annotations
+
+import hashlib
+from dataclasses import dataclass, field
+
+from .bn254 import (
+    JAC_ID,
+    R_MOD,
+    batch_to_affine,
+    fr_random,
+    from_bytes_wide,
+    g1_to_bytes,
+    inv_mod,
+    jac_add,
+    jac_mul,
+    jac_to_affine,
+    to_jac,
+    to_repr,
+)
+from .poly import EvaluationDomain, best_multiexp, eval_polynomial, kate_division
+
+P = R_MOD
+
+
+class Blake2bWrite:
+    """transcript.rs:170-241 with Challenge255 (:287-315)."""
+
+    def __init__(self):
+        self.state = hashlib.blake2b(digest_size=64, person=b"Halo2-Transcript")
+        self.proof = bytearray()
+
+    def common_scalar(self, s: int):
+        self.state.update(b"\x02")
+        self.state.update(to_repr(s))
+
+    def common_point(self, A):
+        if A is None:
+            raise ValueError("cannot write points at infinity to the transcript")
+        self.state.update(b"\x01")
+        self.state.update(to_repr(A[0]))
+        self.state.update(to_repr(A[1]))
+
+    def write_point(self, A):
+        self.common_point(A)
+        self.proof += g1_to_bytes(A)
+
+    def write_scalar(self, s: int):
+        self.common_scalar(s)
+        self.proof += to_repr(s)
+
+    def squeeze_challenge_scalar(self) -> int:
+        self.state.update(b"\x00")
+        return from_bytes_wide(self.state.copy().digest())
+
+
+@dataclass
+class CqCircuit:
+    """Shape descriptor standing in for `ConstraintSystem` (plonk/circuit.rs) on CQ-only
+    circuits.  `lookups[l]` = list of (advice column, table id): one input expression
+    `advice[col]@Rotation::cur()` per table column, as `lookup_static` registers them
+    (plonk/circuit.rs:1579-1602)."""
+
+    k: int
+    num_advice: int
+    lookups: list
+
+    def advice_queries(self):
+        """plonk/circuit.rs:1619-1633: queries in first-seen order."""
+        q = []
+        for lk in self.lookups:
+            for col, _ in lk:
+                if (col, 0) not in q:
+                    q.append((col, 0))
+        return q
+
+    def blinding_factors(self) -> int:
+        """plonk/circuit.rs:2022-2047."""
+        per_col = [0] * self.num_advice
+        for col, _ in self.advice_queries():
+            per_col[col] += 1
+        factors = max(per_col) if per_col else 1
+        return max(3, factors) + 2
+
+    def degree(self) -> int:
+        """plonk/circuit.rs:1979-2018 with static_lookup.rs:181-190 (input degree 1)."""
+        return 3
+
+
+@dataclass
+class ProvingKey:
+    """The slice of `ProvingKey` (plonk.rs:291-308) this path reads."""
+
+    circuit: CqCircuit
+    domain: EvaluationDomain
+    l_active_row: list  # extended coset, keygen.rs:366-373
+    tables: dict  # id -> StaticTableValues
+    table_cfg: object  # TableSRS (g1_lagrange, g_lagrange_opening_at_0), static_lookup.rs:47-66
+    b0_g1_bound: list
+    vk_repr: int  # opaque transcript_repr (plonk.rs:221-232)
+
+
+def keygen_pk(circuit: CqCircuit, tables: dict, table_cfg, b0_g1_bound, vk_repr: int) -> ProvingKey:
+    """plonk/keygen.rs:344-373 restricted to l_active_row."""
+    dom = EvaluationDomain(circuit.degree(), circuit.k)
+    n = dom.n
+    bf = circuit.blinding_factors()
+    l_blind = [0] * n
+    for i in range(n - bf, n):
+        l_blind[i] = 1
+    l_last = [0] * n
+    l_last[n - bf - 1] = 1
+    lb = dom.coeff_to_extended(dom.lagrange_to_coeff(l_blind))
+    ll = dom.coeff_to_extended(dom.lagrange_to_coeff(l_last))
+    l_active = [(1 - (a + b)) % P for a, b in zip(ll, lb)]
+    assert len(b0_g1_bound) == n - 1
+    return ProvingKey(circuit, dom, l_active, tables, table_cfg, b0_g1_bound, vk_repr)
+
+
+@dataclass
+class ProofTrace:
+    """Intermediate values exposed so tests can compare stage by stage."""
+
+    proof: bytes = b""
+    challenges: dict = field(default_factory=dict)
+    points: dict = field(default_factory=dict)
+    scalars: dict = field(default_factory=dict)
+    polys: dict = field(default_factory=dict)
+
+
+def create_proof(params, pk: ProvingKey, advice_usable, rng, msm=None) -> ProofTrace:
+    """plonk/prover.rs:51-779 for a single CQ-only circuit.
+
+    `advice_usable[c]` = the assigned values of advice column c on rows 0..u (shorter
+    lists are zero-padded: unassigned cells are zero, prover.rs:424).
+    `msm(coeffs, bases) -> Jacobian` lets tests swap in a faster multiexp.
+    """
+    msm = msm or best_multiexp
+    cs = pk.circuit
+    dom = pk.domain
+    n = dom.n
+    bf = cs.blinding_factors()
+    u = n - (bf + 1)
+    tr = Blake2bWrite()
+    out = ProofTrace()
+
+    def commit_affine(jac):
+        return jac_to_affine(jac)
+
+    # prover.rs:85
+    tr.common_scalar(pk.vk_repr)
+
+    # ---- phase 0 advice (prover.rs:299-391); no instances -------------------
+    advice = []
+    for c in range(cs.num_advice):
+        col = list(advice_usable[c]) + [0] * (u - len(advice_usable[c]))
+        assert len(col) == u, "advice assigned outside usable rows"
+        advice.append([v % P for v in col] + [0] * (n - u))
+    for c in range(cs.num_advice):  # :346-350
+        for r in range(u, n):
+            advice[c][r] = fr_random(rng)
+    for c in range(cs.num_advice):  # :352-355 (blinds drawn, unused by KZG)
+        fr_random(rng)
+    adv_cm = batch_to_affine([msm(advice[c], params.g_lagrange) for c in range(cs.num_advice)])
+    for A in adv_cm:
+        tr.write_point(A)
+    out.points["advice"] = adv_cm
+
+    theta = tr.squeeze_challenge_scalar()  # :472
+    out.challenges["theta"] = theta
+
+    # ---- CQ round 1 (static_lookup/prover.rs:51-183) -----------------------
+    committed = []
+    for li, lk in enumerate(cs.lookups):
+        tables = [pk.tables[tid] for _, tid in lk]
+        assert all(t.size == tables[0].size for t in tables)
+        exprs = [advice[col] for col, _ in lk]
+        f = [0] * n
+        for e in exprs:  # :108-116
+            f = [(a * theta + b) % P for a, b in zip(f, e)]
+        m_sparse = {}
+        tivm = [dict() for _ in tables]
+        for row in range(u):  # :132-161
+            idx = None
+            for ti, (e, t) in enumerate(zip(exprs, tables)):
+                fi = e[row]
+                if fi not in t.value_index_mapping:
+                    raise KeyError(f"{fi} not in table")
+                index = t.value_index_mapping[fi]
+                tivm[ti][index] = fi
+                if idx is not None and idx != index:
+                    raise ValueError("Vector lookup must be on the same table row")
+                idx = index
+            m_sparse[idx] = m_sparse.get(idx, 0) + 1
+        f_cm = commit_affine(msm(f, params.g_lagrange))
+        m_cm = JAC_ID
+        for index in sorted(m_sparse):  # :167-170
+            m_cm = jac_add(jac_mul(to_jac(pk.table_cfg.g1_lagrange[index]), m_sparse[index]), m_cm)
+        m_cm = commit_affine(m_cm)
+        tr.write_point(f_cm)
+        tr.write_point(m_cm)
+        out.points[f"f_cm{li}"] = f_cm
+        out.points[f"m_cm{li}"] = m_cm
+        committed.append((f, m_sparse, tables, tivm))
+
+    beta = tr.squeeze_challenge_scalar()  # :529
+    gamma = tr.squeeze_challenge_scalar()  # :532
+    out.challenges["beta"] = beta
+    out.challenges["gamma"] = gamma
+
+    # ---- CQ round 2 (static_lookup/prover.rs:187-342) ----------------------
+    logd = []
+    size_n = pk.table_cfg.size
+    for li, (f, m_sparse, tables, tivm) in enumerate(committed):
+        a_cm = JAC_ID
+        qa_cm = JAC_ID
+        a0_cm = JAC_ID
+        f_set = set(f)
+        for index in sorted(m_sparse):  # :245-257
+            tv = 0
+            tq = JAC_ID
+            for ti, t in enumerate(tables):  # compress_tables :224-240
+                tv = (tv * theta + tivm[ti][index]) % P
+                tq = jac_add(jac_mul(tq, theta), to_jac(t.qs[index]))
+            a_i = m_sparse[index] * inv_mod((tv + beta) % P, P) % P
+            assert tv in f_set  # :250
+            a_cm = jac_add(jac_mul(to_jac(pk.table_cfg.g1_lagrange[index]), a_i), a_cm)
+            qa_cm = jac_add(jac_mul(tq, a_i), qa_cm)
+            a0_cm = jac_add(jac_mul(to_jac(pk.table_cfg.g_lagrange_opening_at_0[index]), a_i), a0_cm)
+        bs = [inv_mod((fi + beta) % P, P) for fi in f[:u]]  # :261-266
+        beta_inv = inv_mod(beta, P)
+        bs += [beta_inv] * (bf + 1)  # :268-269
+        b_poly = dom.ifft(bs, dom.omega_inv, dom.k, dom.ifft_divisor)  # :271-276
+        b0 = b_poly[1:]  # :279
+        p_cm = commit_affine(msm(b0, pk.b0_g1_bound))  # :299
+        b0 = b0 + [0]  # :301
+        for Pt in (a_cm, qa_cm, a0_cm):  # :306-308
+            tr.write_point(commit_affine(Pt))
+        b0_cm = commit_affine(msm(b0, params.g))  # :310
+        tr.write_point(b0_cm)  # :312
+        tr.write_point(p_cm)  # :313
+        out.points[f"a_cm{li}"] = commit_affine(a_cm)
+        out.points[f"qa_cm{li}"] = commit_affine(qa_cm)
+        out.points[f"a0_cm{li}"] = commit_affine(a0_cm)
+        out.points[f"b0_cm{li}"] = b0_cm
+        out.points[f"p_cm{li}"] = p_cm
+        b_at_zero = b_poly[0]  # :318
+        a_at_zero = (b_at_zero * n - (bf + 1) * beta_inv) % P * inv_mod(size_n % P, P) % P  # :319-324
+        f_coeff = dom.lagrange_to_coeff(f)  # :326-334
+        logd.append((b_poly, b0, f_coeff, a_at_zero))
+        out.polys[f"b{li}"] = b_poly
+        out.polys[f"f{li}"] = f_coeff
+
+    # ---- vanishing commit (vanishing/prover.rs:37-65) ----------------------
+    random_poly = [fr_random(rng) for _ in range(n)]
+    fr_random(rng)  # random_blind
+    rnd_cm = commit_affine(msm(random_poly, params.g))
+    tr.write_point(rnd_cm)
+    out.points["random"] = rnd_cm
+
+    y = tr.squeeze_challenge_scalar()  # prover.rs:584
+    out.challenges["y"] = y
+
+    advice_polys = [dom.lagrange_to_coeff(a) for a in advice]  # :587-603
+
+    # ---- evaluate_h (evaluation.rs:285-551): no gates => only the CQ term ---
+    # (advice cosets are computed by the reference at :317-325 but feed nothing here)
+    ext = dom.extended_len
+    h = [0] * ext
+    for (b_poly, _b0, f_coeff, _a0) in logd:  # :533-548
+        b_coset = dom.coeff_to_extended(b_poly)
+        f_coset = dom.coeff_to_extended(f_coeff)
+        h = [
+            (hv * y + (bc * ((fc * la + beta) % P) - 1)) % P
+            for hv, bc, fc, la in zip(h, b_coset, f_coset, pk.l_active_row)
+        ]
+    out.polys["h_ext"] = h
+
+    # ---- vanishing construct (vanishing/prover.rs:69-120) -------------------
+    h = dom.divide_by_vanishing_poly(h)
+    h_coeff = dom.extended_to_coeff(h)
+    h_pieces = [h_coeff[i : i + n] for i in range(0, len(h_coeff) - n + 1, n)]
+    for _ in h_pieces:
+        fr_random(rng)  # h_blinds
+    h_cms = batch_to_affine([msm(piece, params.g) for piece in h_pieces])
+    for A in h_cms:
+        tr.write_point(A)
+    out.points["h"] = h_cms
+    out.polys["h_pieces"] = h_pieces
+
+    x = tr.squeeze_challenge_scalar()  # prover.rs:629
+    xn = pow(x, n, P)
+    out.challenges["x"] = x
+
+    # ---- evaluations (prover.rs:654-719) ------------------------------------
+    aq = cs.advice_queries()
+    for col, rot in aq:
+        tr.write_scalar(eval_polynomial(advice_polys[col], dom.rotate_omega(x, rot)))
+    # vanishing.evaluate (vanishing/prover.rs:124-153)
+    h_poly = [0] * n
+    for piece in reversed(h_pieces):
+        h_poly = [(a * xn + b) % P for a, b in zip(h_poly, piece)]
+    tr.write_scalar(eval_polynomial(random_poly, x))
+    for (b_poly, b0, f_coeff, a_at_zero) in logd:  # static_lookup/prover.rs:360-370
+        tr.write_scalar(eval_polynomial(b0, x))
+        tr.write_scalar(eval_polynomial(f_coeff, x))
+        tr.write_scalar(a_at_zero)
+
+    # ---- multiopen GWC (prover.rs:721-778, gwc/prover.rs:42-91) -------------
+    queries = []
+    for col, rot in aq:
+        queries.append((dom.rotate_omega(x, rot), advice_polys[col]))
+    for (b_poly, b0, f_coeff, _a) in logd:
+        queries.append((x, b0))
+        queries.append((x, f_coeff))
+    queries.append((x, h_poly))
+    queries.append((x, random_poly))
+    v = tr.squeeze_challenge_scalar()
+    out.challenges["v"] = v
+    groups = []  # gwc.rs:36-61 first-seen order
+    for pt, poly in queries:
+        for g in groups:
+            if g[0] == pt:
+                g[1].append(poly)
+                break
+        else:
+            groups.append((pt, [poly]))
+    ws = []
+    for z, polys in groups:
+        acc = [0] * n
+        eacc = 0
+        pv = 1
+        for poly in polys:
+            ev = eval_polynomial(poly, z)
+            acc = [(a + b * pv) % P for a, b in zip(acc, poly)]
+            eacc = (eacc + ev * pv) % P
+            pv = pv * v % P
+        acc[0] = (acc[0] - eacc) % P  # `&poly_batch - eval_batch` subtracts from the constant term
+        wit = kate_division(acc, z)
+        w = commit_affine(msm(wit, params.g[: len(wit)]))
+        tr.write_point(w)
+        ws.append(w)
+    out.points["w"] = ws
+    out.proof = bytes(tr.proof)
+    return out
