@@ -1,0 +1,78 @@
+/*
+ * cq_halo2.h -- C ABI of the MI355X (gfx950) backend for the CQ-lookup / KZG
+ * polynomial-commitment hot path of halo2_proofs::plonk::create_proof.
+ *
+ * The reference (aleph-zero-foundation/sha2-on-cq-halo2) is 100 % Rust and has no FFI
+ * seam; each entry point below replaces one Rust function that `create_proof` and its
+ * sub-arguments call (cited as file:line under halo2_proofs/src unless noted).  The Rust
+ * binding a maintainer would add is sketched in INTEGRATION.md.
+ *
+ * Conventions
+ *  - Field elements: 4 x uint64_t little-endian limbs of a*2^256 mod p (Montgomery form),
+ *    byte-identical to halo2curves `Fr([u64;4])` / `Fq([u64;4])` (arithmetic/curves/src/bn256/fr.rs:25).
+ *  - G1 affine: 8 x uint64_t = x || y, identity = all zero (derive/curve.rs:453-463).
+ *  - G1 Jacobian: 12 x uint64_t = x || y || z, identity z = 0 (derive/curve.rs:696-705).
+ *  - Every function returns CQ_OK (0) or a negative status; nothing unwinds or aborts across
+ *    the boundary (the Rust side panics on these contract violations: arithmetic.rs:133,184).
+ *  - `_dev` entry points take DEVICE pointers (hipMalloc / cq_dev_alloc / a torch tensor's
+ *    data_ptr) and run asynchronously on the context's stream; the others take host slices,
+ *    like the Rust functions they replace, and return after the result is in host memory.
+ *  - A context is bound to one GPU and one HIP stream and may be used by one thread at a
+ *    time (create_proof calls these serially, plonk/prover.rs:51-779); use one context per
+ *    thread / per rank for concurrency.
+ */
+#ifndef CQ_HALO2_H
+#define CQ_HALO2_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CQ_OK 0
+#define CQ_ERR_ARG (-1)      /* bad argument (length mismatch, not a power of two, null pointer) */
+#define CQ_ERR_HIP (-2)      /* HIP runtime failure; see cq_last_error */
+#define CQ_ERR_NO_DEVICE (-3)
+#define CQ_ERR_LOOKUP (-4)   /* CQ: witness value not in table / vector lookup on different rows */
+#define CQ_ERR_INTERNAL (-5)
+
+typedef struct cq_ctx cq_ctx;
+typedef struct cq_domain cq_domain;   /* EvaluationDomain<Fr>, poly/domain.rs:19-34 */
+typedef struct cq_params cq_params;   /* ParamsKZG<Bn256> G1 part, poly/kzg/commitment.rs:31-39 */
+
+/* ---- context ------------------------------------------------------------------------- */
+/* `hip_stream` may be NULL (the library creates its own stream) or an existing hipStream_t
+ * (e.g. torch.cuda.current_stream().cuda_stream) that all work is then enqueued on. */
+int cq_ctx_create(int device, void* hip_stream, cq_ctx** out);
+void cq_ctx_destroy(cq_ctx* ctx);
+const char* cq_last_error(const cq_ctx* ctx);
+int cq_ctx_sync(cq_ctx* ctx);
+void* cq_ctx_stream(cq_ctx* ctx);
+const char* cq_version(void);
+
+/* ---- device memory (plumbing) ------------------------------------------------------------ */
+int cq_dev_alloc(cq_ctx* ctx, size_t bytes, void** dptr);
+int cq_dev_free(cq_ctx* ctx, void* dptr);
+int cq_dev_upload(cq_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
+int cq_dev_download(cq_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
+int cq_dev_memset(cq_ctx* ctx, void* dptr, int value, size_t bytes);
+
+/* ---- arithmetic.rs ------------------------------------------------------------------- */
+/* best_fft(a, omega, log_n)  arithmetic.rs:171-234.  In place on a host slice of 2^log_n Fr,
+ * natural order in and out. */
+int cq_best_fft(cq_ctx* ctx, uint64_t* a, uint32_t log_n, const uint64_t omega[4]);
+/* Same on device memory; `out` != `in`, both 2^log_n elements; `in` is preserved. */
+int cq_best_fft_dev(cq_ctx* ctx, const uint64_t* in_dev, uint64_t* out_dev, uint32_t log_n,
+                    const uint64_t omega[4]);
+
+/* ---- microbenchmarks (measurement support, not part of the drop-in surface) -------------- */
+/* Runs `iters` dependent Montgomery multiplications per lane over `lanes` lanes and writes one
+ * folded element per lane; used to measure the chip's 256-bit modmul rate. which: 0 = Fr, 1 = Fq */
+int cq_bench_modmul_dev(cq_ctx* ctx, uint64_t* out_dev, uint32_t lanes, uint32_t iters, int which);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CQ_HALO2_H */

@@ -1,0 +1,63 @@
+"""ctypes loader for libcq_halo2.so.  Fails loudly if the HIP extension is missing: there is
+no CPU fallback anywhere in this package."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import re
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libcq_halo2.so")
+HEADER = os.path.join(HERE, "..", "include", "cq_halo2.h")
+
+_lib = None
+
+
+class CqError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"cq_halo2 error {code}: {msg}")
+        self.code = code
+
+
+def load() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} not found: build it with `python -m sha2_on_cq_halo2_amd.build` "
+                "(hipcc, gfx950).  This package has no CPU fallback."
+            )
+        _lib = C.CDLL(LIB_PATH)
+        _declare(_lib)
+    return _lib
+
+
+def header_symbols():
+    """Every function name declared in include/cq_halo2.h."""
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(cq_[a-z0-9_]+)\s*\(", src)))
+
+
+u64p = C.POINTER(C.c_uint64)
+vp = C.c_void_p
+
+
+def _declare(lib):
+    lib.cq_version.restype = C.c_char_p
+    lib.cq_last_error.restype = C.c_char_p
+    lib.cq_last_error.argtypes = [vp]
+    lib.cq_ctx_stream.restype = vp
+    lib.cq_ctx_stream.argtypes = [vp]
+    lib.cq_ctx_destroy.restype = None
+    lib.cq_ctx_destroy.argtypes = [vp]
+    lib.cq_ctx_create.argtypes = [C.c_int, vp, C.POINTER(vp)]
+    lib.cq_ctx_sync.argtypes = [vp]
+    lib.cq_dev_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
+    lib.cq_dev_free.argtypes = [vp, vp]
+    lib.cq_dev_upload.argtypes = [vp, vp, vp, C.c_size_t]
+    lib.cq_dev_download.argtypes = [vp, vp, vp, C.c_size_t]
+    lib.cq_dev_memset.argtypes = [vp, vp, C.c_int, C.c_size_t]
+    lib.cq_best_fft.argtypes = [vp, vp, C.c_uint32, vp]
+    lib.cq_best_fft_dev.argtypes = [vp, vp, vp, C.c_uint32, vp]
+    lib.cq_bench_modmul_dev.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_int]

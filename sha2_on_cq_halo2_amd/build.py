@@ -1,0 +1,63 @@
+"""Builds libcq_halo2.so (HIP kernels + C ABI) in-tree for gfx950 with hipcc.
+
+The built library is git-ignored but travels to the GPU box with the gpurun snapshot.
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(CSRC, "build")
+LIB = os.path.join(HERE, "libcq_halo2.so")
+ARCH = "gfx950"
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value",
+         "-fno-gpu-rdc", "-I", os.path.join(HERE, "..", "include")]
+
+
+def sources():
+    return sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".cpp")))
+
+
+def _headers_mtime():
+    m = 0.0
+    for root in (CSRC, os.path.join(HERE, "..", "include")):
+        for f in os.listdir(root):
+            if f.endswith((".hpp", ".h")):
+                m = max(m, os.path.getmtime(os.path.join(root, f)))
+    return m
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    os.makedirs(OBJ, exist_ok=True)
+    hdr = _headers_mtime()
+    jobs = []
+    objs = []
+    for src in sources():
+        sp = os.path.join(CSRC, src)
+        op = os.path.join(OBJ, os.path.splitext(src)[0] + ".o")
+        objs.append(op)
+        if force or not os.path.exists(op) or os.path.getmtime(op) < max(os.path.getmtime(sp), hdr):
+            cmd = [HIPCC] + FLAGS + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", sp, "-o", op]
+            jobs.append(cmd)
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + r.stdout + r.stderr)
+
+    with ThreadPoolExecutor(max_workers=min(4, max(1, len(jobs)))) as ex:
+        list(ex.map(run, jobs))
+    if jobs or not os.path.exists(LIB):
+        run([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,142 @@
+// C ABI: context, device memory, arithmetic.rs entry points.  See include/cq_halo2.h.
+#include "ctx.hpp"
+#include <cstring>
+
+using namespace cq;
+
+const NttTables* cq_ctx::tables_for(uint32_t log_n, const Fr& omega, int* rc) {
+  for (auto& t : ntt_cache)
+    if (t->log_n == log_n && t->omega == omega) return t.get();
+  if (ntt_cache.size() >= 16) {
+    hipStreamSynchronize(stream);
+    ntt_cache.erase(ntt_cache.begin());
+  }
+  auto t = std::make_unique<NttTables>();
+  if (t->build(log_n, omega, stream) != 0) {
+    *rc = fail(CQ_ERR_HIP, "building NTT twiddle tables failed");
+    return nullptr;
+  }
+  ntt_cache.push_back(std::move(t));
+  return ntt_cache.back().get();
+}
+
+extern "C" {
+
+const char* cq_version(void) { return "cq_halo2_amd 0.1 (gfx950)"; }
+
+int cq_ctx_create(int device, void* hip_stream, cq_ctx** out) {
+  if (!out) return CQ_ERR_ARG;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count)
+    return CQ_ERR_NO_DEVICE;
+  if (hipSetDevice(device) != hipSuccess) return CQ_ERR_HIP;
+  cq_ctx* c = new cq_ctx();
+  c->device = device;
+  if (hip_stream) {
+    c->stream = (hipStream_t)hip_stream;
+  } else {
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+      delete c;
+      return CQ_ERR_HIP;
+    }
+    c->own_stream = true;
+  }
+  *out = c;
+  return CQ_OK;
+}
+
+void cq_ctx_destroy(cq_ctx* c) {
+  if (!c) return;
+  hipSetDevice(c->device);
+  hipStreamSynchronize(c->stream);
+  c->ntt_cache.clear();
+  for (int i = 0; i < cq_ctx::NSCRATCH; i++)
+    if (c->scratch[i]) hipFree(c->scratch[i]);
+  if (c->pinned) hipHostFree(c->pinned);
+  if (c->own_stream) hipStreamDestroy(c->stream);
+  delete c;
+}
+
+const char* cq_last_error(const cq_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+int cq_ctx_sync(cq_ctx* c) {
+  if (!c) return CQ_ERR_ARG;
+  CQ_HIP(c, hipStreamSynchronize(c->stream));
+  return CQ_OK;
+}
+
+void* cq_ctx_stream(cq_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+int cq_dev_alloc(cq_ctx* c, size_t bytes, void** dptr) {
+  if (!c || !dptr) return CQ_ERR_ARG;
+  CQ_HIP(c, hipSetDevice(c->device));
+  CQ_HIP(c, hipMalloc(dptr, bytes ? bytes : 1));
+  return CQ_OK;
+}
+int cq_dev_free(cq_ctx* c, void* dptr) {
+  if (!c) return CQ_ERR_ARG;
+  if (!dptr) return CQ_OK;
+  CQ_HIP(c, hipStreamSynchronize(c->stream));
+  CQ_HIP(c, hipFree(dptr));
+  return CQ_OK;
+}
+int cq_dev_upload(cq_ctx* c, void* dst, const void* src, size_t bytes) {
+  if (!c || (!dst && bytes) || (!src && bytes)) return CQ_ERR_ARG;
+  if (!bytes) return CQ_OK;
+  CQ_HIP(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+  CQ_HIP(c, hipStreamSynchronize(c->stream));
+  return CQ_OK;
+}
+int cq_dev_download(cq_ctx* c, void* dst, const void* src, size_t bytes) {
+  if (!c || (!dst && bytes) || (!src && bytes)) return CQ_ERR_ARG;
+  if (!bytes) return CQ_OK;
+  CQ_HIP(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+  CQ_HIP(c, hipStreamSynchronize(c->stream));
+  return CQ_OK;
+}
+int cq_dev_memset(cq_ctx* c, void* dptr, int value, size_t bytes) {
+  if (!c || (!dptr && bytes)) return CQ_ERR_ARG;
+  if (!bytes) return CQ_OK;
+  CQ_HIP(c, hipMemsetAsync(dptr, value, bytes, c->stream));
+  return CQ_OK;
+}
+
+// ---- best_fft -------------------------------------------------------------------------------
+static int fft_dev(cq_ctx* c, const Fr* in, Fr* out, uint32_t log_n, const Fr& omega) {
+  int rc = CQ_OK;
+  const NttTables* tb = c->tables_for(log_n, omega, &rc);
+  if (!tb) return rc;
+  void* scr;
+  const size_t n = (size_t)1 << log_n;
+  if ((rc = c->ensure_scratch(0, n * sizeof(Fr), &scr)) != CQ_OK) return rc;
+  NttIo io;
+  io.in_len = io.out_len = (uint32_t)n;
+  io.in_stride = io.out_stride = io.scratch_stride = n;
+  if (ntt_run(*tb, in, out, (Fr*)scr, io, c->stream) != 0) return c->fail(CQ_ERR_HIP, "ntt launch failed");
+  return CQ_OK;
+}
+
+int cq_best_fft_dev(cq_ctx* c, const uint64_t* in_dev, uint64_t* out_dev, uint32_t log_n,
+                    const uint64_t omega[4]) {
+  if (!c || !in_dev || !out_dev || !omega || log_n > FR_S) return CQ_ERR_ARG;
+  if ((const void*)in_dev == (void*)out_dev) return c->fail(CQ_ERR_ARG, "in and out must differ");
+  CQ_HIP(c, hipSetDevice(c->device));
+  return fft_dev(c, (const Fr*)in_dev, (Fr*)out_dev, log_n, Fr::from_limbs64(omega));
+}
+
+int cq_best_fft(cq_ctx* c, uint64_t* a, uint32_t log_n, const uint64_t omega[4]) {
+  if (!c || !a || !omega || log_n > FR_S) return CQ_ERR_ARG;
+  CQ_HIP(c, hipSetDevice(c->device));
+  const size_t bytes = ((size_t)1 << log_n) * sizeof(Fr);
+  void *din, *dout;
+  int rc;
+  if ((rc = c->ensure_scratch(1, bytes, &din)) != CQ_OK) return rc;
+  if ((rc = c->ensure_scratch(2, bytes, &dout)) != CQ_OK) return rc;
+  CQ_HIP(c, hipMemcpyAsync(din, a, bytes, hipMemcpyHostToDevice, c->stream));
+  if ((rc = fft_dev(c, (const Fr*)din, (Fr*)dout, log_n, Fr::from_limbs64(omega))) != CQ_OK) return rc;
+  CQ_HIP(c, hipMemcpyAsync(a, dout, bytes, hipMemcpyDeviceToHost, c->stream));
+  CQ_HIP(c, hipStreamSynchronize(c->stream));
+  return CQ_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,70 @@
+// Library context: one GPU, one stream, grow-only scratch buffers, cached NTT tables.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <memory>
+#include <string>
+#include <vector>
+#include "../../include/cq_halo2.h"
+#include "field.hpp"
+#include "ntt.hpp"
+
+struct cq_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  std::string err;
+  std::vector<std::unique_ptr<cq::NttTables>> ntt_cache;
+  static constexpr int NSCRATCH = 8;
+  void* scratch[NSCRATCH] = {};
+  size_t scratch_bytes[NSCRATCH] = {};
+  void* pinned = nullptr;  // small pinned host staging buffer
+  size_t pinned_bytes = 0;
+
+  int fail(int code, const std::string& msg) {
+    err = msg;
+    return code;
+  }
+  int hip_fail(hipError_t e, const char* what) {
+    err = std::string(what) + ": " + hipGetErrorString(e);
+    return CQ_ERR_HIP;
+  }
+  // grow-only scratch slot
+  int ensure_scratch(int slot, size_t bytes, void** out) {
+    if (scratch_bytes[slot] < bytes) {
+      if (scratch[slot]) {
+        hipStreamSynchronize(stream);
+        hipFree(scratch[slot]);
+        scratch[slot] = nullptr;
+        scratch_bytes[slot] = 0;
+      }
+      size_t want = bytes < (1u << 20) ? (1u << 20) : bytes;
+      hipError_t e = hipMalloc(&scratch[slot], want);
+      if (e != hipSuccess) return hip_fail(e, "hipMalloc(scratch)");
+      scratch_bytes[slot] = want;
+    }
+    *out = scratch[slot];
+    return CQ_OK;
+  }
+  int ensure_pinned(size_t bytes, void** out) {
+    if (pinned_bytes < bytes) {
+      if (pinned) {
+        hipStreamSynchronize(stream);
+        hipHostFree(pinned);
+        pinned = nullptr;
+        pinned_bytes = 0;
+      }
+      hipError_t e = hipHostMalloc(&pinned, bytes, hipHostMallocDefault);
+      if (e != hipSuccess) return hip_fail(e, "hipHostMalloc");
+      pinned_bytes = bytes;
+    }
+    *out = pinned;
+    return CQ_OK;
+  }
+  const cq::NttTables* tables_for(uint32_t log_n, const cq::Fr& omega, int* rc);
+};
+
+#define CQ_HIP(ctx, call)                                   \
+  do {                                                      \
+    hipError_t _e = (call);                                 \
+    if (_e != hipSuccess) return (ctx)->hip_fail(_e, #call); \
+  } while (0)

@@ -1,0 +1,251 @@
+// BN254 Fr / Fq arithmetic for gfx950 (and the host side of this library).
+//
+// Values are Montgomery residues a*2^256 mod p kept as eight 32-bit limbs whose byte image is
+// identical to the reference's `[u64;4]` little-endian limbs (arithmetic/curves/src/bn256/fr.rs:25,
+// fq.rs:25), so buffers cross the C ABI without conversion.  All results are fully reduced
+// (< p), like the reference's `add/sub/mul/montgomery_reduce` (derive/field.rs:351-616): the
+// byte image of every output is therefore identical to the reference's.
+//
+// Why 32-bit limbs: CDNA4's integer multiplier is 32x32 (v_mad_u64_u32 / v_mul_hi_u32); a 256-bit
+// Montgomery product is 2*64 of those plus carries.  No MFMA path applies to modular integers.
+#pragma once
+#include <stdint.h>
+#include <stddef.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define CQ_HD __host__ __device__ __forceinline__
+#define CQ_UNROLL _Pragma("unroll")
+#else
+#define CQ_HD inline
+#define CQ_UNROLL
+#endif
+
+namespace cq {
+
+struct alignas(16) U256 {
+  uint32_t l[8];
+};
+
+// ---- moduli (constants from bn256/fr.rs:29-66 and bn256/fq.rs:29-58, split into 32-bit limbs) ----
+struct FrP {
+  static constexpr uint32_t MOD[8] = {0xf0000001u, 0x43e1f593u, 0x79b97091u, 0x2833e848u,
+                                      0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
+  static constexpr uint32_t INV = 0xefffffffu;  // low word of fr.rs:39
+  static constexpr uint32_t R[8] = {0x4ffffffbu, 0xac96341cu, 0x9f60cd29u, 0x36fc7695u,
+                                    0x7879462eu, 0x666ea36fu, 0x9a07df2fu, 0x0e0a77c1u};
+  static constexpr uint32_t R2[8] = {0xae216da7u, 0x1bb8e645u, 0xe35c59e3u, 0x53fe3ab1u,
+                                     0x53bb8085u, 0x8c49833du, 0x7f4e44a5u, 0x0216d0b1u};
+  static constexpr uint32_t R3[8] = {0xb4bf0040u, 0x5e94d8e1u, 0x1cfbb6b8u, 0x2a489cbeu,
+                                     0xa19fcfedu, 0x893cc664u, 0x7fcc657cu, 0x0cf8594bu};
+};
+
+struct FqP {
+  static constexpr uint32_t MOD[8] = {0xd87cfd47u, 0x3c208c16u, 0x6871ca8du, 0x97816a91u,
+                                      0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
+  static constexpr uint32_t INV = 0xe4866389u;  // low word of fq.rs:37
+  static constexpr uint32_t R[8] = {0xc58f0d9du, 0xd35d438du, 0xf5c70b3du, 0x0a78eb28u,
+                                    0x7879462cu, 0x666ea36fu, 0x9a07df2fu, 0x0e0a77c1u};
+  static constexpr uint32_t R2[8] = {0x538afa89u, 0xf32cfc5bu, 0xd44501fbu, 0xb5e71911u,
+                                     0x0a417ff6u, 0x47ab1effu, 0xcab8351fu, 0x06d89f71u};
+  static constexpr uint32_t R3[8] = {0xda1530dfu, 0xb1cd6dafu, 0xa7283db6u, 0x62f210e6u,
+                                     0x0ada0afbu, 0xef7f0b0cu, 0x2d592544u, 0x20fd6e90u};
+};
+
+template <class P>
+struct Fp {
+  U256 v;
+
+  static CQ_HD Fp zero() {
+    Fp r;
+    CQ_UNROLL for (int i = 0; i < 8; i++) r.v.l[i] = 0;
+    return r;
+  }
+  static CQ_HD Fp one() {
+    Fp r;
+    CQ_UNROLL for (int i = 0; i < 8; i++) r.v.l[i] = P::R[i];
+    return r;
+  }
+  static CQ_HD Fp r2() {
+    Fp r;
+    CQ_UNROLL for (int i = 0; i < 8; i++) r.v.l[i] = P::R2[i];
+    return r;
+  }
+  static CQ_HD Fp r3() {
+    Fp r;
+    CQ_UNROLL for (int i = 0; i < 8; i++) r.v.l[i] = P::R3[i];
+    return r;
+  }
+  static CQ_HD Fp from_limbs64(const uint64_t* s) {
+    Fp r;
+    CQ_UNROLL for (int i = 0; i < 4; i++) {
+      r.v.l[2 * i] = (uint32_t)s[i];
+      r.v.l[2 * i + 1] = (uint32_t)(s[i] >> 32);
+    }
+    return r;
+  }
+  CQ_HD void to_limbs64(uint64_t* d) const {
+    CQ_UNROLL for (int i = 0; i < 4; i++) d[i] = (uint64_t)v.l[2 * i] | ((uint64_t)v.l[2 * i + 1] << 32);
+  }
+
+  CQ_HD bool is_zero() const {
+    uint32_t o = 0;
+    CQ_UNROLL for (int i = 0; i < 8; i++) o |= v.l[i];
+    return o == 0;
+  }
+  CQ_HD bool operator==(const Fp& b) const {
+    uint32_t o = 0;
+    CQ_UNROLL for (int i = 0; i < 8; i++) o |= v.l[i] ^ b.v.l[i];
+    return o == 0;
+  }
+  CQ_HD bool operator!=(const Fp& b) const { return !(*this == b); }
+
+  // r = a - p if a >= p (a < 2p assumed)
+  static CQ_HD void cond_sub_p(uint32_t* a, uint32_t top) {
+    uint32_t t[8];
+    uint64_t br = 0;
+    CQ_UNROLL for (int i = 0; i < 8; i++) {
+      uint64_t d = (uint64_t)a[i] - P::MOD[i] - br;
+      t[i] = (uint32_t)d;
+      br = (d >> 32) & 1;
+    }
+    // take t if (top:a) >= p  <=> top != 0 or no borrow
+    bool ge = top || !br;
+    CQ_UNROLL for (int i = 0; i < 8; i++) a[i] = ge ? t[i] : a[i];
+  }
+
+  CQ_HD Fp operator+(const Fp& b) const {
+    Fp r;
+    uint64_t c = 0;
+    CQ_UNROLL for (int i = 0; i < 8; i++) {
+      c += (uint64_t)v.l[i] + b.v.l[i];
+      r.v.l[i] = (uint32_t)c;
+      c >>= 32;
+    }
+    cond_sub_p(r.v.l, (uint32_t)c);  // p < 2^254 so c is always 0, kept for generality
+    return r;
+  }
+  CQ_HD Fp operator-(const Fp& b) const {
+    Fp r;
+    uint64_t br = 0;
+    CQ_UNROLL for (int i = 0; i < 8; i++) {
+      uint64_t d = (uint64_t)v.l[i] - b.v.l[i] - br;
+      r.v.l[i] = (uint32_t)d;
+      br = (d >> 32) & 1;
+    }
+    uint32_t mask = (uint32_t)0 - (uint32_t)br;
+    uint64_t c = 0;
+    CQ_UNROLL for (int i = 0; i < 8; i++) {
+      c += (uint64_t)r.v.l[i] + (P::MOD[i] & mask);
+      r.v.l[i] = (uint32_t)c;
+      c >>= 32;
+    }
+    return r;
+  }
+  CQ_HD Fp neg() const { return zero() - *this; }
+  CQ_HD Fp dbl() const { return *this + *this; }
+
+  // Montgomery product, CIOS over 32-bit limbs (same function as derive/field.rs:471-564).
+  CQ_HD Fp operator*(const Fp& b) const {
+    uint32_t t[10];
+    CQ_UNROLL for (int i = 0; i < 10; i++) t[i] = 0;
+    CQ_UNROLL for (int i = 0; i < 8; i++) {
+      uint64_t c = 0;
+      const uint32_t bi = b.v.l[i];
+      CQ_UNROLL for (int j = 0; j < 8; j++) {
+        c += (uint64_t)v.l[j] * bi + t[j];
+        t[j] = (uint32_t)c;
+        c >>= 32;
+      }
+      c += t[8];
+      t[8] = (uint32_t)c;
+      t[9] = (uint32_t)(c >> 32);
+      const uint32_t m = t[0] * P::INV;
+      c = (uint64_t)m * P::MOD[0] + t[0];
+      c >>= 32;
+      CQ_UNROLL for (int j = 1; j < 8; j++) {
+        c += (uint64_t)m * P::MOD[j] + t[j];
+        t[j - 1] = (uint32_t)c;
+        c >>= 32;
+      }
+      c += t[8];
+      t[7] = (uint32_t)c;
+      t[8] = t[9] + (uint32_t)(c >> 32);
+    }
+    Fp r;
+    CQ_UNROLL for (int i = 0; i < 8; i++) r.v.l[i] = t[i];
+    cond_sub_p(r.v.l, t[8]);
+    return r;
+  }
+  CQ_HD Fp sqr() const { return *this * *this; }
+
+  // canonical (non-Montgomery) value: a*R -> a   (`to_repr`, fr.rs:245-261)
+  CQ_HD U256 to_canonical() const {
+    Fp o;
+    CQ_UNROLL for (int i = 0; i < 8; i++) o.v.l[i] = (i == 0) ? 1u : 0u;
+    return (*this * o).v;
+  }
+  // canonical integer (< p) -> Montgomery   (`from_raw`, derive/field.rs:51-53)
+  static CQ_HD Fp from_canonical(const U256& a) {
+    Fp x;
+    x.v = a;
+    return x * r2();
+  }
+  static CQ_HD Fp from_u64(uint64_t a) {
+    U256 u;
+    CQ_UNROLL for (int i = 0; i < 8; i++) u.l[i] = 0;
+    u.l[0] = (uint32_t)a;
+    u.l[1] = (uint32_t)(a >> 32);
+    return from_canonical(u);
+  }
+  // `from_u512` (derive/field.rs:29-47): d0*R2 + d1*R3
+  static CQ_HD Fp from_u512(const uint64_t* w8) {
+    Fp d0 = from_limbs64(w8), d1 = from_limbs64(w8 + 4);
+    return d0 * r2() + d1 * r3();
+  }
+
+  // x^e, e given as 8 x 32-bit little-endian words
+  CQ_HD Fp pow(const uint32_t* e) const {
+    Fp acc = one();
+    for (int w = 7; w >= 0; w--) {
+      for (int bit = 31; bit >= 0; bit--) {
+        acc = acc.sqr();
+        if ((e[w] >> bit) & 1) acc = acc * *this;
+      }
+    }
+    return acc;
+  }
+  CQ_HD Fp pow_u64(uint64_t e) const {
+    Fp acc = one();
+    Fp base = *this;
+    while (e) {
+      if (e & 1) acc = acc * base;
+      base = base.sqr();
+      e >>= 1;
+    }
+    return acc;
+  }
+  // Fermat inversion a^(p-2) (fr.rs:200-209); inverse of zero is zero.
+  CQ_HD Fp inv() const {
+    uint32_t e[8];
+    CQ_UNROLL for (int i = 0; i < 8; i++) e[i] = P::MOD[i];
+    e[0] -= 2;  // low limb of both moduli is >= 2
+    return pow(e);
+  }
+};
+
+using Fr = Fp<FrP>;
+using Fq = Fp<FqP>;
+
+// field constants the protocol needs (bn256/fr.rs:72-118), canonical 64-bit limbs
+static constexpr uint32_t FR_S = 28;
+static constexpr uint64_t FR_ROOT_OF_UNITY_RAW[4] = {0xd34f1ed960c37c9cull, 0x3215cf6dd39329c8ull,
+                                                     0x98865ea93dd31f74ull, 0x03ddb9f5166d18b7ull};
+static constexpr uint64_t FR_ZETA_RAW[4] = {0xb8ca0b2d36636f23ull, 0xcc37a73fec2bc5e9ull,
+                                            0x048b6e193fd84104ull, 0x30644e72e131a029ull};
+
+inline Fr fr_from_raw(const uint64_t* raw) {
+  return Fr::from_limbs64(raw) * Fr::r2();
+}
+
+}  // namespace cq

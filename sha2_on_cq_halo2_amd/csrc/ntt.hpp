@@ -1,0 +1,66 @@
+// Internal interface of the NTT engine (see ntt.hip for the algorithm).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "field.hpp"
+
+namespace cq {
+
+constexpr uint32_t NTT_THREADS = 256;
+#ifndef CQ_NTT_MAX_DEG
+#define CQ_NTT_MAX_DEG 6
+#endif
+#ifndef CQ_NTT_TILE_ELEMS
+#define CQ_NTT_TILE_ELEMS 1024
+#endif
+constexpr uint32_t NTT_MAX_DEG = CQ_NTT_MAX_DEG;        // bits resolved per pass (2^deg-point FFT in LDS)
+constexpr uint32_t NTT_TILE_ELEMS = CQ_NTT_TILE_ELEMS;  // elements per workgroup tile (x32 B of LDS)
+
+enum : uint32_t { NTT_IN_COSET = 1, NTT_OUT_MUL = 2, NTT_OUT_COSET = 4 };
+
+struct NttPassArgs {
+  const Fr* in;
+  Fr* out;
+  size_t in_stride, out_stride;  // batch strides, in elements
+  uint32_t log_n, lgp, deg, log_t;
+  const Fr* tw_lo;  // w^j, j < 2^tw_l
+  const Fr* tw_hi;  // w^(j << tw_l)
+  uint32_t tw_l;
+  const Fr* pq;  // (w^(n >> pq_log))^j, j < 2^(pq_log-1)
+  uint32_t pq_shift;
+  uint32_t flags;
+  uint32_t in_len;   // first pass: elements >= in_len read as zero (zero padding)
+  uint32_t out_len;  // last pass: elements >= out_len are not written (truncation)
+  Fr in_coset[2];    // first pass: element g multiplied by in_coset[g%3 - 1] when g%3 != 0
+  Fr out_mul[3];     // last pass: element g multiplied by out_mul[g%3] (or out_mul[0] without OUT_COSET)
+};
+
+// Device-resident twiddles for one (log_n, omega).
+struct NttTables {
+  uint32_t log_n = 0;
+  Fr omega;
+  Fr* tw_lo = nullptr;
+  Fr* tw_hi = nullptr;
+  Fr* pq = nullptr;
+  uint32_t tw_l = 0, pq_log = 0;
+  NttTables() = default;
+  NttTables(const NttTables&) = delete;
+  NttTables& operator=(const NttTables&) = delete;
+  ~NttTables();
+  int build(uint32_t log_n, const Fr& omega, hipStream_t stream);
+};
+
+struct NttIo {
+  uint32_t batch = 1;
+  size_t in_stride = 0, out_stride = 0, scratch_stride = 0;
+  uint32_t in_len = 0, out_len = 0;
+  bool in_coset = false;
+  Fr in_coset_mul[2];
+  bool out_mul = false, out_coset = false;
+  Fr out_mul_v[3];
+};
+
+// out = NTT(in) over `tb`; `in`, `out`, `scratch` pairwise distinct, each batch x 2^log_n elements
+// (the input may be shorter: io.in_len).  The input is left untouched.
+int ntt_run(const NttTables& tb, const Fr* in, Fr* out, Fr* scratch, const NttIo& io, hipStream_t stream);
+
+}  // namespace cq

@@ -1,0 +1,53 @@
+"""GPU parity: HIP NTT (through the C ABI) vs the CPU oracle's restatement of `best_fft`."""
+import numpy as np
+import pytest
+
+from oracle import bn254 as B
+from oracle import poly as OP
+
+pytestmark = pytest.mark.gpu
+
+
+def _omega(log_n):
+    w = B.FR_ROOT_OF_UNITY
+    for _ in range(log_n, B.FR_S):
+        w = w * w % B.R_MOD
+    return w
+
+
+@pytest.mark.parametrize("log_n", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13])
+def test_best_fft_matches_oracle(ctx, log_n):
+    rng = B.Xoshiro256ss(100 + log_n)
+    n = 1 << log_n
+    vals = [B.fr_random(rng) for _ in range(n)]
+    w = _omega(log_n)
+    exp = OP.best_fft(list(vals), w, log_n)
+    got = ctx.best_fft(B.to_mont_limbs(vals), B.to_mont_limbs([w])[0], log_n)
+    assert np.array_equal(got, B.to_mont_limbs(exp))
+
+
+def test_best_fft_inverse_roundtrip_large(ctx):
+    """Size-independent property at a BASELINE size (k=18): iNTT(NTT(a)) * n^-1 == a."""
+    log_n = 18
+    n = 1 << log_n
+    rs = np.random.RandomState(5)
+    # random canonical-looking residues < 2^253 (valid Montgomery residues since < r)
+    a = rs.randint(0, 2**63, size=(n, 4), dtype=np.int64).astype(np.uint64)
+    a[:, 3] &= np.uint64((1 << 60) - 1)
+    w = _omega(log_n)
+    winv = pow(w, B.R_MOD - 2, B.R_MOD)
+    f = ctx.best_fft(a, B.to_mont_limbs([w])[0], log_n)
+    b = ctx.best_fft(f, B.to_mont_limbs([winv])[0], log_n)
+    # compare on a sample (python big-int conversion of 2^18 elements is slow)
+    idx = rs.randint(0, n, size=64)
+    ninv = pow(n, B.R_MOD - 2, B.R_MOD)
+    got = [v * ninv % B.R_MOD for v in B.from_mont_limbs(b[idx])]
+    exp = B.from_mont_limbs(a[idx])
+    assert got == exp
+
+
+def test_best_fft_len_mismatch(ctx):
+    from sha2_on_cq_halo2_amd import CqError
+
+    with pytest.raises(CqError):
+        ctx.best_fft(np.zeros((3, 4), dtype=np.uint64), np.zeros(4, dtype=np.uint64), 2)
