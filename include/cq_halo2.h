@@ -67,6 +67,37 @@ int cq_best_fft(cq_ctx* ctx, uint64_t* a, uint32_t log_n, const uint64_t omega[4
 int cq_best_fft_dev(cq_ctx* ctx, const uint64_t* in_dev, uint64_t* out_dev, uint32_t log_n,
                     const uint64_t omega[4]);
 
+/* best_multiexp(coeffs, bases)  arithmetic.rs:132-159.  sum_i coeffs[i] * bases[i] as a Jacobian
+ * point (the caller normalises, e.g. batch_normalize at plonk/prover.rs:363).  `len` is the common
+ * length of both slices (the Rust function asserts equality, arithmetic.rs:133). */
+int cq_best_multiexp(cq_ctx* ctx, const uint64_t* coeffs, const uint64_t* bases, size_t len,
+                     uint64_t out_jac[12]);
+/* Same with scalars and bases resident in device memory; the result is written to HOST memory
+ * (96 bytes) after the stream has drained. */
+int cq_best_multiexp_dev(cq_ctx* ctx, const uint64_t* coeffs_dev, const uint64_t* bases_dev, size_t len,
+                         uint64_t out_jac[12]);
+/* `count` multiexps over the same bases (e.g. all advice columns of a phase,
+ * plonk/prover.rs:356-360): `coeffs_dev` is a HOST array of `count` device pointers; one host
+ * synchronisation for the whole batch; out_jac = count x 12 limbs on the host. */
+int cq_msm_batch_dev(cq_ctx* ctx, const uint64_t* const* coeffs_dev, const uint64_t* bases_dev, size_t len,
+                     size_t count, uint64_t* out_jac);
+/* Pippenger window width in bits (2..15), 0 = automatic.  Tuning knob; results do not depend on it. */
+int cq_msm_set_window(cq_ctx* ctx, uint32_t bits);
+
+/* ---- poly/kzg/commitment.rs ---------------------------------------------------------------- */
+/* ParamsKZG (commitment.rs:31-39): uploads g = [s^i]_1 and g_lagrange = [L_i(s)]_1 (2^k affine
+ * points each, host memory, `RawBytes` layout) once; they stay resident in HBM. */
+int cq_params_create(cq_ctx* ctx, uint32_t k, const uint64_t* g, const uint64_t* g_lagrange, cq_params** out);
+void cq_params_destroy(cq_params* params);
+const uint64_t* cq_params_g_dev(const cq_params* params);
+const uint64_t* cq_params_g_lagrange_dev(const cq_params* params);
+/* ParamsKZG::commit (commitment.rs:539-543) / commit_lagrange (:496-504); the blind is ignored by
+ * the reference and has no parameter here.  `len` <= 2^k. */
+int cq_commit(cq_params* params, const uint64_t* poly, size_t len, uint64_t out_jac[12]);
+int cq_commit_lagrange(cq_params* params, const uint64_t* poly, size_t len, uint64_t out_jac[12]);
+int cq_commit_dev(cq_params* params, const uint64_t* poly_dev, size_t len, uint64_t out_jac[12]);
+int cq_commit_lagrange_dev(cq_params* params, const uint64_t* poly_dev, size_t len, uint64_t out_jac[12]);
+
 /* ---- microbenchmarks (measurement support, not part of the drop-in surface) -------------- */
 /* Runs `iters` dependent Montgomery multiplications per lane over `lanes` lanes and writes one
  * folded element per lane; used to measure the chip's 256-bit modmul rate. which: 0 = Fr, 1 = Fq */

@@ -61,3 +61,27 @@ def _declare(lib):
     lib.cq_best_fft.argtypes = [vp, vp, C.c_uint32, vp]
     lib.cq_best_fft_dev.argtypes = [vp, vp, vp, C.c_uint32, vp]
     lib.cq_bench_modmul_dev.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_int]
+
+
+def _declare_msm(lib):
+    lib.cq_best_multiexp.argtypes = [vp, vp, vp, C.c_size_t, vp]
+    lib.cq_best_multiexp_dev.argtypes = [vp, vp, vp, C.c_size_t, vp]
+    lib.cq_msm_batch_dev.argtypes = [vp, vp, vp, C.c_size_t, C.c_size_t, vp]
+    lib.cq_msm_set_window.argtypes = [vp, C.c_uint32]
+    lib.cq_params_create.argtypes = [vp, C.c_uint32, vp, vp, C.POINTER(vp)]
+    lib.cq_params_destroy.restype = None
+    lib.cq_params_destroy.argtypes = [vp]
+    lib.cq_params_g_dev.restype = vp
+    lib.cq_params_g_dev.argtypes = [vp]
+    lib.cq_params_g_lagrange_dev.restype = vp
+    lib.cq_params_g_lagrange_dev.argtypes = [vp]
+    for name in ("cq_commit", "cq_commit_lagrange", "cq_commit_dev", "cq_commit_lagrange_dev"):
+        getattr(lib, name).argtypes = [vp, vp, C.c_size_t, vp]
+
+
+_declare_base = _declare
+
+
+def _declare(lib):  # noqa: F811
+    _declare_base(lib)
+    _declare_msm(lib)

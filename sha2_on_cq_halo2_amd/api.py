@@ -104,3 +104,91 @@ class Context:
     def best_fft_dev(self, src: DevBuf, dst: DevBuf, omega: np.ndarray, log_n: int):
         om = np.ascontiguousarray(omega, dtype=np.uint64).reshape(4)
         self._chk(self.lib.cq_best_fft_dev(self.h, src.ptr, dst.ptr, log_n, om.ctypes.data))
+
+
+def _g1(a) -> np.ndarray:
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    assert a.ndim == 2 and a.shape[1] == 8, "expected uint64[n,8] affine points"
+    return a
+
+
+def _ctx_best_multiexp(self, coeffs: np.ndarray, bases: np.ndarray) -> np.ndarray:
+    """`best_multiexp(coeffs, bases)` (arithmetic.rs:132): Jacobian result, uint64[12]."""
+    coeffs = _fr(coeffs) if len(coeffs) else np.zeros((0, 4), dtype=np.uint64)
+    bases = _g1(bases) if len(bases) else np.zeros((0, 8), dtype=np.uint64)
+    if coeffs.shape[0] != bases.shape[0]:  # arithmetic.rs:133 assert_eq
+        raise CqError(-1, "best_multiexp: coeffs.len() != bases.len()")
+    out = np.zeros(12, dtype=np.uint64)
+    self._chk(self.lib.cq_best_multiexp(self.h, coeffs.ctypes.data, bases.ctypes.data, coeffs.shape[0], out.ctypes.data))
+    return out
+
+
+def _ctx_best_multiexp_dev(self, coeffs: DevBuf, bases: DevBuf, n: int) -> np.ndarray:
+    out = np.zeros(12, dtype=np.uint64)
+    self._chk(self.lib.cq_best_multiexp_dev(self.h, coeffs.ptr, bases.ptr, n, out.ctypes.data))
+    return out
+
+
+def _ctx_msm_batch_dev(self, coeff_ptrs, bases_ptr: int, n: int) -> np.ndarray:
+    ptrs = (C.c_void_p * len(coeff_ptrs))(*coeff_ptrs)
+    out = np.zeros((len(coeff_ptrs), 12), dtype=np.uint64)
+    self._chk(self.lib.cq_msm_batch_dev(self.h, ptrs, bases_ptr, n, len(coeff_ptrs), out.ctypes.data))
+    return out
+
+
+def _ctx_set_msm_window(self, bits: int):
+    self._chk(self.lib.cq_msm_set_window(self.h, bits))
+
+
+Context.best_multiexp = _ctx_best_multiexp
+Context.best_multiexp_dev = _ctx_best_multiexp_dev
+Context.msm_batch_dev = _ctx_msm_batch_dev
+Context.set_msm_window = _ctx_set_msm_window
+
+
+class ParamsKZG:
+    """`ParamsKZG<Bn256>` G1 part (poly/kzg/commitment.rs:31-39), SRS resident on the GPU."""
+
+    def __init__(self, ctx: Context, k: int, g: np.ndarray, g_lagrange: np.ndarray):
+        g = _g1(g)
+        g_lagrange = _g1(g_lagrange)
+        assert g.shape[0] == 1 << k and g_lagrange.shape[0] == 1 << k
+        self.ctx = ctx
+        self.k = k
+        self.n = 1 << k
+        h = C.c_void_p()
+        ctx._chk(ctx.lib.cq_params_create(ctx.h, k, g.ctypes.data, g_lagrange.ctypes.data, C.byref(h)))
+        self.h = h
+
+    @property
+    def g_dev(self) -> int:
+        return self.ctx.lib.cq_params_g_dev(self.h)
+
+    @property
+    def g_lagrange_dev(self) -> int:
+        return self.ctx.lib.cq_params_g_lagrange_dev(self.h)
+
+    def _commit(self, fn, poly):
+        poly = _fr(poly)
+        out = np.zeros(12, dtype=np.uint64)
+        self.ctx._chk(fn(self.h, poly.ctypes.data, poly.shape[0], out.ctypes.data))
+        return out
+
+    def commit(self, poly: np.ndarray) -> np.ndarray:
+        """`ParamsKZG::commit` (commitment.rs:539-543)."""
+        return self._commit(self.ctx.lib.cq_commit, poly)
+
+    def commit_lagrange(self, poly: np.ndarray) -> np.ndarray:
+        """`ParamsKZG::commit_lagrange` (commitment.rs:496-504)."""
+        return self._commit(self.ctx.lib.cq_commit_lagrange, poly)
+
+    def close(self):
+        if self.h:
+            self.ctx.lib.cq_params_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

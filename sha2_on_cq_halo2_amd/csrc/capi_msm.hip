@@ -1,0 +1,171 @@
+// C ABI: best_multiexp and ParamsKZG::commit / commit_lagrange.  See include/cq_halo2.h.
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include "ctx.hpp"
+#include "msm.hpp"
+
+using namespace cq;
+
+struct cq_params {
+  cq_ctx* ctx;
+  uint32_t k;
+  size_t n;
+  G1Affine* g;           // [s^i]_1
+  G1Affine* g_lagrange;  // [L_i(s)]_1
+};
+
+static uint32_t pick_c(cq_ctx* c, uint32_t n) {
+  if (c->msm_c) return c->msm_c;
+  return msm_window_bits(n);
+}
+
+// Runs `count` MSMs of equal length (each with its own base array); results to host Jacobians.
+int cq_msm_multi(cq_ctx* c, const Fr* const* scalars, const G1Affine* const* bases, size_t len, size_t count,
+                 uint64_t* out_jac) {
+  if (len > 0x7fffffffull) return c->fail(CQ_ERR_ARG, "msm: len too large");
+  const uint32_t n = (uint32_t)len;
+  if (n == 0 || count == 0) {
+    memset(out_jac, 0, count * 12 * sizeof(uint64_t));
+    return CQ_OK;
+  }
+  const uint32_t cb = pick_c(c, n);
+  size_t done = 0;
+  while (done < count) {
+    uint32_t batch = (uint32_t)((count - done) < MSM_MAX_BATCH ? (count - done) : MSM_MAX_BATCH);
+    // keep the workspace below ~8 GiB
+    while (batch > 1 && MsmLayout(n, cb, batch).total > ((size_t)8 << 30)) batch = (batch + 1) / 2;
+    MsmLayout L(n, cb, batch);
+    void *ws, *wsums, *host;
+    int rc;
+    if ((rc = c->ensure_scratch(3, L.total, &ws)) != CQ_OK) return rc;
+    if ((rc = c->ensure_scratch(4, (size_t)batch * L.W * sizeof(G1Jac), &wsums)) != CQ_OK) return rc;
+    if ((rc = c->ensure_pinned((size_t)batch * L.W * sizeof(G1Jac), &host)) != CQ_OK) return rc;
+    int r = msm_run(c, scalars + done, bases + done, n, cb, batch, ws, (G1Jac*)wsums);
+    if (r != 0) return c->fail(CQ_ERR_HIP, "msm launch failed");
+    CQ_HIP(c, hipMemcpyAsync(host, wsums, (size_t)batch * L.W * sizeof(G1Jac), hipMemcpyDeviceToHost, c->stream));
+    CQ_HIP(c, hipStreamSynchronize(c->stream));
+    for (uint32_t j = 0; j < batch; j++) {
+      G1Jac r = msm_fold_windows((const G1Jac*)host + (size_t)j * L.W, L.W, cb);
+      uint64_t* o = out_jac + (done + j) * 12;
+      r.x.to_limbs64(o);
+      r.y.to_limbs64(o + 4);
+      r.z.to_limbs64(o + 8);
+    }
+    done += batch;
+  }
+  return CQ_OK;
+}
+
+static int msm_batch(cq_ctx* c, const Fr* const* scalars, const G1Affine* bases, size_t len, size_t count,
+                     uint64_t* out_jac) {
+  std::vector<const G1Affine*> bp(count, bases);
+  return cq_msm_multi(c, scalars, bp.data(), len, count, out_jac);
+}
+
+extern "C" {
+
+int cq_msm_set_window(cq_ctx* c, uint32_t bits) {
+  if (!c || (bits != 0 && (bits < 2 || bits > 15))) return CQ_ERR_ARG;
+  c->msm_c = bits;
+  return CQ_OK;
+}
+
+int cq_best_multiexp_dev(cq_ctx* c, const uint64_t* coeffs_dev, const uint64_t* bases_dev, size_t len,
+                         uint64_t out_jac[12]) {
+  if (!c || !out_jac || (len && (!coeffs_dev || !bases_dev))) return CQ_ERR_ARG;
+  CQ_HIP(c, hipSetDevice(c->device));
+  const Fr* sc = (const Fr*)coeffs_dev;
+  return msm_batch(c, &sc, (const G1Affine*)bases_dev, len, 1, out_jac);
+}
+
+int cq_msm_batch_dev(cq_ctx* c, const uint64_t* const* coeffs_dev, const uint64_t* bases_dev, size_t len,
+                     size_t count, uint64_t* out_jac) {
+  if (!c || !out_jac || !coeffs_dev || (len && !bases_dev)) return CQ_ERR_ARG;
+  CQ_HIP(c, hipSetDevice(c->device));
+  return msm_batch(c, (const Fr* const*)coeffs_dev, (const G1Affine*)bases_dev, len, count, out_jac);
+}
+
+int cq_best_multiexp(cq_ctx* c, const uint64_t* coeffs, const uint64_t* bases, size_t len, uint64_t out_jac[12]) {
+  if (!c || !out_jac || (len && (!coeffs || !bases))) return CQ_ERR_ARG;
+  CQ_HIP(c, hipSetDevice(c->device));
+  if (len == 0) {
+    memset(out_jac, 0, 12 * sizeof(uint64_t));
+    return CQ_OK;
+  }
+  void *ds, *db;
+  int rc;
+  if ((rc = c->ensure_scratch(1, len * sizeof(Fr), &ds)) != CQ_OK) return rc;
+  if ((rc = c->ensure_scratch(2, len * sizeof(G1Affine), &db)) != CQ_OK) return rc;
+  CQ_HIP(c, hipMemcpyAsync(ds, coeffs, len * sizeof(Fr), hipMemcpyHostToDevice, c->stream));
+  CQ_HIP(c, hipMemcpyAsync(db, bases, len * sizeof(G1Affine), hipMemcpyHostToDevice, c->stream));
+  const Fr* sc = (const Fr*)ds;
+  return msm_batch(c, &sc, (const G1Affine*)db, len, 1, out_jac);
+}
+
+// ---- ParamsKZG ---------------------------------------------------------------------------------
+int cq_params_create(cq_ctx* c, uint32_t k, const uint64_t* g, const uint64_t* g_lagrange, cq_params** out) {
+  if (!c || !g || !g_lagrange || !out || k > FR_S) return CQ_ERR_ARG;
+  CQ_HIP(c, hipSetDevice(c->device));
+  cq_params* p = new cq_params();
+  p->ctx = c;
+  p->k = k;
+  p->n = (size_t)1 << k;
+  const size_t bytes = p->n * sizeof(G1Affine);
+  hipError_t e;
+  if ((e = hipMalloc(&p->g, bytes)) != hipSuccess || (e = hipMalloc(&p->g_lagrange, bytes)) != hipSuccess) {
+    if (p->g) hipFree(p->g);
+    delete p;
+    return c->hip_fail(e, "hipMalloc(params)");
+  }
+  CQ_HIP(c, hipMemcpyAsync(p->g, g, bytes, hipMemcpyHostToDevice, c->stream));
+  CQ_HIP(c, hipMemcpyAsync(p->g_lagrange, g_lagrange, bytes, hipMemcpyHostToDevice, c->stream));
+  CQ_HIP(c, hipStreamSynchronize(c->stream));
+  *out = p;
+  return CQ_OK;
+}
+
+void cq_params_destroy(cq_params* p) {
+  if (!p) return;
+  hipStreamSynchronize(p->ctx->stream);
+  hipFree(p->g);
+  hipFree(p->g_lagrange);
+  delete p;
+}
+
+const uint64_t* cq_params_g_dev(const cq_params* p) { return p ? (const uint64_t*)p->g : nullptr; }
+const uint64_t* cq_params_g_lagrange_dev(const cq_params* p) { return p ? (const uint64_t*)p->g_lagrange : nullptr; }
+
+static int commit_host(cq_params* p, const G1Affine* bases, const uint64_t* poly, size_t len, uint64_t out_jac[12]) {
+  if (!p || !out_jac || (len && !poly)) return CQ_ERR_ARG;
+  cq_ctx* c = p->ctx;
+  if (len > p->n) return c->fail(CQ_ERR_ARG, "commit: polynomial longer than the SRS");
+  CQ_HIP(c, hipSetDevice(c->device));
+  if (len == 0) {
+    memset(out_jac, 0, 12 * sizeof(uint64_t));
+    return CQ_OK;
+  }
+  void* ds;
+  int rc;
+  if ((rc = c->ensure_scratch(1, len * sizeof(Fr), &ds)) != CQ_OK) return rc;
+  CQ_HIP(c, hipMemcpyAsync(ds, poly, len * sizeof(Fr), hipMemcpyHostToDevice, c->stream));
+  const Fr* sc = (const Fr*)ds;
+  return msm_batch(c, &sc, bases, len, 1, out_jac);
+}
+
+int cq_commit(cq_params* p, const uint64_t* poly, size_t len, uint64_t out_jac[12]) {
+  return commit_host(p, p ? p->g : nullptr, poly, len, out_jac);
+}
+int cq_commit_lagrange(cq_params* p, const uint64_t* poly, size_t len, uint64_t out_jac[12]) {
+  return commit_host(p, p ? p->g_lagrange : nullptr, poly, len, out_jac);
+}
+int cq_commit_dev(cq_params* p, const uint64_t* poly_dev, size_t len, uint64_t out_jac[12]) {
+  if (!p || len > p->n) return CQ_ERR_ARG;
+  return cq_best_multiexp_dev(p->ctx, poly_dev, (const uint64_t*)p->g, len, out_jac);
+}
+int cq_commit_lagrange_dev(cq_params* p, const uint64_t* poly_dev, size_t len, uint64_t out_jac[12]) {
+  if (!p || len > p->n) return CQ_ERR_ARG;
+  return cq_best_multiexp_dev(p->ctx, poly_dev, (const uint64_t*)p->g_lagrange, len, out_jac);
+}
+
+}  // extern "C"

@@ -19,6 +19,7 @@ struct cq_ctx {
   size_t scratch_bytes[NSCRATCH] = {};
   void* pinned = nullptr;  // small pinned host staging buffer
   size_t pinned_bytes = 0;
+  uint32_t msm_c = 0;  // 0 = automatic window size
 
   int fail(int code, const std::string& msg) {
     err = msg;

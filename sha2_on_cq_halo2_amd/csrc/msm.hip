@@ -1,0 +1,535 @@
+// Pippenger multi-scalar multiplication on BN254 G1 for gfx950 -- replaces `best_multiexp`
+// (halo2_proofs/src/arithmetic.rs:132-159, serial core :13-101) and therefore
+// `ParamsKZG::commit` / `commit_lagrange` (poly/kzg/commitment.rs:496-504,539-543).
+//
+// The reference chunks the input per CPU thread and runs unsigned c=ceil(ln n)-bit windows with
+// `None/Affine/Projective` buckets.  None of that shape survives here; only the result (a group
+// element, canonical once normalised) has to match.  A launch handles a BATCH of independent
+// MSMs of equal length (e.g. all advice columns of a phase, plonk/prover.rs:356-360); every
+// (msm, window, bucket) triple is one entry of a flat bucket array, so the batch only adds
+// parallelism.  GPU pipeline, all on one stream:
+//   1. digits    : scalar -> canonical (one Montgomery reduction) -> SIGNED c-bit digits
+//                  (halves the bucket count); flat histogram with wave-aggregated L2 atomics.
+//   2. plan      : exclusive scans of the histogram (reduce / spine / apply): where each bucket's
+//                  index list starts, and how many bounded sub-lists it is cut into per level.
+//   3. scatter   : counting sort of point indices by bucket; sign kept in bit 31.
+//   4. accumulate: level 1 -- one lane per sub-list of <= MSM_S1 indices gathers affine bases
+//                  (64 B each; the SRS stays resident in HBM / Infinity Cache) into an XYZZ
+//                  accumulator (8M+2S per mixed add, no inversion).  Levels >= 2: one WAVE per
+//                  sub-list of <= MSM_S2 partial sums (strided lane sums + 6-step shuffle tree).
+//                  A bucket is written as soon as one lane/wave owns all of it.  Bounding the
+//                  per-lane work keeps the kernel balanced for skewed digit distributions (0/1
+//                  selector columns, SHA limb columns, the short top window) where a
+//                  lane-per-bucket kernel would serialise on one huge bucket.
+//                  256-bit modular integer work: VALU-bound, MFMA does not apply.
+//   5. reduce    : sum_b b*B_b per window: lane-local running sums, an LDS suffix scan and a tree
+//                  reduction, spread over M/256 workgroups per window plus one combining
+//                  workgroup (the reference does this serially, arithmetic.rs:95-99).
+//   6. host      : W window sums per MSM (<= 2 KiB) come back; Horner over windows (c doublings
+//                  each) on the host, O(254) group operations.
+#include "msm.hpp"
+#include "ctx.hpp"
+
+namespace cq {
+
+// ---- wave-aggregated atomic increment ----------------------------------------------------------
+// Returns the value of counters[key] before this lane's increment (unique per lane), issuing one
+// atomic per DISTINCT hot key for the first few keys of the wave; same-address atomics serialise
+// in L2 (~20 ns each on MI355X), which is what skewed digit distributions would otherwise pay.
+static __device__ __forceinline__ uint32_t wave_atomic_inc(uint32_t* counters, uint32_t key, bool active) {
+  uint32_t result = 0;
+  bool pending = active;
+#pragma unroll 1
+  for (int round = 0; round < 3; round++) {
+    const unsigned long long pend = __ballot(pending);
+    if (!pend) return result;
+    const int leader = __ffsll((long long)pend) - 1;
+    const uint32_t lkey = __shfl(key, leader, 64);
+    const bool mine = pending && key == lkey;
+    const unsigned long long grp = __ballot(mine);
+    const uint32_t cntg = __popcll(grp);
+    uint32_t base = 0;
+    if ((int)(threadIdx.x & 63) == leader) base = atomicAdd(&counters[lkey], cntg);
+    base = __shfl(base, leader, 64);
+    if (mine) {
+      const unsigned long long below = grp & ((1ull << (threadIdx.x & 63)) - 1ull);
+      result = base + __popcll(below);
+      pending = false;
+    }
+  }
+  if (pending) result = atomicAdd(&counters[key], 1u);
+  return result;
+}
+
+// ---- pointer tables (per-MSM scalar / base arrays), written from a by-value kernel argument ------
+__global__ void msm_set_ptrs_kernel(MsmPtrs sc, MsmPtrs bs, const void** dst, uint32_t batch) {
+  const uint32_t t = threadIdx.x;
+  if (t < batch) {
+    dst[t] = sc.p[t];
+    dst[batch + t] = bs.p[t];
+  }
+}
+
+// ---- 1. digits + histogram -------------------------------------------------------------------
+__global__ __launch_bounds__(256) void msm_digits_kernel(const Fr* const* __restrict__ scalars, uint32_t n, uint32_t c,
+                                                         uint32_t nwin, uint16_t* __restrict__ digits,
+                                                         uint32_t* __restrict__ counts) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t m = blockIdx.y;
+  const bool live = i < n;
+  U256 v;
+  if (live) v = scalars[m][i].to_canonical();
+  else for (int k = 0; k < 8; k++) v.l[k] = 0;
+  const uint32_t M = 1u << (c - 1);
+  const uint32_t mask = (1u << c) - 1;
+  uint32_t carry = 0;
+  for (uint32_t w = 0; w < nwin; w++) {
+    const uint32_t bitpos = w * c;
+    const uint32_t word = bitpos >> 5, sh = bitpos & 31;
+    uint32_t raw = 0;
+    if (word < 8) {
+      uint64_t two = v.l[word];
+      if (word + 1 < 8) two |= (uint64_t)v.l[word + 1] << 32;
+      raw = (uint32_t)(two >> sh) & mask;
+    }
+    uint32_t d = raw + carry;
+    uint32_t neg = 0;
+    carry = 0;
+    if (d > M) {
+      d = (1u << c) - d;
+      neg = 1;
+      carry = 1;
+    }
+    const size_t mw = (size_t)m * nwin + w;
+    if (live) digits[mw * n + i] = (uint16_t)(d | (neg << 15));
+    wave_atomic_inc(counts, (uint32_t)(mw * M) + (d - 1), live && d != 0);
+  }
+}
+
+// ---- 2. plan: exclusive scans over the flat bucket array -----------------------------------------
+// Sequence 0 is the histogram itself (-> list start of every bucket); sequence k >= 1 is the
+// number of level-k sub-lists of every bucket: t1 = ceil(cnt/S1), t_k = ceil(t_{k-1}/S2) while
+// t_{k-1} > 1, else 0 (the bucket was finished at level k-1).
+static __device__ __forceinline__ uint32_t level_value(uint32_t cnt, uint32_t lv) {
+  if (lv == 0) return cnt;
+  uint32_t t = (cnt + MSM_S1 - 1) / MSM_S1;
+  for (uint32_t k = 2; k <= lv; k++) t = t <= 1 ? 0 : (t + MSM_S2 - 1) / MSM_S2;
+  return t;
+}
+
+// exclusive scan of one value per thread over a 256-thread block; returns prefix, total via out param
+static __device__ __forceinline__ uint32_t block_excl_scan256(uint32_t v, uint32_t* sh /*>=4*/, uint32_t& total) {
+  const uint32_t lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  uint32_t x = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    uint32_t y = __shfl_up(x, off, 64);
+    if ((int)lane >= off) x += y;
+  }
+  __syncthreads();
+  if (lane == 63) sh[wid] = x;
+  __syncthreads();
+  uint32_t wbase = 0, tot = 0;
+  for (uint32_t k = 0; k < 4; k++) {
+    const uint32_t s = sh[k];
+    if (k < wid) wbase += s;
+    tot += s;
+  }
+  total = tot;
+  return wbase + x - v;
+}
+
+constexpr uint32_t SCAN_TILE = 2048;  // elements per block (8 per thread)
+
+__global__ __launch_bounds__(256) void msm_scan_reduce_kernel(const uint32_t* __restrict__ cnt, uint32_t Bt, uint32_t nseq,
+                                                              uint32_t* __restrict__ blocksums /*[nseq][nblk]*/) {
+  __shared__ uint32_t sh[4];
+  const uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * 8;
+  uint32_t c8[8];
+  for (int k = 0; k < 8; k++) c8[k] = (base + k < Bt) ? cnt[base + k] : 0;
+  for (uint32_t lv = 0; lv < nseq; lv++) {
+    uint32_t s = 0;
+    for (int k = 0; k < 8; k++) s += level_value(c8[k], lv);
+    uint32_t tot;
+    block_excl_scan256(s, sh, tot);
+    if (threadIdx.x == 0) blocksums[(size_t)lv * gridDim.x + blockIdx.x] = tot;
+  }
+}
+
+__global__ __launch_bounds__(1024) void msm_scan_spine_kernel(uint32_t* __restrict__ blocksums, uint32_t nblk, uint32_t nseq) {
+  __shared__ uint32_t part[1024];
+  const uint32_t per = (nblk + 1023) / 1024;
+  const uint32_t lo = min(threadIdx.x * per, nblk), hi = min(lo + per, nblk);
+  for (uint32_t lv = 0; lv < nseq; lv++) {
+    uint32_t* a = blocksums + (size_t)lv * nblk;
+    uint32_t s = 0;
+    for (uint32_t j = lo; j < hi; j++) s += a[j];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (uint32_t off = 1; off < 1024; off <<= 1) {
+      uint32_t t = threadIdx.x >= off ? part[threadIdx.x - off] : 0;
+      __syncthreads();
+      part[threadIdx.x] += t;
+      __syncthreads();
+    }
+    uint32_t run = part[threadIdx.x] - s;
+    for (uint32_t j = lo; j < hi; j++) {
+      const uint32_t v = a[j];
+      a[j] = run;
+      run += v;
+    }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(256) void msm_scan_apply_kernel(const uint32_t* __restrict__ cnt, uint32_t Bt, uint32_t nseq,
+                                                             const uint32_t* __restrict__ blocksums,
+                                                             uint32_t* __restrict__ off /*[nseq][Bt+1]*/,
+                                                             uint32_t* __restrict__ tk /*[nseq-1][Bt]*/) {
+  __shared__ uint32_t sh[4];
+  const uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * 8;
+  uint32_t c8[8];
+  for (int k = 0; k < 8; k++) c8[k] = (base + k < Bt) ? cnt[base + k] : 0;
+  for (uint32_t lv = 0; lv < nseq; lv++) {
+    uint32_t v8[8];
+    uint32_t s = 0;
+    for (int k = 0; k < 8; k++) {
+      v8[k] = level_value(c8[k], lv);
+      s += v8[k];
+    }
+    uint32_t tot;
+    uint32_t run = block_excl_scan256(s, sh, tot) + blocksums[(size_t)lv * gridDim.x + blockIdx.x];
+    uint32_t* o = off + (size_t)lv * (Bt + 1);
+    for (int k = 0; k < 8; k++) {
+      if (base + k < Bt) {
+        o[base + k] = run;
+        if (lv) tk[(size_t)(lv - 1) * Bt + base + k] = v8[k];
+      }
+      run += v8[k];
+      if (base + k == Bt - 1) o[Bt] = run;
+    }
+  }
+}
+
+// ---- 3. scatter (counting sort) ----------------------------------------------------------------
+__global__ __launch_bounds__(256) void msm_scatter_kernel(const uint16_t* __restrict__ digits, uint32_t n, uint32_t M,
+                                                          const uint32_t* __restrict__ off0,
+                                                          uint32_t* __restrict__ cursor, uint32_t* __restrict__ sorted) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t mw = blockIdx.y;  // msm * W + window
+  const bool live = i < n;
+  const uint16_t dg = live ? digits[(size_t)mw * n + i] : (uint16_t)0;
+  const uint32_t d = dg & 0x7fffu;
+  const uint32_t g = mw * M + (d - 1);
+  const bool act = live && d != 0;
+  const uint32_t rank = wave_atomic_inc(cursor, g, act);
+  if (act) sorted[off0[g] + rank] = i | ((uint32_t)(dg >> 15) << 31);
+}
+
+// ---- 4. bucket accumulation ----------------------------------------------------------------
+static __device__ __forceinline__ G1Affine load_affine(const G1Affine* p) {
+  const uint4* q = reinterpret_cast<const uint4*>(p);
+  uint4 a = q[0], b = q[1], c = q[2], d = q[3];
+  G1Affine r;
+  r.x.v.l[0] = a.x; r.x.v.l[1] = a.y; r.x.v.l[2] = a.z; r.x.v.l[3] = a.w;
+  r.x.v.l[4] = b.x; r.x.v.l[5] = b.y; r.x.v.l[6] = b.z; r.x.v.l[7] = b.w;
+  r.y.v.l[0] = c.x; r.y.v.l[1] = c.y; r.y.v.l[2] = c.z; r.y.v.l[3] = c.w;
+  r.y.v.l[4] = d.x; r.y.v.l[5] = d.y; r.y.v.l[6] = d.z; r.y.v.l[7] = d.w;
+  return r;
+}
+
+// largest g in [0,B) with off[g] <= j   (off is non-decreasing, off[0] = 0, j < off[B])
+static __device__ __forceinline__ uint32_t owner_of(const uint32_t* __restrict__ off, uint32_t B, uint32_t j) {
+  uint32_t lo = 0, hi = B;  // invariant: off[lo] <= j < off[hi]
+  while (hi - lo > 1) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (off[mid] <= j) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+// level 1: lane j owns sub-list j of <= MSM_S1 point indices
+__global__ __launch_bounds__(MSM_ACC_THREADS) void msm_accumulate_kernel(
+    const G1Affine* const* __restrict__ bases, uint32_t buckets_per_msm, const uint32_t* __restrict__ sorted,
+    const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ off0, const uint32_t* __restrict__ t1,
+    const uint32_t* __restrict__ off1, uint32_t Bt, XYZZ* __restrict__ partial, XYZZ* __restrict__ buckets) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= off1[Bt]) return;
+  const uint32_t g = owner_of(off1, Bt, j);
+  const G1Affine* __restrict__ pts = bases[g / buckets_per_msm];
+  const uint32_t r = j - off1[g];
+  const uint32_t lo = off0[g] + r * MSM_S1;
+  const uint32_t hi = min(off0[g] + cnt[g], lo + MSM_S1);
+  XYZZ acc = XYZZ::identity();
+  for (uint32_t e = lo; e < hi; e++) {
+    const uint32_t ix = sorted[e];
+    G1Affine p = load_affine(pts + (ix & 0x7fffffffu));
+    if (ix >> 31) p = p.neg();
+    xyzz_add_affine(acc, p);
+  }
+  if (t1[g] == 1) buckets[g] = acc; else partial[j] = acc;
+}
+
+static __device__ __forceinline__ XYZZ xyzz_shfl_down(const XYZZ& a, int delta) {
+  XYZZ r;
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    r.x.v.l[k] = __shfl_down(a.x.v.l[k], delta, 64);
+    r.y.v.l[k] = __shfl_down(a.y.v.l[k], delta, 64);
+    r.zz.v.l[k] = __shfl_down(a.zz.v.l[k], delta, 64);
+    r.zzz.v.l[k] = __shfl_down(a.zzz.v.l[k], delta, 64);
+  }
+  return r;
+}
+
+// level k >= 2, long sub-lists: one WAVE per sub-list of <= MSM_S2 partial sums of level k-1
+// (buckets whose level k-1 count is <= MSM_SHORT are left to msm_combine_short_kernel)
+__global__ __launch_bounds__(256) void msm_combine_kernel(
+    const XYZZ* __restrict__ prev, const uint32_t* __restrict__ t_prev, const uint32_t* __restrict__ off_prev,
+    const uint32_t* __restrict__ t_cur, const uint32_t* __restrict__ off_cur, uint32_t Bt, XYZZ* __restrict__ partial,
+    XYZZ* __restrict__ buckets) {
+  const uint32_t lane = threadIdx.x & 63;
+  const uint32_t j = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);  // wave-uniform
+  if (j >= off_cur[Bt]) return;
+  const uint32_t g = owner_of(off_cur, Bt, j);
+  const uint32_t tp = t_prev[g];
+  if (tp <= MSM_SHORT) return;
+  const uint32_t r = j - off_cur[g];
+  const uint32_t lo = off_prev[g] + r * MSM_S2;
+  const uint32_t hi = min(off_prev[g] + tp, lo + MSM_S2);
+  XYZZ acc = XYZZ::identity();
+  for (uint32_t e = lo + lane; e < hi; e += 64) xyzz_add(acc, prev[e]);
+#pragma unroll 1
+  for (int delta = 32; delta >= 1; delta >>= 1) {
+    XYZZ o = xyzz_shfl_down(acc, delta);
+    xyzz_add(acc, o);
+  }
+  if (lane == 0) {
+    if (t_cur[g] == 1) buckets[g] = acc; else partial[j] = acc;
+  }
+}
+
+// level k >= 2, short sub-lists (<= MSM_SHORT partial sums, always the whole bucket): one LANE each
+__global__ __launch_bounds__(MSM_ACC_THREADS) void msm_combine_short_kernel(
+    const XYZZ* __restrict__ prev, const uint32_t* __restrict__ t_prev, const uint32_t* __restrict__ off_prev,
+    const uint32_t* __restrict__ off_cur, uint32_t Bt, XYZZ* __restrict__ buckets) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= off_cur[Bt]) return;
+  const uint32_t g = owner_of(off_cur, Bt, j);
+  const uint32_t tp = t_prev[g];
+  if (tp > MSM_SHORT) return;
+  const uint32_t lo = off_prev[g];
+  XYZZ acc = prev[lo];
+  for (uint32_t e = 1; e < tp; e++) xyzz_add(acc, prev[lo + e]);
+  buckets[g] = acc;  // tp <= MSM_SHORT <= MSM_S2  =>  t_cur[g] == 1
+}
+
+// ---- 5. reduction: sum_{b=1..M} b * B_b per window ------------------------------------------------
+// Block (grp, mw) folds buckets [grp*Mg, (grp+1)*Mg) of (msm,window) mw into the pair
+//   S = sum B_b,  T = sum_{j=1..Mg} j * B_{grp*Mg + j}.
+static __device__ __forceinline__ void block_weighted_sum(const XYZZ* __restrict__ Bk, uint32_t Mg, XYZZ* sh,
+                                                          XYZZ& S_out, XYZZ& T_out) {
+  const uint32_t tid = threadIdx.x;
+  const uint32_t N = Mg < MSM_RED_THREADS ? Mg : MSM_RED_THREADS;  // active lanes
+  const uint32_t L = Mg / N;                                      // buckets per lane (power of two)
+  XYZZ running = XYZZ::identity();  // S_tid
+  XYZZ acc = XYZZ::identity();      // sum_j j * B[tid*L + j - 1]
+  if (tid < N) {
+    for (uint32_t j = L; j >= 1; j--) {
+      xyzz_add(running, Bk[(size_t)tid * L + (j - 1)]);
+      xyzz_add(acc, running);
+    }
+  }
+  // inclusive suffix scan of S over lanes
+  XYZZ inc = running;
+  sh[tid] = inc;
+  __syncthreads();
+  for (uint32_t off = 1; off < N; off <<= 1) {
+    XYZZ t = (tid + off < N) ? sh[tid + off] : XYZZ::identity();
+    __syncthreads();
+    xyzz_add(inc, t);
+    sh[tid] = inc;
+    __syncthreads();
+  }
+  S_out = sh[0];  // total
+  __syncthreads();
+  // sum_t t*S_t = sum_{t>=1} Inc_t ; value = acc + L * Inc (t>=1)
+  XYZZ v = (tid >= 1 && tid < N) ? inc : XYZZ::identity();
+  for (uint32_t l = L; l > 1; l >>= 1) v = xyzz_dbl(v);
+  xyzz_add(v, acc);
+  sh[tid] = v;
+  __syncthreads();
+  for (uint32_t off = MSM_RED_THREADS / 2; off >= 1; off >>= 1) {
+    if (tid < off) {
+      XYZZ t = sh[tid + off];
+      xyzz_add(v, t);
+      sh[tid] = v;
+    }
+    __syncthreads();
+  }
+  T_out = sh[0];
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(MSM_RED_THREADS) void msm_group_reduce_kernel(const XYZZ* __restrict__ buckets, uint32_t M,
+                                                                           uint32_t Mg, XYZZ* __restrict__ pairs) {
+  __shared__ XYZZ sh[MSM_RED_THREADS];
+  const uint32_t grp = blockIdx.x, mw = blockIdx.y, G = gridDim.x;
+  XYZZ S, T;
+  block_weighted_sum(buckets + (size_t)mw * M + (size_t)grp * Mg, Mg, sh, S, T);
+  if (threadIdx.x == 0) {
+    pairs[((size_t)mw * G + grp) * 2] = S;
+    pairs[((size_t)mw * G + grp) * 2 + 1] = T;
+  }
+}
+
+// window sum = sum_g (T_g + g*Mg*S_g) = sum_g T_g + Mg * sum_g g*S_g
+__global__ __launch_bounds__(MSM_RED_THREADS) void msm_window_final_kernel(const XYZZ* __restrict__ pairs, uint32_t G,
+                                                                           uint32_t Mg, G1Jac* __restrict__ window_sums) {
+  __shared__ XYZZ sh[MSM_RED_THREADS];
+  const uint32_t mw = blockIdx.x, tid = threadIdx.x;
+  const XYZZ* P = pairs + (size_t)mw * G * 2;
+  // lanes hold S_g (g = tid); sum_g g*S_g = sum_{g>=1} Inc_g with Inc the inclusive suffix scan
+  XYZZ inc = tid < G ? P[(size_t)tid * 2] : XYZZ::identity();
+  sh[tid] = inc;
+  __syncthreads();
+  for (uint32_t off = 1; off < G; off <<= 1) {
+    XYZZ t = (tid + off < G) ? sh[tid + off] : XYZZ::identity();
+    __syncthreads();
+    xyzz_add(inc, t);
+    sh[tid] = inc;
+    __syncthreads();
+  }
+  XYZZ v = (tid >= 1 && tid < G) ? inc : XYZZ::identity();
+  for (uint32_t l = Mg; l > 1; l >>= 1) v = xyzz_dbl(v);
+  if (tid < G) xyzz_add(v, P[(size_t)tid * 2 + 1]);
+  sh[tid] = v;
+  __syncthreads();
+  for (uint32_t off = MSM_RED_THREADS / 2; off >= 1; off >>= 1) {
+    if (tid < off) {
+      XYZZ t = sh[tid + off];
+      xyzz_add(v, t);
+      sh[tid] = v;
+    }
+    __syncthreads();
+  }
+  if (tid == 0) window_sums[mw] = v.to_jac();
+}
+
+// -------------------------------------------------------------------------------------------------
+uint32_t msm_window_bits(uint32_t n) {
+  // Tuned on MI355X: more buckets = fewer additions in `accumulate` but a longer
+  // reduction.  (The reference uses ceil(ln n), arithmetic.rs:16-22.)
+  if (n < 4) return 2;
+  uint32_t lg = 0;
+  while ((1u << (lg + 1)) <= n) lg++;
+  int c = (int)lg - 5;
+  if (c < 2) c = 2;
+  if (c > 15) c = 15;
+  return (uint32_t)c;
+}
+
+MsmLayout::MsmLayout(uint32_t n_, uint32_t c_, uint32_t batch_) : n(n_), c(c_), batch(batch_) {
+  W = (255 + c - 1) / c;  // signed digits need W*c >= 255 for 254-bit scalars
+  M = 1u << (c - 1);
+  B = W * M;
+  Bt = batch * B;
+  levels = 1;
+  {
+    uint64_t cap = MSM_S1;
+    while (cap < n) { cap *= MSM_S2; levels++; }
+  }
+  nseq = levels + 1;
+  nblk = (Bt + 2047) / 2048;
+  Mg = M < MSM_RED_GROUP ? M : MSM_RED_GROUP;
+  G = M / Mg;
+  auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  const uint64_t E = (uint64_t)batch * W * n;  // upper bound on (point,digit) entries
+  size_t o = 0;
+  off_ptrs = o;    o = up(o + (size_t)2 * batch * sizeof(void*));
+  off_digits = o;  o = up(o + (size_t)E * sizeof(uint16_t));
+  off_counts = o;  o = up(o + (size_t)Bt * sizeof(uint32_t));
+  off_cursor = o;  o = up(o + (size_t)Bt * sizeof(uint32_t));
+  off_buckets = o; o = up(o + (size_t)Bt * sizeof(XYZZ));  // counts..buckets zeroed by one memset
+  zero_end = o;
+  off_blocksums = o; o = up(o + (size_t)nseq * nblk * sizeof(uint32_t));
+  off_off = o;     o = up(o + (size_t)nseq * (Bt + 1) * sizeof(uint32_t));
+  off_tk = o;      o = up(o + (size_t)levels * Bt * sizeof(uint32_t));
+  off_sorted = o;  o = up(o + (size_t)E * sizeof(uint32_t));
+  // partial sums: level k has at most ceil(items_{k-1}/S) + Bt sub-lists
+  uint64_t cap = (E + MSM_S1 - 1) / MSM_S1;
+  for (uint32_t k = 0; k < 8; k++) tmax[k] = 0;
+  for (uint32_t k = 0; k < levels; k++) {
+    tmax[k] = cap + Bt;
+    cap = (tmax[k] + MSM_S2 - 1) / MSM_S2;
+  }
+  off_part[0] = o;
+  o = up(o + (size_t)tmax[0] * sizeof(XYZZ));
+  off_part[1] = o;
+  o = up(o + (size_t)(levels > 1 ? tmax[1] : 0) * sizeof(XYZZ));
+  off_pairs = o;   o = up(o + (size_t)batch * W * G * 2 * sizeof(XYZZ));
+  total = o;
+}
+
+int msm_run(cq_ctx* ctx, const Fr* const* scalars_host_ptrs, const G1Affine* const* bases_host_ptrs, uint32_t n,
+            uint32_t c, uint32_t batch, void* workspace, G1Jac* window_sums_dev) {
+  hipStream_t s = ctx->stream;
+  MsmLayout L(n, c, batch);
+  if (L.tmax[0] > 0xfffffff0ull || (uint64_t)batch * L.W * n > 0xfffffff0ull) return -3;
+  char* ws = (char*)workspace;
+  const Fr** d_scalars = (const Fr**)(ws + L.off_ptrs);
+  const G1Affine** d_bases = (const G1Affine**)(ws + L.off_ptrs) + batch;
+  uint16_t* digits = (uint16_t*)(ws + L.off_digits);
+  uint32_t* counts = (uint32_t*)(ws + L.off_counts);
+  uint32_t* cursor = (uint32_t*)(ws + L.off_cursor);
+  XYZZ* buckets = (XYZZ*)(ws + L.off_buckets);
+  uint32_t* blocksums = (uint32_t*)(ws + L.off_blocksums);
+  uint32_t* off = (uint32_t*)(ws + L.off_off);
+  uint32_t* tk = (uint32_t*)(ws + L.off_tk);
+  uint32_t* sorted = (uint32_t*)(ws + L.off_sorted);
+  XYZZ* part[2] = {(XYZZ*)(ws + L.off_part[0]), (XYZZ*)(ws + L.off_part[1])};
+  XYZZ* pairs = (XYZZ*)(ws + L.off_pairs);
+  const uint32_t M = L.M, W = L.W, Bt = L.Bt;
+  if (batch == 0 || batch > MSM_MAX_BATCH) return -2;
+  MsmPtrs sp, bp;
+  for (uint32_t i = 0; i < MSM_MAX_BATCH; i++) {
+    sp.p[i] = i < batch ? (const void*)scalars_host_ptrs[i] : nullptr;
+    bp.p[i] = i < batch ? (const void*)bases_host_ptrs[i] : nullptr;
+  }
+  msm_set_ptrs_kernel<<<1, 64, 0, s>>>(sp, bp, (const void**)d_scalars, batch);
+  // counts, cursor and buckets (identity = all zero) are adjacent: one memset
+  if (hipMemsetAsync(counts, 0, L.zero_end - L.off_counts, s) != hipSuccess) return -1;
+  msm_digits_kernel<<<dim3((n + 255) / 256, batch), 256, 0, s>>>(d_scalars, n, c, W, digits, counts);
+  msm_scan_reduce_kernel<<<L.nblk, 256, 0, s>>>(counts, Bt, L.nseq, blocksums);
+  msm_scan_spine_kernel<<<1, 1024, 0, s>>>(blocksums, L.nblk, L.nseq);
+  msm_scan_apply_kernel<<<L.nblk, 256, 0, s>>>(counts, Bt, L.nseq, blocksums, off, tk);
+  const uint32_t* off0 = off;
+  msm_scatter_kernel<<<dim3((n + 255) / 256, batch * W), 256, 0, s>>>(digits, n, M, off0, cursor, sorted);
+  msm_accumulate_kernel<<<(uint32_t)((L.tmax[0] + MSM_ACC_THREADS - 1) / MSM_ACC_THREADS), MSM_ACC_THREADS, 0, s>>>(
+      d_bases, L.B, sorted, counts, off0, tk, off + (size_t)(Bt + 1), Bt, part[0], buckets);
+  for (uint32_t k = 1; k < L.levels; k++) {
+    const uint32_t* t_prev = tk + (size_t)(k - 1) * Bt;
+    const uint32_t* off_prev = off + (size_t)k * (Bt + 1);
+    const uint32_t* t_cur = tk + (size_t)k * Bt;
+    const uint32_t* off_cur = off + (size_t)(k + 1) * (Bt + 1);
+    // ping-pong: level k+1 reads part[(k-1)&1], writes part[k&1]; one wave per sub-list
+    msm_combine_short_kernel<<<(uint32_t)((L.tmax[k] + MSM_ACC_THREADS - 1) / MSM_ACC_THREADS), MSM_ACC_THREADS, 0, s>>>(
+        part[(k - 1) & 1], t_prev, off_prev, off_cur, Bt, buckets);
+    msm_combine_kernel<<<(uint32_t)((L.tmax[k] + 3) / 4), 256, 0, s>>>(part[(k - 1) & 1], t_prev, off_prev, t_cur, off_cur, Bt,
+                                                                       part[k & 1], buckets);
+  }
+  msm_group_reduce_kernel<<<dim3(L.G, batch * W), MSM_RED_THREADS, 0, s>>>(buckets, M, L.Mg, pairs);
+  msm_window_final_kernel<<<batch * W, MSM_RED_THREADS, 0, s>>>(pairs, L.G, L.Mg, window_sums_dev);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+G1Jac msm_fold_windows(const G1Jac* window_sums, uint32_t W, uint32_t c) {
+  G1Jac acc = G1Jac::identity();
+  for (int w = (int)W - 1; w >= 0; w--) {
+    for (uint32_t j = 0; j < c; j++) acc = jac_dbl(acc);
+    acc = jac_add(acc, window_sums[w]);
+  }
+  return acc;
+}
+
+}  // namespace cq

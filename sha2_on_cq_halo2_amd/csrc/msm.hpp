@@ -1,0 +1,43 @@
+// Internal interface of the MSM engine (see msm.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "curve.hpp"
+
+struct cq_ctx;
+
+namespace cq {
+
+constexpr uint32_t MSM_ACC_THREADS = 128;
+constexpr uint32_t MSM_RED_THREADS = 256;
+
+#ifndef CQ_MSM_S1
+#define CQ_MSM_S1 32
+#endif
+constexpr uint32_t MSM_S1 = CQ_MSM_S1;  // max point indices summed by one lane (level 1)
+constexpr uint32_t MSM_S2 = 256;        // max partial sums summed by one wave (levels >= 2)
+constexpr uint32_t MSM_SHORT = 8;        // level >= 2 lists up to this long are summed by one lane
+constexpr uint32_t MSM_RED_GROUP = 1024; // buckets folded by one reduce workgroup (4 per lane)
+constexpr uint32_t MSM_MAX_BATCH = 16;  // MSMs per launch
+
+struct MsmPtrs {
+  const void* p[MSM_MAX_BATCH];
+};
+
+// Workspace carve-up for `batch` MSMs of n terms each with c-bit signed windows.
+struct MsmLayout {
+  uint32_t n, c, batch, W, M, B, Bt, levels, nseq, nblk, Mg, G;
+  uint64_t tmax[8];
+  size_t off_ptrs, off_digits, off_counts, off_cursor, off_buckets, zero_end, off_blocksums, off_off, off_tk,
+      off_sorted, off_part[2], off_pairs, total;
+  MsmLayout(uint32_t n_, uint32_t c_, uint32_t batch_);
+};
+
+uint32_t msm_window_bits(uint32_t n);
+// Enqueues the whole pipeline on ctx->stream.
+// `scalars` / `bases`: HOST arrays of `batch` device pointers; window_sums_dev receives batch*W points.
+int msm_run(cq_ctx* ctx, const Fr* const* scalars, const G1Affine* const* bases, uint32_t n, uint32_t c,
+            uint32_t batch, void* workspace, G1Jac* window_sums_dev);
+// Host: sum_w 2^(c*w) * window_sums[w].
+G1Jac msm_fold_windows(const G1Jac* window_sums, uint32_t W, uint32_t c);
+
+}  // namespace cq

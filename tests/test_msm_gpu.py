@@ -1,0 +1,115 @@
+"""GPU parity: HIP Pippenger MSM (C ABI) vs the oracle's restatement of `best_multiexp`."""
+import numpy as np
+import pytest
+
+from oracle import bn254 as B
+from oracle import poly as OP
+from tests.util import jac_limbs_to_affine, random_points, random_scalars
+
+pytestmark = pytest.mark.gpu
+
+
+def _check(ctx, scalars, points):
+    exp = B.jac_to_affine(OP.best_multiexp(scalars, points))
+    got = ctx.best_multiexp(B.to_mont_limbs(scalars), B.points_to_mont_limbs(points))
+    assert jac_limbs_to_affine(got) == exp
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 3, 4, 5, 31, 32, 33, 100, 257, 1000, 4096])
+def test_msm_random(ctx, n):
+    _check(ctx, random_scalars(n, 10 + n), random_points(n, 20 + n))
+
+
+@pytest.mark.parametrize("c", [2, 3, 5, 8, 11, 13, 15])
+def test_msm_window_sizes(ctx, c):
+    n = 700
+    ctx.set_msm_window(c)
+    try:
+        _check(ctx, random_scalars(n, 77), random_points(n, 78))
+    finally:
+        ctx.set_msm_window(0)
+
+
+def test_msm_edge_scalars(ctx):
+    n = 300
+    pts = random_points(n, 5)
+    sc = random_scalars(n, 6)
+    sc[0] = 0
+    sc[1] = 1
+    sc[2] = B.R_MOD - 1
+    sc[3] = B.R_MOD - 2
+    sc[4] = (1 << 253) + 12345
+    sc[5] = (1 << 128) - 1
+    for i in range(6, 60):
+        sc[i] = i - 6  # small scalars, many zero high windows
+    _check(ctx, sc, pts)
+
+
+def test_msm_identity_and_repeated_bases(ctx):
+    n = 200
+    pts = random_points(n, 9)
+    for i in range(0, n, 7):
+        pts[i] = None  # identity bases (0,0)
+    for i in range(50, 120):
+        pts[i] = pts[50]  # repeated base: forces the doubling branch inside buckets
+    pts[130] = B.g1_neg(pts[131])  # P and -P
+    sc = random_scalars(n, 11)
+    for i in range(50, 120):
+        sc[i] = 5  # same bucket
+    sc[130] = sc[131] = 9
+    _check(ctx, sc, pts)
+
+
+def test_msm_all_same_point_small_scalars(ctx):
+    n = 512
+    pts = [B.G1_GEN] * n
+    sc = [(i % 3) for i in range(n)]
+    _check(ctx, sc, pts)
+
+
+def test_msm_len_mismatch(ctx):
+    from sha2_on_cq_halo2_amd import CqError
+
+    with pytest.raises(CqError):
+        ctx.best_multiexp(np.zeros((3, 4), dtype=np.uint64), np.zeros((2, 8), dtype=np.uint64))
+
+
+def test_commit_equals_commit_lagrange(ctx):
+    """Reference identity test `test_commit_lagrange` (poly/kzg/commitment.rs:570-593):
+    commit(lagrange_to_coeff(a)) == commit_lagrange(a), on a true SRS."""
+    from oracle import kzg
+    from sha2_on_cq_halo2_amd import ParamsKZG
+
+    k = 6
+    s = B.fr_random(B.Xoshiro256ss(1234))
+    op = kzg.ParamsKZG(k, s)
+    params = ParamsKZG(ctx, k, B.points_to_mont_limbs(op.g), B.points_to_mont_limbs(op.g_lagrange))
+    a = random_scalars(1 << k, 99)
+    dom = OP.EvaluationDomain(2, k)
+    coeffs = dom.lagrange_to_coeff(a)
+    c1 = jac_limbs_to_affine(params.commit(B.to_mont_limbs(coeffs)))
+    c2 = jac_limbs_to_affine(params.commit_lagrange(B.to_mont_limbs(a)))
+    assert c1 == c2
+    assert c1 == B.jac_to_affine(op.commit(coeffs))
+
+
+@pytest.mark.parametrize("kind", ["bits", "limb12", "const"])
+def test_msm_skewed_scalars_multilevel(ctx, kind):
+    """Skewed digit distributions force the multi-level (bounded sub-list) accumulation path:
+    0/1 selector-like columns, 12-bit SHA limbs, and one repeated full-size scalar."""
+    n = 6000
+    pts = random_points(n, 41)
+    rng = B.Xoshiro256ss(42)
+    if kind == "bits":
+        sc = [rng.next_u64() & 1 for _ in range(n)]
+    elif kind == "limb12":
+        sc = [rng.next_u64() & 0xFFF for _ in range(n)]
+    else:
+        v = B.fr_random(rng)
+        sc = [v] * n
+    ctx.set_msm_window(9)
+    try:
+        _check(ctx, sc, pts)
+    finally:
+        ctx.set_msm_window(0)
+    _check(ctx, sc, pts)
