@@ -88,6 +88,11 @@ int cq_msm_set_window(cq_ctx* ctx, uint32_t bits);
 /* ParamsKZG (commitment.rs:31-39): uploads g = [s^i]_1 and g_lagrange = [L_i(s)]_1 (2^k affine
  * points each, host memory, `RawBytes` layout) once; they stay resident in HBM. */
 int cq_params_create(cq_ctx* ctx, uint32_t k, const uint64_t* g, const uint64_t* g_lagrange, cq_params** out);
+/* ParamsKZG::setup_from_toxic_waste (commitment.rs:209-276; "MUST NOT be used in production"):
+ * builds g and g_lagrange on the GPU from the toxic waste `s` -- for tests and benches. */
+int cq_params_setup_from_toxic_waste(cq_ctx* ctx, uint32_t k, const uint64_t s[4], cq_params** out);
+/* out[i] = scalars[i] * G1::generator(), device in / device out (affine). */
+int cq_fixed_base_mul_dev(cq_ctx* ctx, const uint64_t* scalars_dev, size_t n, uint64_t* out_affine_dev);
 void cq_params_destroy(cq_params* params);
 const uint64_t* cq_params_g_dev(const cq_params* params);
 const uint64_t* cq_params_g_lagrange_dev(const cq_params* params);
@@ -97,6 +102,15 @@ int cq_commit(cq_params* params, const uint64_t* poly, size_t len, uint64_t out_
 int cq_commit_lagrange(cq_params* params, const uint64_t* poly, size_t len, uint64_t out_jac[12]);
 int cq_commit_dev(cq_params* params, const uint64_t* poly_dev, size_t len, uint64_t out_jac[12]);
 int cq_commit_lagrange_dev(cq_params* params, const uint64_t* poly_dev, size_t len, uint64_t out_jac[12]);
+
+/* ---- measurement support ---------------------------------------------------------------------- */
+/* When enabled, the library brackets its dominant kernels with HIP events on the context's stream.
+ * cq_profile_read drains the stream and returns the summed duration and launch count for `id`
+ * (and forgets those spans). */
+#define CQ_PROF_MSM_ACCUMULATE 1 /* msm_accumulate_kernel: bucket accumulation (mixed additions) */
+#define CQ_PROF_NTT_PASS 2       /* ntt_pass_kernel: one radix-2^deg Stockham pass */
+int cq_profile_enable(cq_ctx* ctx, int on);
+int cq_profile_read(cq_ctx* ctx, int id, double* total_ms, uint64_t* calls);
 
 /* ---- microbenchmarks (measurement support, not part of the drop-in surface) -------------- */
 /* Runs `iters` dependent Montgomery multiplications per lane over `lanes` lanes and writes one

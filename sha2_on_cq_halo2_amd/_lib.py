@@ -85,3 +85,7 @@ _declare_base = _declare
 def _declare(lib):  # noqa: F811
     _declare_base(lib)
     _declare_msm(lib)
+    lib.cq_params_setup_from_toxic_waste.argtypes = [vp, C.c_uint32, vp, C.POINTER(vp)]
+    lib.cq_fixed_base_mul_dev.argtypes = [vp, vp, C.c_size_t, vp]
+    lib.cq_profile_enable.argtypes = [vp, C.c_int]
+    lib.cq_profile_read.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]

@@ -7,6 +7,7 @@ violations that panic in Rust raise `CqError` here.
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 
 import numpy as np
 
@@ -28,6 +29,7 @@ class DevBuf:
         p = C.c_void_p()
         ctx._chk(ctx.lib.cq_dev_alloc(ctx.h, nbytes, C.byref(p)))
         self.ptr = p.value
+        ctx._children.add(self)
 
     def upload(self, arr: np.ndarray):
         arr = np.ascontiguousarray(arr)
@@ -42,9 +44,11 @@ class DevBuf:
         return out
 
     def free(self):
-        if self.ptr:
+        if self.ptr and self.ctx.h:
             self.ctx.lib.cq_dev_free(self.ctx.h, self.ptr)
-            self.ptr = None
+        self.ptr = None
+
+    close = free
 
     def __del__(self):
         try:
@@ -61,9 +65,12 @@ class Context:
         if rc != 0:
             raise CqError(rc, "cq_ctx_create failed (no usable GPU?)")
         self.h = h
+        self._children = weakref.WeakSet()  # device objects that must die before the context
 
     def close(self):
         if self.h:
+            for ch in list(self._children):
+                ch.close()
             self.lib.cq_ctx_destroy(self.h)
             self.h = None
 
@@ -149,6 +156,26 @@ Context.set_msm_window = _ctx_set_msm_window
 class ParamsKZG:
     """`ParamsKZG<Bn256>` G1 part (poly/kzg/commitment.rs:31-39), SRS resident on the GPU."""
 
+    @classmethod
+    def setup_from_toxic_waste(cls, ctx: Context, k: int, s: np.ndarray) -> "ParamsKZG":
+        """`ParamsKZG::setup_from_toxic_waste(k, s)` (commitment.rs:209-276), built on the GPU."""
+        self = cls.__new__(cls)
+        self.ctx, self.k, self.n = ctx, k, 1 << k
+        sm = np.ascontiguousarray(s, dtype=np.uint64).reshape(4)
+        h = C.c_void_p()
+        ctx._chk(ctx.lib.cq_params_setup_from_toxic_waste(ctx.h, k, sm.ctypes.data, C.byref(h)))
+        self.h = h
+        ctx._children.add(self)
+        return self
+
+    def download(self):
+        """(g, g_lagrange) as uint64[n,8] host arrays."""
+        g = np.empty((self.n, 8), dtype=np.uint64)
+        gl = np.empty((self.n, 8), dtype=np.uint64)
+        self.ctx._chk(self.ctx.lib.cq_dev_download(self.ctx.h, g.ctypes.data, self.g_dev, g.nbytes))
+        self.ctx._chk(self.ctx.lib.cq_dev_download(self.ctx.h, gl.ctypes.data, self.g_lagrange_dev, gl.nbytes))
+        return g, gl
+
     def __init__(self, ctx: Context, k: int, g: np.ndarray, g_lagrange: np.ndarray):
         g = _g1(g)
         g_lagrange = _g1(g_lagrange)
@@ -159,6 +186,7 @@ class ParamsKZG:
         h = C.c_void_p()
         ctx._chk(ctx.lib.cq_params_create(ctx.h, k, g.ctypes.data, g_lagrange.ctypes.data, C.byref(h)))
         self.h = h
+        ctx._children.add(self)
 
     @property
     def g_dev(self) -> int:
@@ -183,12 +211,61 @@ class ParamsKZG:
         return self._commit(self.ctx.lib.cq_commit_lagrange, poly)
 
     def close(self):
-        if self.h:
+        if self.h and self.ctx.h:
             self.ctx.lib.cq_params_destroy(self.h)
-            self.h = None
+        self.h = None
 
     def __del__(self):
         try:
             self.close()
         except Exception:
             pass
+
+
+PROF_MSM_ACCUMULATE = 1
+PROF_NTT_PASS = 2
+
+
+def _ctx_profile_enable(self, on: bool = True):
+    self._chk(self.lib.cq_profile_enable(self.h, 1 if on else 0))
+
+
+def _ctx_profile_read(self, which: int):
+    """(total milliseconds, launches) of the bracketed kernel since the last read."""
+    ms = C.c_double()
+    calls = C.c_uint64()
+    self._chk(self.lib.cq_profile_read(self.h, which, C.byref(ms), C.byref(calls)))
+    return ms.value, calls.value
+
+
+Context.profile_enable = _ctx_profile_enable
+Context.profile_read = _ctx_profile_read
+
+
+# ---- small host-side field helpers (Python ints; constants from bn256/fr.rs:29-83) ----------------
+FR_MODULUS = 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001
+FR_S = 28
+FR_ROOT_OF_UNITY = 0x03DDB9F5166D18B798865EA93DD31F743215CF6DD39329C8D34F1ED960C37C9C
+
+
+def fr_to_mont(v: int) -> np.ndarray:
+    """canonical int -> uint64[4] Montgomery limbs (the layout every entry point takes)."""
+    m = (v % FR_MODULUS) * (1 << 256) % FR_MODULUS
+    return np.array([(m >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)], dtype=np.uint64)
+
+
+def fr_from_mont(limbs) -> int:
+    m = sum(int(x) << (64 * i) for i, x in enumerate(np.asarray(limbs, dtype=np.uint64).reshape(4)))
+    return m * pow(1 << 256, -1, FR_MODULUS) % FR_MODULUS
+
+
+def domain_omega_int(k: int) -> int:
+    """2^k-th root of unity as `EvaluationDomain::new` derives it (poly/domain.rs:54-75)."""
+    w = FR_ROOT_OF_UNITY
+    for _ in range(k, FR_S):
+        w = w * w % FR_MODULUS
+    return w
+
+
+def domain_omega(k: int) -> np.ndarray:
+    return fr_to_mont(domain_omega_int(k))

@@ -53,6 +53,7 @@ void cq_ctx_destroy(cq_ctx* c) {
   for (int i = 0; i < cq_ctx::NSCRATCH; i++)
     if (c->scratch[i]) hipFree(c->scratch[i]);
   if (c->pinned) hipHostFree(c->pinned);
+  if (c->fb_table) hipFree(c->fb_table);
   if (c->own_stream) hipStreamDestroy(c->stream);
   delete c;
 }
@@ -101,6 +102,38 @@ int cq_dev_memset(cq_ctx* c, void* dptr, int value, size_t bytes) {
   return CQ_OK;
 }
 
+// ---- per-kernel timing (HIP events on the context's stream) ---------------------------------------
+int cq_profile_enable(cq_ctx* c, int on) {
+  if (!c) return CQ_ERR_ARG;
+  c->prof_on = on != 0;
+  return CQ_OK;
+}
+
+int cq_profile_read(cq_ctx* c, int id, double* total_ms, uint64_t* calls) {
+  if (!c || !total_ms || !calls) return CQ_ERR_ARG;
+  CQ_HIP(c, hipStreamSynchronize(c->stream));
+  double tot = 0;
+  uint64_t n = 0;
+  std::vector<cq_ctx::ProfSpan> keep;
+  for (auto& sp : c->prof_spans) {
+    if (sp.id != id) {
+      keep.push_back(sp);
+      continue;
+    }
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, sp.a, sp.b) == hipSuccess) {
+      tot += ms;
+      n++;
+    }
+    hipEventDestroy(sp.a);
+    hipEventDestroy(sp.b);
+  }
+  c->prof_spans.swap(keep);
+  *total_ms = tot;
+  *calls = n;
+  return CQ_OK;
+}
+
 // ---- best_fft -------------------------------------------------------------------------------
 static int fft_dev(cq_ctx* c, const Fr* in, Fr* out, uint32_t log_n, const Fr& omega) {
   int rc = CQ_OK;
@@ -112,6 +145,7 @@ static int fft_dev(cq_ctx* c, const Fr* in, Fr* out, uint32_t log_n, const Fr& o
   NttIo io;
   io.in_len = io.out_len = (uint32_t)n;
   io.in_stride = io.out_stride = io.scratch_stride = n;
+  io.prof = c;
   if (ntt_run(*tb, in, out, (Fr*)scr, io, c->stream) != 0) return c->fail(CQ_ERR_HIP, "ntt launch failed");
   return CQ_OK;
 }

@@ -4,6 +4,7 @@
 #include <vector>
 #include "ctx.hpp"
 #include "msm.hpp"
+#include "setup.hpp"
 
 using namespace cq;
 
@@ -123,6 +124,38 @@ int cq_params_create(cq_ctx* c, uint32_t k, const uint64_t* g, const uint64_t* g
   CQ_HIP(c, hipStreamSynchronize(c->stream));
   *out = p;
   return CQ_OK;
+}
+
+/* ParamsKZG::setup_from_toxic_waste (kzg/commitment.rs:209-276), computed on the GPU */
+int cq_params_setup_from_toxic_waste(cq_ctx* c, uint32_t k, const uint64_t s[4], cq_params** out) {
+  if (!c || !s || !out || k > FR_S) return CQ_ERR_ARG;
+  CQ_HIP(c, hipSetDevice(c->device));
+  cq_params* p = new cq_params();
+  p->ctx = c;
+  p->k = k;
+  p->n = (size_t)1 << k;
+  const size_t bytes = p->n * sizeof(G1Affine);
+  hipError_t e;
+  if ((e = hipMalloc(&p->g, bytes)) != hipSuccess || (e = hipMalloc(&p->g_lagrange, bytes)) != hipSuccess) {
+    if (p->g) hipFree(p->g);
+    delete p;
+    return c->hip_fail(e, "hipMalloc(params)");
+  }
+  void* tmp;
+  int rc;
+  if ((rc = c->ensure_scratch(1, p->n * sizeof(Fr), &tmp)) != CQ_OK) return rc;
+  rc = srs_powers_and_lagrange(c, k, Fr::from_limbs64(s), p->g, p->g_lagrange, (Fr*)tmp, nullptr);
+  if (rc != CQ_OK) return rc;
+  CQ_HIP(c, hipStreamSynchronize(c->stream));
+  *out = p;
+  return CQ_OK;
+}
+
+/* scalars[i] * G for device-resident scalars (every SRS element has this form) */
+int cq_fixed_base_mul_dev(cq_ctx* c, const uint64_t* scalars_dev, size_t n, uint64_t* out_affine_dev) {
+  if (!c || (n && (!scalars_dev || !out_affine_dev)) || n > 0x7fffffffull) return CQ_ERR_ARG;
+  CQ_HIP(c, hipSetDevice(c->device));
+  return fixed_base_mul(c, (const Fr*)scalars_dev, (uint32_t)n, (G1Affine*)out_affine_dev);
 }
 
 void cq_params_destroy(cq_params* p) {

@@ -20,6 +20,24 @@ struct cq_ctx {
   void* pinned = nullptr;  // small pinned host staging buffer
   size_t pinned_bytes = 0;
   uint32_t msm_c = 0;  // 0 = automatic window size
+  void* fb_table = nullptr;  // fixed-base table d*2^(8j)*G (setup.hip)
+  // optional per-kernel timing with HIP events on `stream` (bench.py's roofline leg)
+  struct ProfSpan { int id; hipEvent_t a, b; };
+  bool prof_on = false;
+  std::vector<ProfSpan> prof_spans;
+  hipEvent_t prof_begin(int id) {
+    if (!prof_on) return nullptr;
+    ProfSpan sp;
+    sp.id = id;
+    hipEventCreate(&sp.a);
+    hipEventCreate(&sp.b);
+    hipEventRecord(sp.a, stream);
+    prof_spans.push_back(sp);
+    return sp.b;
+  }
+  void prof_end(hipEvent_t b) {
+    if (b) hipEventRecord(b, stream);
+  }
 
   int fail(int code, const std::string& msg) {
     err = msg;

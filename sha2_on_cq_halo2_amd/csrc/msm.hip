@@ -418,15 +418,14 @@ __global__ __launch_bounds__(MSM_RED_THREADS) void msm_window_final_kernel(const
 
 // -------------------------------------------------------------------------------------------------
 uint32_t msm_window_bits(uint32_t n) {
-  // Tuned on MI355X: more buckets = fewer additions in `accumulate` but a longer
-  // reduction.  (The reference uses ceil(ln n), arithmetic.rs:16-22.)
-  if (n < 4) return 2;
-  uint32_t lg = 0;
-  while ((1u << (lg + 1)) <= n) lg++;
-  int c = (int)lg - 5;
-  if (c < 2) c = 2;
-  if (c > 15) c = 15;
-  return (uint32_t)c;
+  // Measured on MI355X (tools/msm_sweep.py, uniform scalars).  15 is also the width whose top
+  // window (bits 240..254) is well filled; widths that leave 1-7 bits for the top window pile
+  // n/2^bits entries on a handful of buckets.  (The reference uses ceil(ln n), arithmetic.rs:16-22.)
+  if (n >= (1u << 15)) return 15;
+  if (n >= (1u << 13)) return 10;
+  if (n >= 256) return 8;
+  if (n >= 16) return 4;
+  return 2;
 }
 
 MsmLayout::MsmLayout(uint32_t n_, uint32_t c_, uint32_t batch_) : n(n_), c(c_), batch(batch_) {
@@ -505,8 +504,10 @@ int msm_run(cq_ctx* ctx, const Fr* const* scalars_host_ptrs, const G1Affine* con
   msm_scan_apply_kernel<<<L.nblk, 256, 0, s>>>(counts, Bt, L.nseq, blocksums, off, tk);
   const uint32_t* off0 = off;
   msm_scatter_kernel<<<dim3((n + 255) / 256, batch * W), 256, 0, s>>>(digits, n, M, off0, cursor, sorted);
+  hipEvent_t pe = ctx->prof_begin(CQ_PROF_MSM_ACCUMULATE);
   msm_accumulate_kernel<<<(uint32_t)((L.tmax[0] + MSM_ACC_THREADS - 1) / MSM_ACC_THREADS), MSM_ACC_THREADS, 0, s>>>(
       d_bases, L.B, sorted, counts, off0, tk, off + (size_t)(Bt + 1), Bt, part[0], buckets);
+  ctx->prof_end(pe);
   for (uint32_t k = 1; k < L.levels; k++) {
     const uint32_t* t_prev = tk + (size_t)(k - 1) * Bt;
     const uint32_t* off_prev = off + (size_t)k * (Bt + 1);

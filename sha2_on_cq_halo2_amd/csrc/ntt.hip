@@ -19,6 +19,7 @@
 // of `extended_to_coeff` (domain.rs:311-312) are fused into the first/last pass instead of being
 // separate streaming passes.
 #include "ntt.hpp"
+#include "ctx.hpp"
 
 namespace cq {
 
@@ -171,9 +172,6 @@ int NttTables::build(uint32_t log_n_, const Fr& omega_, hipStream_t stream) {
 int ntt_run(const NttTables& tb, const Fr* in, Fr* out, Fr* scratch, const NttIo& io, hipStream_t stream) {
   const uint32_t log_n = tb.log_n;
   const uint32_t n = 1u << log_n;
-  if (log_n == 0) {
-    // 1-point transform: copy (with the fused multipliers), handled by a degenerate pass
-  }
   uint32_t npass = log_n == 0 ? 1 : (log_n + NTT_MAX_DEG - 1) / NTT_MAX_DEG;
   uint32_t degs[8];
   {
@@ -237,7 +235,9 @@ int ntt_run(const NttTables& tb, const Fr* in, Fr* out, Fr* scratch, const NttIo
     const uint32_t T = 1u << log_t;
     dim3 grid(t / T, io.batch);
     const size_t lds = (size_t)(T << degs[ps]) * 32;
+    hipEvent_t pe = io.prof ? io.prof->prof_begin(CQ_PROF_NTT_PASS) : nullptr;
     ntt_pass_kernel<<<grid, NTT_THREADS, lds, stream>>>(a);
+    if (io.prof) io.prof->prof_end(pe);
     src = dst;
     lgp += degs[ps];
   }

@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include "field.hpp"
 
+struct cq_ctx;
+
 namespace cq {
 
 constexpr uint32_t NTT_THREADS = 256;
@@ -57,6 +59,7 @@ struct NttIo {
   Fr in_coset_mul[2];
   bool out_mul = false, out_coset = false;
   Fr out_mul_v[3];
+  cq_ctx* prof = nullptr;  // when set and profiling is on, passes are bracketed with HIP events
 };
 
 // out = NTT(in) over `tb`; `in`, `out`, `scratch` pairwise distinct, each batch x 2^log_n elements
