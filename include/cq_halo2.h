@@ -63,7 +63,7 @@ int cq_dev_memset(cq_ctx* ctx, void* dptr, int value, size_t bytes);
 /* best_fft(a, omega, log_n)  arithmetic.rs:171-234.  In place on a host slice of 2^log_n Fr,
  * natural order in and out. */
 int cq_best_fft(cq_ctx* ctx, uint64_t* a, uint32_t log_n, const uint64_t omega[4]);
-/* Same on device memory; `out` != `in`, both 2^log_n elements; `in` is preserved. */
+/* Same on device memory; both 2^log_n elements; `out` may alias `in`. */
 int cq_best_fft_dev(cq_ctx* ctx, const uint64_t* in_dev, uint64_t* out_dev, uint32_t log_n,
                     const uint64_t omega[4]);
 
@@ -83,6 +83,38 @@ int cq_msm_batch_dev(cq_ctx* ctx, const uint64_t* const* coeffs_dev, const uint6
                      size_t count, uint64_t* out_jac);
 /* Pippenger window width in bits (2..15), 0 = automatic.  Tuning knob; results do not depend on it. */
 int cq_msm_set_window(cq_ctx* ctx, uint32_t bits);
+
+/* eval_polynomial(poly, point)  arithmetic.rs:304-329 */
+int cq_eval_polynomial(cq_ctx* ctx, const uint64_t* poly, size_t n, const uint64_t point[4], uint64_t out[4]);
+int cq_eval_polynomial_dev(cq_ctx* ctx, const uint64_t* poly_dev, size_t n, const uint64_t point[4], uint64_t out[4]);
+/* kate_division(a, b)  arithmetic.rs:351-387: (a(X) - a(b)) / (X - b), n-1 coefficients into q.
+ * (The reference's always-on re-multiplication check is a debug assertion and is not reproduced.) */
+int cq_kate_division(cq_ctx* ctx, const uint64_t* a, size_t n, const uint64_t b[4], uint64_t* q);
+int cq_kate_division_dev(cq_ctx* ctx, const uint64_t* a_dev, size_t n, const uint64_t b[4], uint64_t* q_dev);
+/* ff::BatchInvert::batch_invert (ff 0.12; call sites poly.rs:192,232, domain.rs:124,468): in place,
+ * zeros stay zero. */
+int cq_batch_invert(cq_ctx* ctx, uint64_t* a, size_t n);
+int cq_batch_invert_dev(cq_ctx* ctx, uint64_t* a_dev, size_t n);
+
+/* ---- poly/domain.rs ------------------------------------------------------------------------ */
+/* EvaluationDomain::new(j, k)  domain.rs:39-142 */
+int cq_domain_create(cq_ctx* ctx, uint32_t j, uint32_t k, cq_domain** out);
+void cq_domain_destroy(cq_domain* domain);
+uint32_t cq_domain_k(const cq_domain* domain);
+uint32_t cq_domain_extended_k(const cq_domain* domain);
+/* get_omega / get_omega_inv / get_extended_omega / ifft_divisor (domain.rs:391-410); any pointer may be NULL */
+int cq_domain_constants(const cq_domain* domain, uint64_t omega[4], uint64_t omega_inv[4],
+                        uint64_t extended_omega[4], uint64_t ifft_divisor[4]);
+/* lagrange_to_coeff  domain.rs:238-248 (host slice of n, in place) */
+int cq_lagrange_to_coeff(cq_domain* domain, uint64_t* a);
+/* coeff_to_extended  domain.rs:252-266 (n coefficients in, 2^extended_k coset evaluations out) */
+int cq_coeff_to_extended(cq_domain* domain, const uint64_t* a, uint64_t* out);
+/* extended_to_coeff  domain.rs:293-315 (2^extended_k in, n*(j-1) coefficients out) */
+int cq_extended_to_coeff(cq_domain* domain, const uint64_t* a, uint64_t* out);
+/* Device variants; `batch` columns stored back to back (stride n in, n resp. 2^extended_k out). */
+int cq_lagrange_to_coeff_dev(cq_domain* domain, const uint64_t* in_dev, uint64_t* out_dev, uint32_t batch);
+int cq_coeff_to_extended_dev(cq_domain* domain, const uint64_t* in_dev, uint64_t* out_dev, uint32_t batch);
+int cq_extended_to_coeff_dev(cq_domain* domain, const uint64_t* in_dev, uint64_t* out_dev);
 
 /* ---- poly/kzg/commitment.rs ---------------------------------------------------------------- */
 /* ParamsKZG (commitment.rs:31-39): uploads g = [s^i]_1 and g_lagrange = [L_i(s)]_1 (2^k affine

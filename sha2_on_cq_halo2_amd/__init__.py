@@ -8,4 +8,4 @@ the tests and the bench; arrays are numpy uint64[..., 4] Montgomery limbs, exact
 the Rust side holds.
 """
 from ._lib import CqError, load, header_symbols  # noqa: F401
-from .api import Context, ParamsKZG, DevBuf  # noqa: F401
+from .api import Context, ParamsKZG, DevBuf, EvaluationDomain  # noqa: F401

@@ -87,5 +87,25 @@ def _declare(lib):  # noqa: F811
     _declare_msm(lib)
     lib.cq_params_setup_from_toxic_waste.argtypes = [vp, C.c_uint32, vp, C.POINTER(vp)]
     lib.cq_fixed_base_mul_dev.argtypes = [vp, vp, C.c_size_t, vp]
+    lib.cq_eval_polynomial.argtypes = [vp, vp, C.c_size_t, vp, vp]
+    lib.cq_eval_polynomial_dev.argtypes = [vp, vp, C.c_size_t, vp, vp]
+    lib.cq_kate_division.argtypes = [vp, vp, C.c_size_t, vp, vp]
+    lib.cq_kate_division_dev.argtypes = [vp, vp, C.c_size_t, vp, vp]
+    lib.cq_batch_invert.argtypes = [vp, vp, C.c_size_t]
+    lib.cq_batch_invert_dev.argtypes = [vp, vp, C.c_size_t]
+    lib.cq_domain_create.argtypes = [vp, C.c_uint32, C.c_uint32, C.POINTER(vp)]
+    lib.cq_domain_destroy.restype = None
+    lib.cq_domain_destroy.argtypes = [vp]
+    lib.cq_domain_k.restype = C.c_uint32
+    lib.cq_domain_k.argtypes = [vp]
+    lib.cq_domain_extended_k.restype = C.c_uint32
+    lib.cq_domain_extended_k.argtypes = [vp]
+    lib.cq_domain_constants.argtypes = [vp, vp, vp, vp, vp]
+    lib.cq_lagrange_to_coeff.argtypes = [vp, vp]
+    lib.cq_coeff_to_extended.argtypes = [vp, vp, vp]
+    lib.cq_extended_to_coeff.argtypes = [vp, vp, vp]
+    lib.cq_lagrange_to_coeff_dev.argtypes = [vp, vp, vp, C.c_uint32]
+    lib.cq_coeff_to_extended_dev.argtypes = [vp, vp, vp, C.c_uint32]
+    lib.cq_extended_to_coeff_dev.argtypes = [vp, vp, vp]
     lib.cq_profile_enable.argtypes = [vp, C.c_int]
     lib.cq_profile_read.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]

@@ -269,3 +269,91 @@ def domain_omega_int(k: int) -> int:
 
 def domain_omega(k: int) -> np.ndarray:
     return fr_to_mont(domain_omega_int(k))
+
+
+def _ctx_eval_polynomial(self, poly: np.ndarray, point: np.ndarray) -> np.ndarray:
+    """`eval_polynomial(poly, point)` (arithmetic.rs:304)."""
+    poly = _fr(poly) if len(poly) else np.zeros((0, 4), dtype=np.uint64)
+    pt = np.ascontiguousarray(point, dtype=np.uint64).reshape(4)
+    out = np.zeros(4, dtype=np.uint64)
+    self._chk(self.lib.cq_eval_polynomial(self.h, poly.ctypes.data, poly.shape[0], pt.ctypes.data, out.ctypes.data))
+    return out
+
+
+def _ctx_kate_division(self, a: np.ndarray, b: np.ndarray) -> np.ndarray:
+    """`kate_division(a, b)` (arithmetic.rs:351): n-1 quotient coefficients."""
+    a = _fr(a)
+    bm = np.ascontiguousarray(b, dtype=np.uint64).reshape(4)
+    q = np.zeros((max(a.shape[0] - 1, 0), 4), dtype=np.uint64)
+    self._chk(self.lib.cq_kate_division(self.h, a.ctypes.data, a.shape[0], bm.ctypes.data, q.ctypes.data))
+    return q
+
+
+def _ctx_batch_invert(self, a: np.ndarray) -> np.ndarray:
+    """`BatchInvert::batch_invert` (ff 0.12): returns the inverted copy, zeros untouched."""
+    a = _fr(a).copy() if len(a) else np.zeros((0, 4), dtype=np.uint64)
+    self._chk(self.lib.cq_batch_invert(self.h, a.ctypes.data, a.shape[0]))
+    return a
+
+
+Context.eval_polynomial = _ctx_eval_polynomial
+Context.kate_division = _ctx_kate_division
+Context.batch_invert = _ctx_batch_invert
+
+
+class EvaluationDomain:
+    """`EvaluationDomain<Fr>` (poly/domain.rs:19-34)."""
+
+    def __init__(self, ctx: Context, j: int, k: int):
+        self.ctx = ctx
+        h = C.c_void_p()
+        ctx._chk(ctx.lib.cq_domain_create(ctx.h, j, k, C.byref(h)))
+        self.h = h
+        self.j = j
+        self.k = k
+        self.extended_k = ctx.lib.cq_domain_extended_k(h)
+        self.n = 1 << k
+        ctx._children.add(self)
+
+    @property
+    def extended_len(self) -> int:
+        return 1 << self.extended_k
+
+    def constants(self):
+        arrs = [np.zeros(4, dtype=np.uint64) for _ in range(4)]
+        self.ctx._chk(self.ctx.lib.cq_domain_constants(self.h, *[a.ctypes.data for a in arrs]))
+        return dict(zip(("omega", "omega_inv", "extended_omega", "ifft_divisor"), arrs))
+
+    def lagrange_to_coeff(self, a: np.ndarray) -> np.ndarray:
+        a = _fr(a).copy()
+        if a.shape[0] != self.n:  # domain.rs:239 assert
+            raise CqError(-1, "lagrange_to_coeff: wrong length")
+        self.ctx._chk(self.ctx.lib.cq_lagrange_to_coeff(self.h, a.ctypes.data))
+        return a
+
+    def coeff_to_extended(self, a: np.ndarray) -> np.ndarray:
+        a = _fr(a)
+        if a.shape[0] != self.n:  # domain.rs:256 assert
+            raise CqError(-1, "coeff_to_extended: wrong length")
+        out = np.zeros((self.extended_len, 4), dtype=np.uint64)
+        self.ctx._chk(self.ctx.lib.cq_coeff_to_extended(self.h, a.ctypes.data, out.ctypes.data))
+        return out
+
+    def extended_to_coeff(self, a: np.ndarray) -> np.ndarray:
+        a = _fr(a)
+        if a.shape[0] != self.extended_len:  # domain.rs:294 assert
+            raise CqError(-1, "extended_to_coeff: wrong length")
+        out = np.zeros((self.n * (self.j - 1), 4), dtype=np.uint64)
+        self.ctx._chk(self.ctx.lib.cq_extended_to_coeff(self.h, a.ctypes.data, out.ctypes.data))
+        return out
+
+    def close(self):
+        if self.h and self.ctx.h:
+            self.ctx.lib.cq_domain_destroy(self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

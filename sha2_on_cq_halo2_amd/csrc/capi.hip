@@ -1,5 +1,6 @@
 // C ABI: context, device memory, arithmetic.rs entry points.  See include/cq_halo2.h.
 #include "ctx.hpp"
+#include "poly.hpp"
 #include <cstring>
 
 using namespace cq;
@@ -136,24 +137,12 @@ int cq_profile_read(cq_ctx* c, int id, double* total_ms, uint64_t* calls) {
 
 // ---- best_fft -------------------------------------------------------------------------------
 static int fft_dev(cq_ctx* c, const Fr* in, Fr* out, uint32_t log_n, const Fr& omega) {
-  int rc = CQ_OK;
-  const NttTables* tb = c->tables_for(log_n, omega, &rc);
-  if (!tb) return rc;
-  void* scr;
-  const size_t n = (size_t)1 << log_n;
-  if ((rc = c->ensure_scratch(0, n * sizeof(Fr), &scr)) != CQ_OK) return rc;
-  NttIo io;
-  io.in_len = io.out_len = (uint32_t)n;
-  io.in_stride = io.out_stride = io.scratch_stride = n;
-  io.prof = c;
-  if (ntt_run(*tb, in, out, (Fr*)scr, io, c->stream) != 0) return c->fail(CQ_ERR_HIP, "ntt launch failed");
-  return CQ_OK;
+  return domain_fft(c, in, out, log_n, omega, 1, (size_t)1 << log_n, (size_t)1 << log_n);
 }
 
 int cq_best_fft_dev(cq_ctx* c, const uint64_t* in_dev, uint64_t* out_dev, uint32_t log_n,
                     const uint64_t omega[4]) {
   if (!c || !in_dev || !out_dev || !omega || log_n > FR_S) return CQ_ERR_ARG;
-  if ((const void*)in_dev == (void*)out_dev) return c->fail(CQ_ERR_ARG, "in and out must differ");
   CQ_HIP(c, hipSetDevice(c->device));
   return fft_dev(c, (const Fr*)in_dev, (Fr*)out_dev, log_n, Fr::from_limbs64(omega));
 }

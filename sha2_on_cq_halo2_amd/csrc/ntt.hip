@@ -182,21 +182,19 @@ int ntt_run(const NttTables& tb, const Fr* in, Fr* out, Fr* scratch, const NttIo
       rem -= d;
     }
   }
-  // ping-pong so that the last pass lands in `out`; the input buffer is never written
-  // unless in == out (in-place): then pass 0 writes scratch.
+  // intermediate passes ping-pong between the two halves of `scratch`; only the last pass writes
+  // `out` (which may be shorter than n when the result is truncated, and may alias `in`).
+  Fr* sbuf[2] = {scratch, scratch + (size_t)io.batch * n};
   const Fr* src = in;
   uint32_t lgp = 0;
   for (uint32_t ps = 0; ps < npass; ps++) {
     const bool last = (ps + 1 == npass);
-    Fr* dst;
-    if (last) dst = out;
-    else dst = (((npass - 1 - ps) & 1) ? scratch : out);
-    if (dst == src) return -2;  // cannot happen with the parity rule below
+    Fr* dst = last ? out : sbuf[ps & 1];
     NttPassArgs a;
     a.in = src;
     a.out = dst;
-    a.in_stride = (ps == 0) ? io.in_stride : ((src == out) ? io.out_stride : io.scratch_stride);
-    a.out_stride = (dst == out) ? io.out_stride : io.scratch_stride;
+    a.in_stride = (ps == 0) ? io.in_stride : (size_t)n;
+    a.out_stride = last ? io.out_stride : (size_t)n;
     a.log_n = log_n;
     a.lgp = lgp;
     a.deg = degs[ps];

@@ -53,7 +53,7 @@ struct NttTables {
 
 struct NttIo {
   uint32_t batch = 1;
-  size_t in_stride = 0, out_stride = 0, scratch_stride = 0;
+  size_t in_stride = 0, out_stride = 0;
   uint32_t in_len = 0, out_len = 0;
   bool in_coset = false;
   Fr in_coset_mul[2];
@@ -62,8 +62,8 @@ struct NttIo {
   cq_ctx* prof = nullptr;  // when set and profiling is on, passes are bracketed with HIP events
 };
 
-// out = NTT(in) over `tb`; `in`, `out`, `scratch` pairwise distinct, each batch x 2^log_n elements
-// (the input may be shorter: io.in_len).  The input is left untouched.
+// out = NTT(in) over `tb`.  `scratch` holds 2 * batch * 2^log_n elements; `in` may be shorter
+// (io.in_len, zero-padded), `out` may be shorter (io.out_len, truncated) and may alias `in`.
 int ntt_run(const NttTables& tb, const Fr* in, Fr* out, Fr* scratch, const NttIo& io, hipStream_t stream);
 
 }  // namespace cq

@@ -1,0 +1,66 @@
+// Internal interface of the streaming polynomial kernels (poly.hip) and EvaluationDomain (domain.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <vector>
+#include "field.hpp"
+#include "ntt.hpp"
+
+struct cq_ctx;
+
+namespace cq {
+
+constexpr uint32_t POLY_CHUNK = 64;   // coefficients per lane in chunked Horner / division
+constexpr uint32_t LINCOMB_MAX = 40;  // polynomials per linear combination launch
+constexpr uint32_t CQ_MAX_LOOKUPS = 16;
+
+struct LincombArgs {
+  const Fr* p[LINCOMB_MAX];
+  uint32_t len[LINCOMB_MAX];
+  Fr coeff[LINCOMB_MAX];
+  uint32_t count;
+  Fr sub_const;  // subtracted from coefficient 0
+};
+
+struct CqQuotientArgs {
+  const Fr* b[CQ_MAX_LOOKUPS];
+  const Fr* f[CQ_MAX_LOOKUPS];
+  uint32_t count;
+  const Fr* l_active;
+  const Fr* t_evals;
+  uint32_t t_len;
+  Fr y, beta;
+};
+
+int poly_eval(cq_ctx* c, const Fr* a_dev, uint32_t n, const Fr& z, Fr* out_host);
+int poly_kate_division(cq_ctx* c, const Fr* a_dev, uint32_t n, const Fr& z, Fr* q_dev);
+int poly_batch_invert(cq_ctx* c, Fr* a_dev, uint32_t n);
+int poly_lincomb(cq_ctx* c, const LincombArgs& args, uint32_t n, Fr* out_dev);
+int poly_from_u512(cq_ctx* c, const uint64_t* words_dev, uint32_t n, Fr* out_dev);
+int poly_cq_b_denominators(cq_ctx* c, const Fr* f, uint32_t n, uint32_t u, const Fr& beta, Fr* out);
+int poly_cq_quotient(cq_ctx* c, const CqQuotientArgs& args, uint32_t ext, Fr* h);
+int poly_fill_usable_rows(cq_ctx* c, Fr* out, uint32_t n, uint32_t u);
+
+}  // namespace cq
+
+// EvaluationDomain<Fr> (poly/domain.rs:19-34): constants on the host, twiddles cached in the context.
+struct cq_domain {
+  cq_ctx* ctx;
+  uint32_t j, k, extended_k, quotient_poly_degree;
+  cq::Fr omega, omega_inv, extended_omega, extended_omega_inv, g_coset, g_coset_inv, ifft_divisor,
+      extended_ifft_divisor, barycentric_weight;
+  std::vector<cq::Fr> t_evaluations;
+  cq::Fr* t_evaluations_dev = nullptr;
+  size_t n() const { return (size_t)1 << k; }
+  size_t ext() const { return (size_t)1 << extended_k; }
+};
+
+namespace cq {
+int domain_create(cq_ctx* c, uint32_t j, uint32_t k, cq_domain** out);
+void domain_destroy(cq_domain* d);
+// batch of columns, contiguous with the given strides (elements)
+int domain_lagrange_to_coeff(cq_domain* d, const Fr* in, Fr* out, uint32_t batch, size_t in_stride, size_t out_stride);
+int domain_coeff_to_extended(cq_domain* d, const Fr* in, Fr* out, uint32_t batch, size_t in_stride, size_t out_stride);
+int domain_extended_to_coeff(cq_domain* d, const Fr* in, Fr* out /* n*(j-1) */);
+int domain_fft(cq_ctx* c, const Fr* in, Fr* out, uint32_t log_n, const Fr& omega, uint32_t batch, size_t in_stride,
+               size_t out_stride);
+}  // namespace cq
