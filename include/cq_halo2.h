@@ -37,10 +37,17 @@ extern "C" {
 #define CQ_ERR_NO_DEVICE (-3)
 #define CQ_ERR_LOOKUP (-4)   /* CQ: witness value not in table / vector lookup on different rows */
 #define CQ_ERR_INTERNAL (-5)
+#define CQ_ERR_TRANSCRIPT (-6) /* a commitment was the identity (transcript.rs:221-227) */
 
 typedef struct cq_ctx cq_ctx;
 typedef struct cq_domain cq_domain;   /* EvaluationDomain<Fr>, poly/domain.rs:19-34 */
 typedef struct cq_params cq_params;   /* ParamsKZG<Bn256> G1 part, poly/kzg/commitment.rs:31-39 */
+typedef struct cq_table_config cq_table_config; /* StaticTableConfig, plonk/static_lookup.rs:47-66 */
+typedef struct cq_static_table cq_static_table; /* StaticTableValues, plonk/static_lookup.rs:68-75 */
+typedef struct cq_pk cq_pk;           /* ProvingKey slice read by the CQ-only prover, plonk.rs:291-308 */
+/* `R: RngCore` of create_proof (plonk/prover.rs:65): the library calls next_u64 exactly as
+ * `Fr::random` does (8 calls per scalar, low limb first, bn256/fr.rs:159-170). */
+typedef uint64_t (*cq_rng_next_u64)(void* state);
 
 /* ---- context ------------------------------------------------------------------------- */
 /* `hip_stream` may be NULL (the library creates its own stream) or an existing hipStream_t
@@ -134,6 +141,75 @@ int cq_commit(cq_params* params, const uint64_t* poly, size_t len, uint64_t out_
 int cq_commit_lagrange(cq_params* params, const uint64_t* poly, size_t len, uint64_t out_jac[12]);
 int cq_commit_dev(cq_params* params, const uint64_t* poly_dev, size_t len, uint64_t out_jac[12]);
 int cq_commit_lagrange_dev(cq_params* params, const uint64_t* poly_dev, size_t len, uint64_t out_jac[12]);
+
+/* ---- plonk/static_lookup.rs, plonk/keygen.rs, plonk/prover.rs ------------------------------- */
+/* StaticTableConfig::new(size, g1_lagrange, g_lagrange_opening_at_0)  static_lookup.rs:55-65
+ * (host arrays of `size` affine points; `size` a power of two). */
+int cq_table_config_create(cq_ctx* ctx, size_t size, const uint64_t* g1_lagrange,
+                           const uint64_t* g_lagrange_opening_at_0, cq_table_config** out);
+/* G1 part of TableSRS::setup_from_toxic_waste (kzg/commitment.rs:73-178), built on the GPU (tests/benches). */
+int cq_table_config_setup_from_toxic_waste(cq_ctx* ctx, size_t size, const uint64_t s[4], cq_table_config** out);
+void cq_table_config_destroy(cq_table_config* cfg);
+int cq_table_config_download(cq_table_config* cfg, uint64_t* g1_lagrange, uint64_t* g_lagrange_opening_at_0);
+/* StaticTableValues {size, value_index_mapping, qs}  static_lookup.rs:68-75.  `values`: `size` unique
+ * field elements (CQ_ERR_ARG if not unique, as the assert at :84-85); `qs`: the cached quotient
+ * commitments as affine points (normalise the reference's Vec<G1> first). */
+int cq_static_table_create(cq_ctx* ctx, size_t size, const uint64_t* values, const uint64_t* qs_affine,
+                           cq_static_table** out);
+/* Same, with qs computed in closed form from the toxic waste: Q_i = [(T(s)-T(w^i))/(s-w^i) * w^i/N]_1
+ * (equal to StaticTableValues::new's O(N^2) result, static_lookup.rs:108-119; tests/benches). */
+int cq_static_table_setup_from_toxic_waste(cq_ctx* ctx, size_t size, const uint64_t* values, const uint64_t s[4],
+                                           cq_static_table** out);
+void cq_static_table_destroy(cq_static_table* table);
+int cq_static_table_download_qs(cq_static_table* table, uint64_t* qs_affine);
+
+/* Shape of a CQ-only constraint system (stands in for ConstraintSystem, plonk/circuit.rs):
+ * `num_advice` advice columns; lookup l has `lookup_widths[l]` (input, table) pairs; inputs are
+ * advice[column] @ Rotation::cur() (lookup_static, circuit.rs:1579-1602), flattened in
+ * lookup_columns / lookup_tables.  vk_repr = VerifyingKey::transcript_repr (plonk.rs:221-232). */
+typedef struct {
+  uint32_t k;
+  uint32_t num_advice;
+  uint32_t num_lookups;
+  const uint32_t* lookup_widths;
+  const uint32_t* lookup_columns;
+  cq_static_table* const* lookup_tables;
+  uint64_t vk_repr[4];
+} cq_circuit;
+/* keygen_pk (plonk/keygen.rs:278-397) restricted to what the CQ-only prover reads: the domain,
+ * l_active_row on the extended coset (:366-373), the table config and `b0_g1_bound` (n-1 affine
+ * points; device pointer if b0_on_device != 0, else host). */
+int cq_pk_create(cq_ctx* ctx, cq_params* params, const cq_circuit* circuit, cq_table_config* cfg,
+                 const uint64_t* b0_g1_bound, int b0_on_device, cq_pk** out);
+void cq_pk_destroy(cq_pk* pk);
+uint32_t cq_pk_usable_rows(const cq_pk* pk);
+size_t cq_pk_proof_size(const cq_pk* pk);
+/* create_proof (plonk/prover.rs:51-779) with ProverGWC + Blake2bWrite<Challenge255>.
+ * advice_dev: `num_advice` DEVICE pointers to 2^k field elements each; rows [0, usable_rows) are the
+ * assigned witness (unassigned cells zero), the rest is ignored (blinding rows are drawn from rng).
+ * The proof (cq_pk_proof_size bytes) is written to `proof`. */
+int cq_create_proof(cq_pk* pk, const uint64_t* const* advice_dev, cq_rng_next_u64 rng, void* rng_state,
+                    uint8_t* proof, size_t proof_cap, size_t* proof_len);
+/* Same with host-resident advice columns (uploaded first). */
+int cq_create_proof_host(cq_pk* pk, const uint64_t* const* advice, cq_rng_next_u64 rng, void* rng_state,
+                         uint8_t* proof, size_t proof_cap, size_t* proof_len);
+
+/* ---- sha/src/tables.rs: SHA-256 word -> limb witness fill ----------------------------------------- */
+/* Decomposes `nwords` 32-bit words (device) into 12/10/10-bit limbs (LongLimbs, tables.rs:70-75,
+ * 135-154) and writes, for limb t, its dense value to column 2*(t % pairs) and its bit-spread value
+ * (bit i -> bit 2i) to column 2*(t % pairs)+1 at row t / pairs, Montgomery-encoded.  `cols_dev`:
+ * 2*pairs device columns of `n` elements, zero-filled by the caller. */
+int cq_sha_witness_fill_dev(cq_ctx* ctx, const uint32_t* words_dev, size_t nwords, uint32_t pairs, size_t n,
+                            uint64_t* const* cols_dev);
+/* dense[i] = i, spread[i] = bit-spread(i) for i < size (device arrays of `size` elements). */
+int cq_sha_spread_table_dev(cq_ctx* ctx, size_t size, uint64_t* dense_dev, uint64_t* spread_dev);
+
+/* ---- harness RNG (not in the reference: its test draws from OsRng) ---------------------------------- */
+void cq_xoshiro256ss_seed(uint64_t seed, uint64_t state[4]);
+uint64_t cq_xoshiro256ss_next_u64(void* state /* uint64_t[4] */);
+/* replays a pre-drawn stream: state = {const uint64_t* words; size_t pos; size_t len} */
+typedef struct { const uint64_t* words; size_t pos; size_t len; } cq_buffer_rng;
+uint64_t cq_buffer_rng_next_u64(void* state /* cq_buffer_rng* */);
 
 /* ---- measurement support ---------------------------------------------------------------------- */
 /* When enabled, the library brackets its dominant kernels with HIP events on the context's stream.

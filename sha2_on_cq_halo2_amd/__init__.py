@@ -8,4 +8,5 @@ the tests and the bench; arrays are numpy uint64[..., 4] Montgomery limbs, exact
 the Rust side holds.
 """
 from ._lib import CqError, load, header_symbols  # noqa: F401
-from .api import Context, ParamsKZG, DevBuf, EvaluationDomain  # noqa: F401
+from .api import (Context, DevBuf, EvaluationDomain, ParamsKZG, ProvingKey, StaticTable,  # noqa: F401
+                  TableConfig)

@@ -107,5 +107,32 @@ def _declare(lib):  # noqa: F811
     lib.cq_lagrange_to_coeff_dev.argtypes = [vp, vp, vp, C.c_uint32]
     lib.cq_coeff_to_extended_dev.argtypes = [vp, vp, vp, C.c_uint32]
     lib.cq_extended_to_coeff_dev.argtypes = [vp, vp, vp]
+    lib.cq_table_config_create.argtypes = [vp, C.c_size_t, vp, vp, C.POINTER(vp)]
+    lib.cq_table_config_setup_from_toxic_waste.argtypes = [vp, C.c_size_t, vp, C.POINTER(vp)]
+    lib.cq_table_config_destroy.restype = None
+    lib.cq_table_config_destroy.argtypes = [vp]
+    lib.cq_table_config_download.argtypes = [vp, vp, vp]
+    lib.cq_static_table_create.argtypes = [vp, C.c_size_t, vp, vp, C.POINTER(vp)]
+    lib.cq_static_table_setup_from_toxic_waste.argtypes = [vp, C.c_size_t, vp, vp, C.POINTER(vp)]
+    lib.cq_static_table_destroy.restype = None
+    lib.cq_static_table_destroy.argtypes = [vp]
+    lib.cq_static_table_download_qs.argtypes = [vp, vp]
+    lib.cq_pk_create.argtypes = [vp, vp, vp, vp, vp, C.c_int, C.POINTER(vp)]
+    lib.cq_pk_destroy.restype = None
+    lib.cq_pk_destroy.argtypes = [vp]
+    lib.cq_pk_usable_rows.restype = C.c_uint32
+    lib.cq_pk_usable_rows.argtypes = [vp]
+    lib.cq_pk_proof_size.restype = C.c_size_t
+    lib.cq_pk_proof_size.argtypes = [vp]
+    lib.cq_create_proof.argtypes = [vp, vp, vp, vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
+    lib.cq_create_proof_host.argtypes = [vp, vp, vp, vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
+    lib.cq_sha_witness_fill_dev.argtypes = [vp, vp, C.c_size_t, C.c_uint32, C.c_size_t, vp]
+    lib.cq_sha_spread_table_dev.argtypes = [vp, C.c_size_t, vp, vp]
+    lib.cq_xoshiro256ss_seed.restype = None
+    lib.cq_xoshiro256ss_seed.argtypes = [C.c_uint64, vp]
+    lib.cq_xoshiro256ss_next_u64.restype = C.c_uint64
+    lib.cq_xoshiro256ss_next_u64.argtypes = [vp]
+    lib.cq_buffer_rng_next_u64.restype = C.c_uint64
+    lib.cq_buffer_rng_next_u64.argtypes = [vp]
     lib.cq_profile_enable.argtypes = [vp, C.c_int]
     lib.cq_profile_read.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]

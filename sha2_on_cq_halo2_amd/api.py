@@ -357,3 +357,170 @@ class EvaluationDomain:
             self.close()
         except Exception:
             pass
+
+
+# ---- CQ static lookup objects and the prover ----------------------------------------------------------
+class _Handle:
+    _destroy = None
+
+    def close(self):
+        if self.h and self.ctx.h:
+            getattr(self.ctx.lib, self._destroy)(self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class TableConfig(_Handle):
+    """`StaticTableConfig` (plonk/static_lookup.rs:47-66)."""
+
+    _destroy = "cq_table_config_destroy"
+
+    def __init__(self, ctx: Context, g1_lagrange: np.ndarray, g_lagrange_opening_at_0: np.ndarray):
+        a, b = _g1(g1_lagrange), _g1(g_lagrange_opening_at_0)
+        assert a.shape == b.shape
+        self.ctx, self.size = ctx, a.shape[0]
+        h = C.c_void_p()
+        ctx._chk(ctx.lib.cq_table_config_create(ctx.h, self.size, a.ctypes.data, b.ctypes.data, C.byref(h)))
+        self.h = h
+        ctx._children.add(self)
+
+    @classmethod
+    def setup_from_toxic_waste(cls, ctx: Context, size: int, s: np.ndarray) -> "TableConfig":
+        self = cls.__new__(cls)
+        self.ctx, self.size = ctx, size
+        sm = np.ascontiguousarray(s, dtype=np.uint64).reshape(4)
+        h = C.c_void_p()
+        ctx._chk(ctx.lib.cq_table_config_setup_from_toxic_waste(ctx.h, size, sm.ctypes.data, C.byref(h)))
+        self.h = h
+        ctx._children.add(self)
+        return self
+
+    def download(self):
+        a = np.empty((self.size, 8), dtype=np.uint64)
+        b = np.empty((self.size, 8), dtype=np.uint64)
+        self.ctx._chk(self.ctx.lib.cq_table_config_download(self.h, a.ctypes.data, b.ctypes.data))
+        return a, b
+
+
+class StaticTable(_Handle):
+    """`StaticTableValues` (plonk/static_lookup.rs:68-75)."""
+
+    _destroy = "cq_static_table_destroy"
+
+    def __init__(self, ctx: Context, values: np.ndarray, qs_affine: np.ndarray):
+        v, q = _fr(values), _g1(qs_affine)
+        assert v.shape[0] == q.shape[0]
+        self.ctx, self.size = ctx, v.shape[0]
+        h = C.c_void_p()
+        ctx._chk(ctx.lib.cq_static_table_create(ctx.h, self.size, v.ctypes.data, q.ctypes.data, C.byref(h)))
+        self.h = h
+        ctx._children.add(self)
+
+    @classmethod
+    def setup_from_toxic_waste(cls, ctx: Context, values: np.ndarray, s: np.ndarray) -> "StaticTable":
+        self = cls.__new__(cls)
+        v = _fr(values)
+        self.ctx, self.size = ctx, v.shape[0]
+        sm = np.ascontiguousarray(s, dtype=np.uint64).reshape(4)
+        h = C.c_void_p()
+        ctx._chk(ctx.lib.cq_static_table_setup_from_toxic_waste(ctx.h, self.size, v.ctypes.data, sm.ctypes.data, C.byref(h)))
+        self.h = h
+        ctx._children.add(self)
+        return self
+
+    def download_qs(self) -> np.ndarray:
+        q = np.empty((self.size, 8), dtype=np.uint64)
+        self.ctx._chk(self.ctx.lib.cq_static_table_download_qs(self.h, q.ctypes.data))
+        return q
+
+
+class _CqCircuit(C.Structure):
+    _fields_ = [
+        ("k", C.c_uint32),
+        ("num_advice", C.c_uint32),
+        ("num_lookups", C.c_uint32),
+        ("lookup_widths", C.POINTER(C.c_uint32)),
+        ("lookup_columns", C.POINTER(C.c_uint32)),
+        ("lookup_tables", C.POINTER(C.c_void_p)),
+        ("vk_repr", C.c_uint64 * 4),
+    ]
+
+
+class _BufferRng(C.Structure):
+    _fields_ = [("words", C.POINTER(C.c_uint64)), ("pos", C.c_size_t), ("len", C.c_size_t)]
+
+
+class ProvingKey(_Handle):
+    """The slice of `ProvingKey` (plonk.rs:291-308) that `create_proof` reads for a CQ-only circuit.
+
+    lookups: list of lookups, each a list of (advice column, StaticTable)."""
+
+    _destroy = "cq_pk_destroy"
+
+    def __init__(self, ctx: Context, params: ParamsKZG, k: int, num_advice: int, lookups, table_cfg: TableConfig,
+                 b0_g1_bound, vk_repr: np.ndarray):
+        self.ctx, self.params, self.k = ctx, params, k
+        self._keep = (params, table_cfg, [t for lk in lookups for _, t in lk])
+        widths = (C.c_uint32 * max(len(lookups), 1))(*[len(lk) for lk in lookups])
+        flat_cols = [c for lk in lookups for c, _ in lk]
+        flat_tabs = [t.h.value if isinstance(t.h, C.c_void_p) else t.h for lk in lookups for _, t in lk]
+        cols = (C.c_uint32 * max(len(flat_cols), 1))(*flat_cols)
+        tabs = (C.c_void_p * max(len(flat_tabs), 1))(*flat_tabs)
+        cs = _CqCircuit()
+        cs.k, cs.num_advice, cs.num_lookups = k, num_advice, len(lookups)
+        cs.lookup_widths = C.cast(widths, C.POINTER(C.c_uint32))
+        cs.lookup_columns = C.cast(cols, C.POINTER(C.c_uint32))
+        cs.lookup_tables = C.cast(tabs, C.POINTER(C.c_void_p))
+        vr = np.ascontiguousarray(vk_repr, dtype=np.uint64).reshape(4)
+        for i in range(4):
+            cs.vk_repr[i] = int(vr[i])
+        h = C.c_void_p()
+        if isinstance(b0_g1_bound, (int,)):
+            b0_ptr, on_dev = b0_g1_bound, 1
+        else:
+            b0 = _g1(b0_g1_bound)
+            assert b0.shape[0] == (1 << k) - 1, "b0_g1_bound must hold n-1 points (arithmetic.rs:133)"
+            self._b0 = b0
+            b0_ptr, on_dev = b0.ctypes.data, 0
+        ctx._chk(ctx.lib.cq_pk_create(ctx.h, params.h, C.byref(cs), table_cfg.h, b0_ptr, on_dev, C.byref(h)))
+        self.h = h
+        self.num_advice = num_advice
+        self.usable_rows = ctx.lib.cq_pk_usable_rows(h)
+        self.proof_size = ctx.lib.cq_pk_proof_size(h)
+        ctx._children.add(self)
+
+    def _run(self, fn, ptrs, rng_fn, rng_state) -> bytes:
+        arr = (C.c_void_p * max(len(ptrs), 1))(*ptrs)
+        proof = (C.c_uint8 * self.proof_size)()
+        plen = C.c_size_t()
+        self.ctx._chk(fn(self.h, arr, rng_fn, rng_state, proof, self.proof_size, C.byref(plen)))
+        return bytes(proof[: plen.value])
+
+    def _rng(self, rng_words=None, seed=None):
+        lib = self.ctx.lib
+        if rng_words is not None:
+            w = np.ascontiguousarray(rng_words, dtype=np.uint64)
+            st = _BufferRng(w.ctypes.data_as(C.POINTER(C.c_uint64)), 0, w.shape[0])
+            self._rng_keep = (w, st)
+            return C.cast(lib.cq_buffer_rng_next_u64, C.c_void_p), C.cast(C.byref(st), C.c_void_p)
+        st = (C.c_uint64 * 4)()
+        lib.cq_xoshiro256ss_seed(seed, st)
+        self._rng_keep = st
+        return C.cast(lib.cq_xoshiro256ss_next_u64, C.c_void_p), C.cast(st, C.c_void_p)
+
+    def create_proof(self, advice, rng_words=None, seed=None) -> bytes:
+        """`create_proof` (plonk/prover.rs:51) with host advice columns (uint64[n,4] each; rows
+        beyond the usable rows are ignored).  RNG: a pre-drawn u64 stream or a xoshiro256** seed."""
+        cols = [np.ascontiguousarray(a, dtype=np.uint64) for a in advice]
+        assert len(cols) == self.num_advice and all(c.shape == (1 << self.k, 4) for c in cols)
+        fn, st = self._rng(rng_words, seed)
+        return self._run(self.ctx.lib.cq_create_proof_host, [c.ctypes.data for c in cols], fn, st)
+
+    def create_proof_dev(self, advice_ptrs, rng_words=None, seed=None) -> bytes:
+        fn, st = self._rng(rng_words, seed)
+        return self._run(self.ctx.lib.cq_create_proof, list(advice_ptrs), fn, st)

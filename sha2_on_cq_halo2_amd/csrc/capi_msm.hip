@@ -5,16 +5,9 @@
 #include "ctx.hpp"
 #include "msm.hpp"
 #include "setup.hpp"
+#include "cq.hpp"
 
 using namespace cq;
-
-struct cq_params {
-  cq_ctx* ctx;
-  uint32_t k;
-  size_t n;
-  G1Affine* g;           // [s^i]_1
-  G1Affine* g_lagrange;  // [L_i(s)]_1
-};
 
 static uint32_t pick_c(cq_ctx* c, uint32_t n) {
   if (c->msm_c) return c->msm_c;

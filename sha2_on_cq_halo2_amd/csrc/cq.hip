@@ -1,0 +1,229 @@
+// CQ ("cached quotients") static-lookup argument, device side: table objects and the per-row /
+// per-table-entry kernels of prover rounds 1 and 2 (halo2_proofs/src/plonk/static_lookup.rs,
+// plonk/static_lookup/prover.rs).  The reference walks BTreeMaps row by row on one thread and adds
+// commitments with serial double-and-add; here the value->index map is an open-addressing hash table
+// in HBM, multiplicities are a dense atomic histogram, and every commitment is a (dense) MSM.
+// Also: the SHA-256 word -> (dense limb, spread limb) witness fill (sha/src/tables.rs).
+#include "cq.hpp"
+#include "ctx.hpp"
+
+namespace cq {
+
+static __device__ __forceinline__ Fr ld(const Fr* p) {
+  const uint4* q = reinterpret_cast<const uint4*>(p);
+  uint4 a = q[0], b = q[1];
+  Fr r;
+  r.v.l[0] = a.x; r.v.l[1] = a.y; r.v.l[2] = a.z; r.v.l[3] = a.w;
+  r.v.l[4] = b.x; r.v.l[5] = b.y; r.v.l[6] = b.z; r.v.l[7] = b.w;
+  return r;
+}
+static __device__ __forceinline__ void st(Fr* p, const Fr& r) {
+  uint4* q = reinterpret_cast<uint4*>(p);
+  q[0] = make_uint4(r.v.l[0], r.v.l[1], r.v.l[2], r.v.l[3]);
+  q[1] = make_uint4(r.v.l[4], r.v.l[5], r.v.l[6], r.v.l[7]);
+}
+
+// ---- value -> index hash table (replaces BTreeMap<Fr, usize>, static_lookup.rs:72,82-85) ------------
+static __device__ __forceinline__ uint32_t hash_fr(const Fr& v) {
+  uint32_t h = 0x9e3779b9u;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    h ^= v.v.l[i];
+    h *= 0x85ebca6bu;
+    h ^= h >> 15;
+  }
+  return h;
+}
+
+constexpr uint32_t EMPTY = 0xffffffffu;
+
+// slot array of `nslots` (power of two) table indices; values are compared in full (256 bits)
+__global__ void table_insert_kernel(const Fr* __restrict__ values, uint32_t N, uint32_t* __restrict__ slots, uint32_t nslots,
+                                    uint32_t* __restrict__ err) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const Fr v = ld(values + i);
+  uint32_t s = hash_fr(v) & (nslots - 1);
+  for (uint32_t probe = 0; probe < nslots; probe++) {
+    const uint32_t prev = atomicCAS(&slots[s], EMPTY, i);
+    if (prev == EMPTY) return;
+    if (prev != i && ld(values + prev) == v) {
+      atomicExch(err, 1u);  // duplicate table value (static_lookup.rs:84-85 assert)
+      return;
+    }
+    s = (s + 1) & (nslots - 1);
+  }
+  atomicExch(err, 2u);
+}
+
+static __device__ __forceinline__ uint32_t table_find(const Fr* __restrict__ values, const uint32_t* __restrict__ slots,
+                                                      uint32_t nslots, const Fr& v) {
+  uint32_t s = hash_fr(v) & (nslots - 1);
+  for (uint32_t probe = 0; probe < nslots; probe++) {
+    const uint32_t idx = slots[s];
+    if (idx == EMPTY) return EMPTY;
+    if (ld(values + idx) == v) return idx;
+    s = (s + 1) & (nslots - 1);
+  }
+  return EMPTY;
+}
+
+// ---- round 1 (static_lookup/prover.rs:132-161): row -> table index, multiplicities --------------------
+__global__ __launch_bounds__(256) void cq_round1_kernel(CqRound1Args a, uint32_t u, uint32_t* __restrict__ m_counts,
+                                                        uint32_t* __restrict__ err) {
+  const uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= u) return;
+  uint32_t idx = EMPTY;
+  for (uint32_t j = 0; j < a.width; j++) {
+    const Fr v = ld(a.cols[j] + row);
+    const uint32_t ix = table_find(a.values[j], a.slots[j], a.nslots[j], v);
+    if (ix == EMPTY) {
+      atomicExch(err, 1u);  // "{:?} not in table" (:141)
+      return;
+    }
+    if (j && ix != idx) {
+      atomicExch(err, 2u);  // "Vector lookup must be on the same table row" (:148)
+      return;
+    }
+    idx = ix;
+  }
+  atomicAdd(&m_counts[idx], 1u);
+}
+
+// ---- round 2 (static_lookup/prover.rs:245-257), dense over the table -----------------------------------
+// den[i] = m[i] ? t[i] + beta : 0           (t = theta-compressed table values)
+__global__ void cq_a_denominators_kernel(const Fr* __restrict__ t, const uint32_t* __restrict__ m, uint32_t N, Fr beta,
+                                         Fr* __restrict__ den) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  st(den + i, m[i] ? ld(t + i) + beta : Fr::zero());
+}
+// a[i] = m[i] * den_inv[i]; scaled copies a[i]*theta^(w-1-j) for the q_a MSM over [qs_0 | qs_1 | ...]
+__global__ void cq_a_values_kernel(const Fr* __restrict__ den_inv, const uint32_t* __restrict__ m, uint32_t N, CqThetaPowers tp,
+                                   Fr* __restrict__ a, Fr* __restrict__ a_scaled /* width*N */) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const uint32_t mi = m[i];
+  Fr ai = Fr::zero();
+  if (mi) ai = Fr::from_u64(mi) * ld(den_inv + i);
+  st(a + i, ai);
+  for (uint32_t j = 0; j < tp.width; j++) st(a_scaled + (size_t)j * N + i, mi ? ai * tp.pow[j] : Fr::zero());
+}
+// multiplicities as field elements (for m_cm)
+__global__ void cq_m_to_fr_kernel(const uint32_t* __restrict__ m, uint32_t N, Fr* __restrict__ out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  st(out + i, m[i] ? Fr::from_u64(m[i]) : Fr::zero());
+}
+
+// ---- closed-form cached quotients for test tables: sc[i] = (T(s) - T(w^i)) / (s - w^i) * w^i / N -----------
+__global__ void cq_qs_scalars_kernel(const Fr* __restrict__ values, uint32_t N, Fr ts, Fr s, Fr omega, Fr n_inv,
+                                     Fr* __restrict__ out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const Fr g = omega.pow_u64(i);
+  st(out + i, (ts - ld(values + i)) * (s - g).inv() * g * n_inv);
+}
+
+// ---- SHA-256 witness fill: 32-bit words -> 12/10/10 limbs (LongLimbs, sha/src/tables.rs:70-75) as
+//      (dense, spread) pairs, Montgomery-encoded, round-robin over `pairs` column pairs ---------------------
+static __device__ __forceinline__ uint32_t spread_bits(uint32_t x) {
+  // bit i of x -> bit 2i
+  x &= 0xffffu;
+  x = (x | (x << 8)) & 0x00ff00ffu;
+  x = (x | (x << 4)) & 0x0f0f0f0fu;
+  x = (x | (x << 2)) & 0x33333333u;
+  x = (x | (x << 1)) & 0x55555555u;
+  return x;
+}
+
+__global__ __launch_bounds__(256) void sha_witness_fill_kernel(const uint32_t* __restrict__ words, uint32_t nwords, uint32_t pairs,
+                                                               uint32_t n, ShaCols cols) {
+  // limb t (0..3*nwords) goes to pair (t % pairs), row (t / pairs)
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t rows = (3 * nwords + pairs - 1) / pairs;
+  if (t >= rows * pairs) return;
+  const uint32_t pr = t % pairs, row = t / pairs;
+  if (row >= n) return;
+  uint32_t limb = 0;
+  if (t < 3 * nwords) {
+    const uint32_t w = words[t / 3];
+    const uint32_t which = t % 3;  // tables.rs:139-149: x = a >> 20, y = (a >> 10) & 0x3ff, z = a & 0x3ff
+    limb = which == 0 ? (w >> 20) : which == 1 ? ((w >> 10) & 0x3ffu) : (w & 0x3ffu);
+  }
+  st(cols.p[2 * pr] + row, limb ? Fr::from_u64(limb) : Fr::zero());
+  const uint32_t sp = spread_bits(limb);
+  st(cols.p[2 * pr + 1] + row, sp ? Fr::from_u64(sp) : Fr::zero());
+}
+
+// dense / spread table columns of size N = 2^bits: values i and spread(i)
+__global__ void sha_spread_table_kernel(uint32_t N, Fr* __restrict__ dense, Fr* __restrict__ spread) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  st(dense + i, i ? Fr::from_u64(i) : Fr::zero());
+  const uint32_t sp = spread_bits(i);
+  st(spread + i, sp ? Fr::from_u64(sp) : Fr::zero());
+}
+
+// =================================================================================================
+static inline uint32_t blocks_for(uint32_t n) { return (n + 255) / 256; }
+
+int cq_table_build_index(cq_ctx* c, const Fr* values, uint32_t N, uint32_t** slots_out, uint32_t* nslots_out) {
+  uint32_t nslots = 4;
+  while (nslots < 4 * N) nslots <<= 1;
+  uint32_t* slots = nullptr;
+  uint32_t* err = nullptr;
+  if (hipMalloc(&slots, (size_t)nslots * 4) != hipSuccess) return c->fail(CQ_ERR_HIP, "hipMalloc(table slots)");
+  if (hipMalloc(&err, 4) != hipSuccess) {
+    hipFree(slots);
+    return c->fail(CQ_ERR_HIP, "hipMalloc(err)");
+  }
+  hipMemsetAsync(slots, 0xff, (size_t)nslots * 4, c->stream);
+  hipMemsetAsync(err, 0, 4, c->stream);
+  table_insert_kernel<<<blocks_for(N), 256, 0, c->stream>>>(values, N, slots, nslots, err);
+  uint32_t herr = 0;
+  hipMemcpyAsync(&herr, err, 4, hipMemcpyDeviceToHost, c->stream);
+  hipStreamSynchronize(c->stream);
+  hipFree(err);
+  if (herr) {
+    hipFree(slots);
+    return c->fail(CQ_ERR_ARG, herr == 1 ? "static table values are not unique" : "static table index overflow");
+  }
+  *slots_out = slots;
+  *nslots_out = nslots;
+  return CQ_OK;
+}
+
+int cq_round1(cq_ctx* c, const CqRound1Args& a, uint32_t u, uint32_t* m_counts, uint32_t* err_dev) {
+  if (u) cq_round1_kernel<<<blocks_for(u), 256, 0, c->stream>>>(a, u, m_counts, err_dev);
+  return hipGetLastError() == hipSuccess ? CQ_OK : c->fail(CQ_ERR_HIP, "cq_round1 launch failed");
+}
+
+int cq_a_denominators(cq_ctx* c, const Fr* t, const uint32_t* m, uint32_t N, const Fr& beta, Fr* den) {
+  cq_a_denominators_kernel<<<blocks_for(N), 256, 0, c->stream>>>(t, m, N, beta, den);
+  return hipGetLastError() == hipSuccess ? CQ_OK : c->fail(CQ_ERR_HIP, "cq_a_den launch failed");
+}
+int cq_a_values(cq_ctx* c, const Fr* den_inv, const uint32_t* m, uint32_t N, const CqThetaPowers& tp, Fr* a, Fr* a_scaled) {
+  cq_a_values_kernel<<<blocks_for(N), 256, 0, c->stream>>>(den_inv, m, N, tp, a, a_scaled);
+  return hipGetLastError() == hipSuccess ? CQ_OK : c->fail(CQ_ERR_HIP, "cq_a_values launch failed");
+}
+int cq_m_to_fr(cq_ctx* c, const uint32_t* m, uint32_t N, Fr* out) {
+  cq_m_to_fr_kernel<<<blocks_for(N), 256, 0, c->stream>>>(m, N, out);
+  return hipGetLastError() == hipSuccess ? CQ_OK : c->fail(CQ_ERR_HIP, "cq_m_to_fr launch failed");
+}
+int cq_qs_scalars(cq_ctx* c, const Fr* values, uint32_t N, const Fr& ts, const Fr& s, const Fr& omega, const Fr& n_inv, Fr* out) {
+  cq_qs_scalars_kernel<<<blocks_for(N), 256, 0, c->stream>>>(values, N, ts, s, omega, n_inv, out);
+  return hipGetLastError() == hipSuccess ? CQ_OK : c->fail(CQ_ERR_HIP, "cq_qs_scalars launch failed");
+}
+int sha_witness_fill(cq_ctx* c, const uint32_t* words_dev, uint32_t nwords, uint32_t pairs, uint32_t n, const ShaCols& cols) {
+  const uint32_t rows = (3 * nwords + pairs - 1) / pairs;
+  if (rows > n) return c->fail(CQ_ERR_ARG, "sha witness does not fit the usable rows");
+  if (rows) sha_witness_fill_kernel<<<blocks_for(rows * pairs), 256, 0, c->stream>>>(words_dev, nwords, pairs, n, cols);
+  return hipGetLastError() == hipSuccess ? CQ_OK : c->fail(CQ_ERR_HIP, "sha_witness_fill launch failed");
+}
+int sha_spread_table(cq_ctx* c, uint32_t N, Fr* dense, Fr* spread) {
+  sha_spread_table_kernel<<<blocks_for(N), 256, 0, c->stream>>>(N, dense, spread);
+  return hipGetLastError() == hipSuccess ? CQ_OK : c->fail(CQ_ERR_HIP, "sha_spread_table launch failed");
+}
+
+}  // namespace cq

@@ -1,0 +1,88 @@
+// Internal interface of the CQ device kernels (cq.hip) and the proving-key objects.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <vector>
+#include "curve.hpp"
+#include "poly.hpp"
+
+struct cq_ctx;
+struct cq_params;
+
+namespace cq {
+
+constexpr uint32_t CQ_MAX_WIDTH = 8;  // table columns per vector lookup
+
+struct CqRound1Args {
+  const Fr* cols[CQ_MAX_WIDTH];      // input expression values (advice columns), n each
+  const Fr* values[CQ_MAX_WIDTH];    // table values, N each
+  const uint32_t* slots[CQ_MAX_WIDTH];
+  uint32_t nslots[CQ_MAX_WIDTH];
+  uint32_t width;
+};
+struct CqThetaPowers {
+  Fr pow[CQ_MAX_WIDTH];  // theta^(width-1-j)
+  uint32_t width;
+};
+struct ShaCols {
+  Fr* p[16];
+};
+
+int cq_table_build_index(cq_ctx* c, const Fr* values, uint32_t N, uint32_t** slots_out, uint32_t* nslots_out);
+int cq_round1(cq_ctx* c, const CqRound1Args& a, uint32_t u, uint32_t* m_counts, uint32_t* err_dev);
+int cq_a_denominators(cq_ctx* c, const Fr* t, const uint32_t* m, uint32_t N, const Fr& beta, Fr* den);
+int cq_a_values(cq_ctx* c, const Fr* den_inv, const uint32_t* m, uint32_t N, const CqThetaPowers& tp, Fr* a, Fr* a_scaled);
+int cq_m_to_fr(cq_ctx* c, const uint32_t* m, uint32_t N, Fr* out);
+int cq_qs_scalars(cq_ctx* c, const Fr* values, uint32_t N, const Fr& ts, const Fr& s, const Fr& omega, const Fr& n_inv, Fr* out);
+int sha_witness_fill(cq_ctx* c, const uint32_t* words_dev, uint32_t nwords, uint32_t pairs, uint32_t n, const ShaCols& cols);
+int sha_spread_table(cq_ctx* c, uint32_t N, Fr* dense, Fr* spread);
+
+}  // namespace cq
+
+// ParamsKZG G1 part (poly/kzg/commitment.rs:31-39), SRS resident in HBM
+struct cq_params {
+  cq_ctx* ctx;
+  uint32_t k;
+  size_t n;
+  cq::G1Affine* g;           // [s^i]_1
+  cq::G1Affine* g_lagrange;  // [L_i(s)]_1
+};
+
+// StaticTableConfig (plonk/static_lookup.rs:47-66): Lagrange SRS of the table-sized domain
+struct cq_table_config {
+  cq_ctx* ctx;
+  uint32_t log_n;
+  size_t N;
+  cq::G1Affine* g1_lagrange = nullptr;
+  cq::G1Affine* g_lagrange_opening_at_0 = nullptr;
+};
+
+// StaticTableValues (plonk/static_lookup.rs:68-75)
+struct cq_static_table {
+  cq_ctx* ctx;
+  size_t N;
+  cq::Fr* values = nullptr;
+  cq::G1Affine* qs = nullptr;  // cached quotient commitments, affine
+  uint32_t* slots = nullptr;   // value -> index hash table
+  uint32_t nslots = 0;
+};
+
+struct cq_lookup_desc {
+  std::vector<uint32_t> cols;             // advice column per table column (input = advice[col] @ Rotation::cur())
+  std::vector<cq_static_table*> tables;
+};
+
+// the slice of ProvingKey (plonk.rs:291-308) the CQ-only proving path reads
+struct cq_pk {
+  cq_ctx* ctx;
+  cq_params* params;
+  cq_domain* domain = nullptr;
+  uint32_t k, num_advice, bf, u;
+  std::vector<cq_lookup_desc> lookups;
+  std::vector<std::pair<uint32_t, uint32_t>> advice_queries;  // (column, rotation=0), first-seen order
+  cq_table_config* table_cfg;
+  cq::G1Affine* b0_g1_bound = nullptr;  // n-1 points
+  bool own_b0 = false;
+  cq::Fr* l_active_row = nullptr;       // extended coset
+  cq::Fr vk_repr;
+  std::vector<cq::G1Affine*> qs_concat;  // per lookup: [qs_0 | qs_1 | ...] (width*N points)
+};

@@ -145,8 +145,12 @@ struct Fp {
   CQ_HD Fp neg() const { return zero() - *this; }
   CQ_HD Fp dbl() const { return *this + *this; }
 
-  // Montgomery product, CIOS over 32-bit limbs (same function as derive/field.rs:471-564).
+  // Montgomery product (same function as derive/field.rs:471-564); result < p.
+  // Device: CIOS over 32-bit limbs (v_mad_u64_u32).  Host: CIOS over 64-bit limbs with a 128-bit
+  // accumulator -- identical values, ~4x fewer multiplies for the host-side glue (window folding,
+  // normalisation, transcript scalars).
   CQ_HD Fp operator*(const Fp& b) const {
+#if defined(__HIP_DEVICE_COMPILE__)
     uint32_t t[10];
     CQ_UNROLL for (int i = 0; i < 10; i++) t[i] = 0;
     CQ_UNROLL for (int i = 0; i < 8; i++) {
@@ -176,6 +180,48 @@ struct Fp {
     CQ_UNROLL for (int i = 0; i < 8; i++) r.v.l[i] = t[i];
     cond_sub_p(r.v.l, t[8]);
     return r;
+#else
+    typedef unsigned __int128 u128;
+    uint64_t a4[4], b4[4], m4[4];
+    for (int i = 0; i < 4; i++) {
+      a4[i] = (uint64_t)v.l[2 * i] | ((uint64_t)v.l[2 * i + 1] << 32);
+      b4[i] = (uint64_t)b.v.l[2 * i] | ((uint64_t)b.v.l[2 * i + 1] << 32);
+      m4[i] = (uint64_t)P::MOD[2 * i] | ((uint64_t)P::MOD[2 * i + 1] << 32);
+    }
+    // 64-bit -p^-1 mod 2^64 from the 32-bit one by one Newton step: inv64 = inv32 * (2 + p0 * inv32)
+    const uint64_t i32 = P::INV;
+    const uint64_t inv64 = i32 * (2 + m4[0] * i32);
+    uint64_t t[6] = {0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < 4; i++) {
+      u128 c = 0;
+      for (int j = 0; j < 4; j++) {
+        c += (u128)a4[j] * b4[i] + t[j];
+        t[j] = (uint64_t)c;
+        c >>= 64;
+      }
+      c += t[4];
+      t[4] = (uint64_t)c;
+      t[5] = (uint64_t)(c >> 64);
+      const uint64_t m = t[0] * inv64;
+      c = (u128)m * m4[0] + t[0];
+      c >>= 64;
+      for (int j = 1; j < 4; j++) {
+        c += (u128)m * m4[j] + t[j];
+        t[j - 1] = (uint64_t)c;
+        c >>= 64;
+      }
+      c += t[4];
+      t[3] = (uint64_t)c;
+      t[4] = t[5] + (uint64_t)(c >> 64);
+    }
+    Fp r;
+    for (int i = 0; i < 4; i++) {
+      r.v.l[2 * i] = (uint32_t)t[i];
+      r.v.l[2 * i + 1] = (uint32_t)(t[i] >> 32);
+    }
+    cond_sub_p(r.v.l, (uint32_t)t[4]);
+    return r;
+#endif
   }
   CQ_HD Fp sqr() const { return *this * *this; }
 

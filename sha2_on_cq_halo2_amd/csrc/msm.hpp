@@ -41,3 +41,8 @@ int msm_run(cq_ctx* ctx, const Fr* const* scalars, const G1Affine* const* bases,
 G1Jac msm_fold_windows(const G1Jac* window_sums, uint32_t W, uint32_t c);
 
 }  // namespace cq
+
+// `count` MSMs of equal length, each with its own device base array; Jacobian results on the host
+// (count x 12 limbs); one stream synchronisation per launch batch.
+int cq_msm_multi(cq_ctx* c, const cq::Fr* const* scalars, const cq::G1Affine* const* bases, size_t len, size_t count,
+                 uint64_t* out_jac);

@@ -1,0 +1,494 @@
+// Host orchestrator: `create_proof` for CQ-only circuits (halo2_proofs/src/plonk/prover.rs:51-779),
+// with the sub-arguments of plonk/static_lookup/prover.rs, plonk/vanishing/prover.rs,
+// plonk/evaluation.rs:533-548 and poly/kzg/multiopen/gwc/prover.rs.  Everything O(n) runs on the GPU
+// (polynomials never leave HBM); the host keeps the Fiat-Shamir transcript (transcript.rs:170-241),
+// draws the blinding scalars from the caller's RNG in the reference's order, folds MSM window sums
+// and normalises the handful of commitment points.  Call order, RNG order and transcript order are
+// the contract: the proof bytes equal the reference's for
+// the same (pk, witness, RNG stream).
+//
+// Scope: constraint systems with advice columns and static lookups whose inputs are
+// `advice[col] @ Rotation::cur()` -- the shape of the reference's one CQ test (tests/my_test.rs).
+// Gates, fixed/instance columns, permutations and legacy lookups are "next" rows.
+// One deliberate omission: evaluation.rs:317-325 also transforms every advice polynomial to the
+// extended coset although no CQ-only term reads them; that dead work is not reproduced.
+#include <cstring>
+#include <vector>
+#include "blake2b.hpp"
+#include "cq.hpp"
+#include "ctx.hpp"
+#include "msm.hpp"
+#include "prover.hpp"
+
+using namespace cq;
+
+namespace {
+
+struct Transcript {
+  Blake2b st;
+  std::vector<uint8_t> proof;
+  Transcript() { st.init(64, "Halo2-Transcript"); }
+  void common_scalar(const Fr& s) {
+    const uint8_t tag = 2;
+    st.update(&tag, 1);
+    U256 c = s.to_canonical();
+    st.update((const uint8_t*)c.l, 32);
+  }
+  // transcript.rs:221-233; identity is an error
+  bool common_point(const G1Affine& p) {
+    if (p.is_identity()) return false;
+    const uint8_t tag = 1;
+    st.update(&tag, 1);
+    U256 x = p.x.to_canonical(), y = p.y.to_canonical();
+    st.update((const uint8_t*)x.l, 32);
+    st.update((const uint8_t*)y.l, 32);
+    return true;
+  }
+  bool write_point(const G1Affine& p) {
+    if (!common_point(p)) return false;
+    U256 x = p.x.to_canonical(), y = p.y.to_canonical();
+    uint8_t b[32];
+    memcpy(b, x.l, 32);
+    b[31] |= (uint8_t)((y.l[0] & 1) << 7);  // derive/curve.rs:635-646
+    proof.insert(proof.end(), b, b + 32);
+    return true;
+  }
+  void write_scalar(const Fr& s) {
+    common_scalar(s);
+    U256 c = s.to_canonical();
+    const uint8_t* b = (const uint8_t*)c.l;
+    proof.insert(proof.end(), b, b + 32);
+  }
+  Fr squeeze() {
+    const uint8_t tag = 0;
+    st.update(&tag, 1);
+    uint8_t out[64];
+    st.finalize_clone(out);
+    uint64_t w[8];
+    memcpy(w, out, 64);
+    return Fr::from_u512(w);  // from_bytes_wide (transcript.rs:300-309)
+  }
+};
+
+// derive/curve.rs:362-397 `batch_normalize`
+void batch_normalize(const std::vector<G1Jac>& in, std::vector<G1Affine>& out) {
+  out.resize(in.size());
+  std::vector<Fq> pref(in.size());
+  Fq acc = Fq::one();
+  for (size_t i = 0; i < in.size(); i++) {
+    pref[i] = acc;
+    if (!in[i].is_identity()) acc = acc * in[i].z;
+  }
+  acc = acc.inv();
+  for (size_t i = in.size(); i-- > 0;) {
+    if (in[i].is_identity()) {
+      out[i] = G1Affine::identity();
+      continue;
+    }
+    Fq zi = pref[i] * acc;
+    acc = acc * in[i].z;
+    Fq zi2 = zi.sqr();
+    out[i] = {in[i].x * zi2, in[i].y * zi2 * zi};
+  }
+}
+
+G1Jac jac_from_limbs(const uint64_t* l) {
+  return {Fq::from_limbs64(l), Fq::from_limbs64(l + 4), Fq::from_limbs64(l + 8)};
+}
+
+struct Rng {
+  cq_rng_next_u64 next;
+  void* state;
+  // Fr::random (bn256/fr.rs:159-170): eight next_u64, low limb first
+  void words(uint64_t* w8) {
+    for (int i = 0; i < 8; i++) w8[i] = next(state);
+  }
+  Fr fr() {
+    uint64_t w[8];
+    words(w);
+    return Fr::from_u512(w);
+  }
+};
+
+// msms over device scalars; one host sync; results normalised
+int commit_batch(cq_ctx* c, const std::vector<const Fr*>& scalars, const std::vector<const G1Affine*>& bases, size_t len,
+                 std::vector<G1Affine>& out) {
+  std::vector<uint64_t> jac(scalars.size() * 12);
+  int rc = cq_msm_multi(c, scalars.data(), bases.data(), len, scalars.size(), jac.data());
+  if (rc != CQ_OK) return rc;
+  std::vector<G1Jac> j(scalars.size());
+  for (size_t i = 0; i < scalars.size(); i++) j[i] = jac_from_limbs(jac.data() + 12 * i);
+  batch_normalize(j, out);
+  return CQ_OK;
+}
+
+}  // namespace
+
+#define CQ_TRY(x)               \
+  do {                          \
+    int _rc = (x);              \
+    if (_rc != CQ_OK) return _rc; \
+  } while (0)
+
+namespace cq {
+
+size_t prover_arena_elems(const cq_pk* pk) {
+  const size_t n = (size_t)1 << pk->k, ext = pk->domain->ext();
+  const size_t L = pk->lookups.size(), A = pk->num_advice, N = pk->table_cfg->N;
+  size_t wsum = 0;
+  for (auto& lk : pk->lookups) wsum += lk.cols.size();
+  size_t e = 0;
+  e += A * n;          // advice (lagrange -> coeff in place)
+  e += 3 * L * n;      // f_lagrange, f_coeff, b
+  e += n;              // random poly
+  e += 2 * L * ext;    // cosets
+  e += ext;            // h on the extended coset
+  e += ext;            // h coefficients (n*(j-1) = 2n)
+  e += 2 * n;          // gwc batch poly + witness
+  e += 3 * N + L * N * 2 + wsum * N;  // t, den, (spare), a, m_fr, a_scaled
+  e += 2 * n;          // rng staging (64 B per element = 2 Fr)
+  e += L * N / 8 + 64; // m_counts (u32) + error word
+  return e + 1024;
+}
+
+int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, cq_rng_next_u64 rng_next, void* rng_state,
+                     std::vector<uint8_t>& proof_out) {
+  cq_ctx* c = pk->ctx;
+  cq_domain* dom = pk->domain;
+  const uint32_t k = pk->k;
+  const size_t n = (size_t)1 << k, ext = dom->ext();
+  const uint32_t bf = pk->bf, u = pk->u;
+  const size_t L = pk->lookups.size(), A = pk->num_advice;
+  const size_t N = pk->table_cfg->N;
+  hipStream_t s = c->stream;
+  Rng rng{rng_next, rng_state};
+  Transcript tr;
+
+  // ---- carve the arena --------------------------------------------------------------------------
+  void* arena_v;
+  CQ_TRY(c->ensure_scratch(6, prover_arena_elems(pk) * sizeof(Fr), &arena_v));
+  Fr* cur = (Fr*)arena_v;
+  auto take = [&](size_t elems) {
+    Fr* p = cur;
+    cur += elems;
+    return p;
+  };
+  Fr* adv = take(A * n);
+  Fr* f_lag = take(L * n);
+  Fr* f_coeff = take(L * n);
+  Fr* bpoly = take(L * n);
+  Fr* random_poly = take(n);
+  Fr* cosets = take(2 * L * ext);
+  Fr* h_ext = take(ext);
+  Fr* h_coeff = take(ext);
+  Fr* gwc_batch = take(n);
+  Fr* gwc_wit = take(n);
+  Fr* t_comp = take(N);
+  Fr* den = take(N);
+  take(N);
+  Fr* a_val = take(L * N);
+  Fr* m_fr = take(L * N);
+  size_t wsum = 0;
+  for (auto& lk : pk->lookups) wsum += lk.cols.size();
+  Fr* a_scaled = take(wsum * N);
+  uint64_t* rng_dev = (uint64_t*)take(2 * n);
+  uint32_t* m_counts = (uint32_t*)take(L * N / 8 + 64);
+  uint32_t* err_dev = m_counts + L * N;
+
+  // prover.rs:85 -- vk.hash_into(transcript)
+  tr.common_scalar(pk->vk_repr);
+
+  // ---- advice: copy in, blind rows u..n (prover.rs:346-350), one unused blind per column (:352-355) ----
+  for (size_t a = 0; a < A; a++)
+    CQ_HIP(c, hipMemcpyAsync(adv + a * n, advice_dev[a], (size_t)u * sizeof(Fr), hipMemcpyDeviceToDevice, s));
+  {
+    std::vector<Fr> tails(A * (n - u));
+    for (size_t a = 0; a < A; a++)
+      for (size_t r = 0; r < n - u; r++) tails[a * (n - u) + r] = rng.fr();
+    for (size_t a = 0; a < A; a++) (void)rng.fr();
+    void* pin;
+    CQ_TRY(c->ensure_pinned(std::max(tails.size() * sizeof(Fr), (size_t)64 * n), &pin));
+    memcpy(pin, tails.data(), tails.size() * sizeof(Fr));
+    for (size_t a = 0; a < A; a++)
+      CQ_HIP(c, hipMemcpyAsync(adv + a * n + u, (Fr*)pin + a * (n - u), (n - u) * sizeof(Fr), hipMemcpyHostToDevice, s));
+    CQ_HIP(c, hipStreamSynchronize(s));  // pinned buffer is reused below
+  }
+  // commit_lagrange per column (:356-360), batch_normalize (:363-366), write (:370-374)
+  std::vector<G1Affine> pts;
+  {
+    std::vector<const Fr*> sc(A);
+    std::vector<const G1Affine*> bs(A, pk->params->g_lagrange);
+    for (size_t a = 0; a < A; a++) sc[a] = adv + a * n;
+    if (A) CQ_TRY(commit_batch(c, sc, bs, n, pts));
+    for (auto& p : pts)
+      if (!tr.write_point(p)) return c->fail(CQ_ERR_TRANSCRIPT, "advice commitment is the identity");
+  }
+  const Fr theta = tr.squeeze();  // :472
+
+  // ---- CQ round 1 (static_lookup/prover.rs:51-183) ------------------------------------------------
+  CQ_HIP(c, hipMemsetAsync(m_counts, 0, (L * N + 16) * sizeof(uint32_t), s));
+  for (size_t l = 0; l < L; l++) {
+    const cq_lookup_desc& lk = pk->lookups[l];
+    const uint32_t w = (uint32_t)lk.cols.size();
+    // f = sum_j theta^(w-1-j) * e_j   (:108-116, Horner with the first expression first)
+    LincombArgs la;
+    la.count = w;
+    la.sub_const = Fr::zero();
+    Fr p = Fr::one();
+    for (int j = (int)w - 1; j >= 0; j--) {
+      la.p[j] = adv + (size_t)lk.cols[j] * n;
+      la.len[j] = (uint32_t)n;
+      la.coeff[j] = p;
+      p = p * theta;
+    }
+    CQ_TRY(poly_lincomb(c, la, (uint32_t)n, f_lag + l * n));
+    CqRound1Args ra;
+    ra.width = w;
+    for (uint32_t j = 0; j < w; j++) {
+      ra.cols[j] = adv + (size_t)lk.cols[j] * n;
+      ra.values[j] = lk.tables[j]->values;
+      ra.slots[j] = lk.tables[j]->slots;
+      ra.nslots[j] = lk.tables[j]->nslots;
+    }
+    CQ_TRY(cq_round1(c, ra, u, m_counts + l * N, err_dev));
+    CQ_TRY(cq_m_to_fr(c, m_counts + l * N, (uint32_t)N, m_fr + l * N));
+  }
+  {
+    uint32_t herr = 0;
+    CQ_HIP(c, hipMemcpyAsync(&herr, err_dev, 4, hipMemcpyDeviceToHost, s));
+    CQ_HIP(c, hipStreamSynchronize(s));
+    if (herr == 1) return c->fail(CQ_ERR_LOOKUP, "witness value not in table");
+    if (herr == 2) return c->fail(CQ_ERR_LOOKUP, "Vector lookup must be on the same table row");
+  }
+  if (L) {
+    std::vector<const Fr*> sc(L);
+    std::vector<const G1Affine*> bs(L, pk->params->g_lagrange);
+    std::vector<G1Affine> fcm, mcm;
+    for (size_t l = 0; l < L; l++) sc[l] = f_lag + l * n;
+    CQ_TRY(commit_batch(c, sc, bs, n, fcm));  // f_cm (:165)
+    std::vector<const G1Affine*> bt(L, pk->table_cfg->g1_lagrange);
+    for (size_t l = 0; l < L; l++) sc[l] = m_fr + l * N;
+    CQ_TRY(commit_batch(c, sc, bt, N, mcm));  // m_cm (:167-172) as a dense MSM over the table SRS
+    for (size_t l = 0; l < L; l++) {
+      if (!tr.write_point(fcm[l])) return c->fail(CQ_ERR_TRANSCRIPT, "f commitment is the identity");
+      if (!tr.write_point(mcm[l])) return c->fail(CQ_ERR_TRANSCRIPT, "m commitment is the identity");
+    }
+  }
+  const Fr beta = tr.squeeze();   // prover.rs:529
+  (void)tr.squeeze();             // gamma (:532), unused without permutations / legacy lookups
+  const Fr beta_inv = beta.inv();
+
+  // ---- CQ round 2 (static_lookup/prover.rs:187-342) -------------------------------------------------
+  std::vector<Fr> a_at_zero(L);
+  {
+    size_t woff = 0;
+    for (size_t l = 0; l < L; l++) {
+      const cq_lookup_desc& lk = pk->lookups[l];
+      const uint32_t w = (uint32_t)lk.cols.size();
+      // t_i = sum_j theta^(w-1-j) T_j[i]  (compress_tables :224-240)
+      LincombArgs la;
+      la.count = w;
+      la.sub_const = Fr::zero();
+      CqThetaPowers tp;
+      tp.width = w;
+      Fr p = Fr::one();
+      for (int j = (int)w - 1; j >= 0; j--) {
+        la.p[j] = lk.tables[j]->values;
+        la.len[j] = (uint32_t)N;
+        la.coeff[j] = p;
+        tp.pow[j] = p;
+        p = p * theta;
+      }
+      CQ_TRY(poly_lincomb(c, la, (uint32_t)N, t_comp));
+      CQ_TRY(cq_a_denominators(c, t_comp, m_counts + l * N, (uint32_t)N, beta, den));
+      CQ_TRY(poly_batch_invert(c, den, (uint32_t)N));
+      CQ_TRY(cq_a_values(c, den, m_counts + l * N, (uint32_t)N, tp, a_val + l * N, a_scaled + woff * N));
+      woff += w;
+      // B_r = 1/(f_r + beta), r < u ; 1/beta on the blinding rows (:261-269); iNTT -> b (:271-276)
+      CQ_TRY(poly_cq_b_denominators(c, f_lag + l * n, (uint32_t)n, u, beta, bpoly + l * n));
+      CQ_TRY(poly_batch_invert(c, bpoly + l * n, (uint32_t)n));
+    }
+    if (L) {
+      CQ_TRY(domain_lagrange_to_coeff(dom, bpoly, bpoly, (uint32_t)L, n, n));
+      CQ_TRY(domain_lagrange_to_coeff(dom, f_lag, f_coeff, (uint32_t)L, n, n));  // :326-334
+    }
+    // commitments: a, a0 (dense over the table SRS), q_a (over [qs_0|qs_1|...]), p, b0 (n-1 terms of b[1..])
+    std::vector<G1Affine> a_pts, qa_pts(L), pb_pts;
+    if (L) {
+      std::vector<const Fr*> sc;
+      std::vector<const G1Affine*> bs;
+      for (size_t l = 0; l < L; l++) {
+        sc.push_back(a_val + l * N);
+        bs.push_back(pk->table_cfg->g1_lagrange);
+        sc.push_back(a_val + l * N);
+        bs.push_back(pk->table_cfg->g_lagrange_opening_at_0);
+      }
+      CQ_TRY(commit_batch(c, sc, bs, N, a_pts));
+      woff = 0;
+      for (size_t l = 0; l < L; l++) {
+        const uint32_t w = (uint32_t)pk->lookups[l].cols.size();
+        std::vector<const Fr*> s1{a_scaled + woff * N};
+        std::vector<const G1Affine*> b1{pk->qs_concat[l]};
+        std::vector<G1Affine> o;
+        CQ_TRY(commit_batch(c, s1, b1, (size_t)w * N, o));
+        qa_pts[l] = o[0];
+        woff += w;
+      }
+      sc.clear();
+      bs.clear();
+      for (size_t l = 0; l < L; l++) {
+        sc.push_back(bpoly + l * n + 1);  // b0 = (b - b(0))/X : coefficients shifted down (:279)
+        bs.push_back(pk->b0_g1_bound);    // p_cm (:299)
+        sc.push_back(bpoly + l * n + 1);
+        bs.push_back(pk->params->g);       // b0_cm (:310); the padded top coefficient is zero
+      }
+      CQ_TRY(commit_batch(c, sc, bs, n - 1, pb_pts));
+    }
+    for (size_t l = 0; l < L; l++) {
+      // write order :306-313: a, q_a, a0, b0, p
+      if (!tr.write_point(a_pts[2 * l]) || !tr.write_point(qa_pts[l]) || !tr.write_point(a_pts[2 * l + 1]) ||
+          !tr.write_point(pb_pts[2 * l + 1]) || !tr.write_point(pb_pts[2 * l]))
+        return c->fail(CQ_ERR_TRANSCRIPT, "a CQ round-2 commitment is the identity");
+    }
+    // a(0) = (n*b(0) - (bf+1)/beta) / N   (:318-324)
+    if (L) {
+      std::vector<Fr> b0(L);
+      for (size_t l = 0; l < L; l++)
+        CQ_HIP(c, hipMemcpyAsync(&b0[l], bpoly + l * n, sizeof(Fr), hipMemcpyDeviceToHost, s));
+      CQ_HIP(c, hipStreamSynchronize(s));
+      const Fr n_table_inv = Fr::from_u64(N).inv();
+      for (size_t l = 0; l < L; l++)
+        a_at_zero[l] = (b0[l] * Fr::from_u64(n) - Fr::from_u64(bf + 1) * beta_inv) * n_table_inv;
+    }
+  }
+
+  // ---- vanishing::Argument::commit (vanishing/prover.rs:37-65) -------------------------------------
+  {
+    void* pin;
+    CQ_TRY(c->ensure_pinned((size_t)64 * n, &pin));
+    uint64_t* w = (uint64_t*)pin;
+    for (size_t i = 0; i < n; i++) rng.words(w + 8 * i);
+    (void)rng.fr();  // random_blind
+    CQ_HIP(c, hipMemcpyAsync(rng_dev, pin, (size_t)64 * n, hipMemcpyHostToDevice, s));
+    CQ_TRY(poly_from_u512(c, rng_dev, (uint32_t)n, random_poly));
+    std::vector<const Fr*> sc{random_poly};
+    std::vector<const G1Affine*> bs{pk->params->g};
+    std::vector<G1Affine> o;
+    CQ_TRY(commit_batch(c, sc, bs, n, o));
+    if (!tr.write_point(o[0])) return c->fail(CQ_ERR_TRANSCRIPT, "random poly commitment is the identity");
+  }
+  const Fr y = tr.squeeze();  // prover.rs:584
+
+  // advice polys: lagrange_to_coeff (:587-603), in place
+  if (A) CQ_TRY(domain_lagrange_to_coeff(dom, adv, adv, (uint32_t)A, n, n));
+
+  // ---- evaluate_h, CQ terms (evaluation.rs:533-548) + divide by the vanishing polynomial -----------
+  {
+    if (L) {
+      CQ_TRY(domain_coeff_to_extended(dom, bpoly, cosets, (uint32_t)L, n, ext));
+      CQ_TRY(domain_coeff_to_extended(dom, f_coeff, cosets + L * ext, (uint32_t)L, n, ext));
+    }
+    CqQuotientArgs qa;
+    qa.count = (uint32_t)L;
+    for (size_t l = 0; l < L; l++) {
+      qa.b[l] = cosets + l * ext;
+      qa.f[l] = cosets + (L + l) * ext;
+    }
+    qa.l_active = pk->l_active_row;
+    qa.t_evals = dom->t_evaluations_dev;
+    qa.t_len = (uint32_t)dom->t_evaluations.size();
+    qa.y = y;
+    qa.beta = beta;
+    CQ_TRY(poly_cq_quotient(c, qa, (uint32_t)ext, h_ext));
+  }
+  // vanishing.construct (vanishing/prover.rs:69-120): coefficients, n-sized pieces, blinds, commitments
+  const size_t pieces = dom->quotient_poly_degree;
+  CQ_TRY(domain_extended_to_coeff(dom, h_ext, h_coeff));
+  for (size_t i = 0; i < pieces; i++) (void)rng.fr();  // h_blinds (:95-98)
+  {
+    std::vector<const Fr*> sc(pieces);
+    std::vector<const G1Affine*> bs(pieces, pk->params->g);
+    for (size_t i = 0; i < pieces; i++) sc[i] = h_coeff + i * n;
+    std::vector<G1Affine> o;
+    CQ_TRY(commit_batch(c, sc, bs, n, o));
+    for (auto& p : o)
+      if (!tr.write_point(p)) return c->fail(CQ_ERR_TRANSCRIPT, "h piece commitment is the identity");
+  }
+  const Fr x = tr.squeeze();  // prover.rs:629
+  const Fr xn = x.pow_u64(n);
+
+  // ---- evaluations (prover.rs:654-719) ---------------------------------------------------------------
+  std::vector<Fr> advice_evals(pk->advice_queries.size());
+  for (size_t q = 0; q < pk->advice_queries.size(); q++) {
+    CQ_TRY(poly_eval(c, adv + (size_t)pk->advice_queries[q].first * n, (uint32_t)n, x, &advice_evals[q]));
+    tr.write_scalar(advice_evals[q]);
+  }
+  Fr random_eval;
+  CQ_TRY(poly_eval(c, random_poly, (uint32_t)n, x, &random_eval));  // vanishing/prover.rs:145-146
+  tr.write_scalar(random_eval);
+  std::vector<Fr> b0_evals(L), f_evals(L);
+  for (size_t l = 0; l < L; l++) {  // static_lookup/prover.rs:360-370
+    CQ_TRY(poly_eval(c, bpoly + l * n + 1, (uint32_t)(n - 1), x, &b0_evals[l]));
+    CQ_TRY(poly_eval(c, f_coeff + l * n, (uint32_t)n, x, &f_evals[l]));
+    tr.write_scalar(b0_evals[l]);
+    tr.write_scalar(f_evals[l]);
+    tr.write_scalar(a_at_zero[l]);
+  }
+
+  // ---- multiopen, GWC (gwc/prover.rs:42-91): every query is at x => one point group ---------------------
+  {
+    const Fr v = tr.squeeze();
+    // h(X) = sum_i xn^i h_i (vanishing/prover.rs:131-135); its evaluation is recomputed by get_eval
+    std::vector<Fr> h_evals(pieces);
+    for (size_t i = 0; i < pieces; i++) CQ_TRY(poly_eval(c, h_coeff + i * n, (uint32_t)n, x, &h_evals[i]));
+    Fr h_eval = Fr::zero();
+    for (size_t i = pieces; i-- > 0;) h_eval = h_eval * xn + h_evals[i];
+    LincombArgs la;
+    la.count = 0;
+    Fr pv = Fr::one();
+    Fr eval_batch = Fr::zero();
+    auto push = [&](const Fr* p, uint32_t len, const Fr& coeff) {
+      la.p[la.count] = p;
+      la.len[la.count] = len;
+      la.coeff[la.count] = coeff;
+      la.count++;
+    };
+    if (pk->advice_queries.size() + 2 * L + pieces + 1 > LINCOMB_MAX) return c->fail(CQ_ERR_ARG, "too many opening queries");
+    for (size_t q = 0; q < pk->advice_queries.size(); q++) {
+      push(adv + (size_t)pk->advice_queries[q].first * n, (uint32_t)n, pv);
+      eval_batch = eval_batch + advice_evals[q] * pv;
+      pv = pv * v;
+    }
+    for (size_t l = 0; l < L; l++) {
+      push(bpoly + l * n + 1, (uint32_t)(n - 1), pv);
+      eval_batch = eval_batch + b0_evals[l] * pv;
+      pv = pv * v;
+      push(f_coeff + l * n, (uint32_t)n, pv);
+      eval_batch = eval_batch + f_evals[l] * pv;
+      pv = pv * v;
+    }
+    {
+      Fr xp = Fr::one();
+      for (size_t i = 0; i < pieces; i++) {
+        push(h_coeff + i * n, (uint32_t)n, pv * xp);
+        xp = xp * xn;
+      }
+      eval_batch = eval_batch + h_eval * pv;
+      pv = pv * v;
+    }
+    push(random_poly, (uint32_t)n, pv);
+    eval_batch = eval_batch + random_eval * pv;
+    la.sub_const = eval_batch;
+    CQ_TRY(poly_lincomb(c, la, (uint32_t)n, gwc_batch));
+    CQ_TRY(poly_kate_division(c, gwc_batch, (uint32_t)n, x, gwc_wit));
+    std::vector<const Fr*> sc{gwc_wit};
+    std::vector<const G1Affine*> bs{pk->params->g};
+    std::vector<G1Affine> o;
+    CQ_TRY(commit_batch(c, sc, bs, n - 1, o));
+    if (!tr.write_point(o[0])) return c->fail(CQ_ERR_TRANSCRIPT, "opening witness commitment is the identity");
+  }
+  proof_out.swap(tr.proof);
+  return CQ_OK;
+}
+
+}  // namespace cq

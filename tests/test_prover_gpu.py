@@ -1,0 +1,114 @@
+"""GPU parity: full `create_proof` (CQ-only circuits) -- proof BYTES must equal the oracle's for the
+same proving key, witness and RNG stream; every proof must also pass the acceptance verifier."""
+import numpy as np
+import pytest
+
+from oracle import bn254 as B
+from oracle import cq_prover as CP
+from oracle import cq_verifier as CV
+from oracle import kzg
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(ctx, k, table_values, lookups_desc, num_advice, seed, srs_len=None):
+    """Builds oracle + GPU proving keys over the same toxic waste.
+    lookups_desc: list of lookups, each a list of (advice col, table name)."""
+    from sha2_on_cq_halo2_amd import ParamsKZG, ProvingKey, StaticTable, TableConfig
+
+    n = 1 << k
+    s = B.fr_random(B.Xoshiro256ss(seed))
+    sm = B.to_mont_limbs([s])[0]
+    N = len(next(iter(table_values.values())))
+    L = srs_len or N
+    assert L >= N and L - 1 - (n - 2) >= 0
+    tsrs = kzg.TableSRS(N - 1, s)
+    # b0 bound: n-1 consecutive powers [s^(L-1-(n-2)) .. s^(L-1)]_1 (my_test.rs:205)
+    g1_long = kzg._powers_g1(s, L)
+    b0 = g1_long[L - 1 - (n - 2):]
+    otables = {name: kzg.StaticTableValues(v, None, qs=kzg.StaticTableValues.qs_closed_form(v, s)) for name, v in table_values.items()}
+    oparams = kzg.ParamsKZG(k, s)
+    circ = CP.CqCircuit(k, num_advice, lookups_desc)
+    vk_repr = 0x1234567 + k
+    opk = CP.keygen_pk(circ, otables, tsrs, b0, vk_repr)
+
+    gparams = ParamsKZG.setup_from_toxic_waste(ctx, k, sm)
+    gcfg = TableConfig.setup_from_toxic_waste(ctx, N, sm)
+    gtables = {name: StaticTable.setup_from_toxic_waste(ctx, B.to_mont_limbs(v), sm) for name, v in table_values.items()}
+    gpk = ProvingKey(ctx, gparams, k, num_advice, [[(c, gtables[t]) for c, t in lk] for lk in lookups_desc], gcfg,
+                     B.points_to_mont_limbs(b0), B.to_mont_limbs([vk_repr])[0])
+    return dict(s=s, circ=circ, oparams=oparams, opk=opk, gpk=gpk, gcfg=gcfg, gtables=gtables, tsrs=tsrs, otables=otables,
+                vk_repr=vk_repr, N=N, L=L)
+
+
+def _prove_both(env, advice_usable, rng_seed):
+    k = env["circ"].k
+    n = 1 << k
+    tr = CP.create_proof(env["oparams"], env["opk"], advice_usable, B.Xoshiro256ss(rng_seed))
+    words = B.Xoshiro256ss(rng_seed).words(8 * (len(advice_usable) * 8 + n + 16))
+    cols = []
+    for col in advice_usable:
+        full = list(col) + [0] * (n - len(col))
+        cols.append(B.to_mont_limbs(full))
+    proof = env["gpk"].create_proof(cols, rng_words=words)
+    return tr, proof
+
+
+def test_table_setup_matches_oracle(ctx):
+    env = _setup(ctx, 3, {"t": [0, 1, 6, 8, 10, 12, 14, 16, 18, 20, 22, 24, 26, 28, 30, 32]}, [[(0, "t")]], 1, 5)
+    g1l, op0 = env["gcfg"].download()
+    assert np.array_equal(g1l, B.points_to_mont_limbs(env["tsrs"].g1_lagrange))
+    assert np.array_equal(op0, B.points_to_mont_limbs(env["tsrs"].g_lagrange_opening_at_0))
+    assert np.array_equal(env["gtables"]["t"].download_qs(), B.points_to_mont_limbs(env["otables"]["t"].qs))
+
+
+def test_my_test_shape_proof_bytes(ctx):
+    """The reference's only CQ end-to-end test (halo2_proofs/tests/my_test.rs:179-259): K=3, two
+    16-entry tables, vector lookup of (advice0, advice1), witness rows (30,15), (6,3)."""
+    tv = {"table": [0, 1, 6, 8, 10, 12, 14, 16, 18, 20, 22, 24, 26, 28, 30, 32],
+          "table_2": [0, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16]}
+    env = _setup(ctx, 3, tv, [[(0, "table"), (1, "table_2")]], 2, 0x6371)
+    tr, proof = _prove_both(env, [[30, 6], [15, 3]], 7)
+    assert len(proof) == 608  # 13 points + 6 scalars
+    assert proof == tr.proof
+    assert CV.verify_proof(proof, env["circ"], env["vk_repr"], env["s"], tv, 16, 16)
+
+
+@pytest.mark.parametrize("k,nbits,pairs", [(5, 5, 1), (6, 6, 2), (7, 6, 4)])
+def test_sha_shaped_proof_bytes(ctx, k, nbits, pairs):
+    """SHA-shaped CQ circuit at small k: `pairs` (dense, spread) column pairs, one width-2 vector
+    lookup per pair against (dense, spread) tables of 2^nbits entries."""
+    N = 1 << nbits
+    n = 1 << k
+
+    def spread(x):
+        r = 0
+        for i in range(16):
+            r |= ((x >> i) & 1) << (2 * i)
+        return r
+
+    tv = {"dense": list(range(N)), "spread": [spread(i) for i in range(N)]}
+    lookups = [[(2 * p, "dense"), (2 * p + 1, "spread")] for p in range(pairs)]
+    env = _setup(ctx, k, tv, lookups, 2 * pairs, 100 + k, srs_len=max(N, n))
+    u = n - 6
+    rng = B.Xoshiro256ss(k)
+    advice = []
+    for p in range(pairs):
+        vals = [rng.next_u64() % N for _ in range(u - 3)]  # leaves unassigned (zero) cells at the end
+        advice.append(vals)
+        advice.append([spread(v) for v in vals])
+    tr, proof = _prove_both(env, advice, 1000 + k)
+    assert proof == tr.proof
+    assert CV.verify_proof(proof, env["circ"], env["vk_repr"], env["s"], tv, N, env["L"])
+
+
+def test_lookup_failure_is_an_error(ctx):
+    from sha2_on_cq_halo2_amd import CqError
+
+    tv = {"t": list(range(16))}
+    env = _setup(ctx, 4, tv, [[(0, "t")]], 1, 9, srs_len=16)
+    n = 16
+    cols = [B.to_mont_limbs([3, 5, 99] + [0] * (n - 3))]  # 99 is not in the table
+    with pytest.raises(CqError) as e:
+        env["gpk"].create_proof(cols, seed=1)
+    assert e.value.code == -4
