@@ -117,3 +117,51 @@ def ifft(a, omega_inv, log_n, divisor) -> np.ndarray:
     om, dm = _a(omega_inv).reshape(4), _a(divisor).reshape(4)
     lib().cqo_ifft(a.ctypes.data, om.ctypes.data, log_n, dm.ctypes.data)
     return a
+
+
+def keygen_l_active(k: int, blinding_factors: int) -> np.ndarray:
+    """keygen.rs:344-373: l_active_row on the extended coset (degree-3 circuit => 2n values)."""
+    L = lib()
+    L.cqo_keygen_l_active.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p]
+    out = np.zeros((2 << k, 4), dtype=np.uint64)
+    L.cqo_keygen_l_active(k, blinding_factors, out.ctypes.data)
+    return out
+
+
+def xoshiro_state(seed: int) -> np.ndarray:
+    """splitmix64-seeded xoshiro256** state (same as oracle.bn254.Xoshiro256ss)."""
+    from .bn254 import Xoshiro256ss
+
+    return np.array(Xoshiro256ss(seed).s, dtype=np.uint64)
+
+
+def create_proof(k, num_advice, lookups, table_values, table_qs, g, g_lagrange, t_g1_lagrange, t_open0, b0_bound,
+                 l_active, vk_repr, advice, seed) -> bytes:
+    """C restatement of create_proof (CQ-only).  lookups: list of lists of (advice col, table index);
+    table_values / table_qs: lists of uint64[N,4] / uint64[N,8]; advice: list of uint64[n,4]."""
+    L = lib()
+    vp = C.c_void_p
+    L.cqo_create_proof.restype = C.c_int
+    L.cqo_create_proof.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp, C.c_uint32, C.c_size_t] + [vp] * 11 + [
+        vp, C.POINTER(C.c_size_t)]
+    widths = np.array([len(lk) for lk in lookups] or [0], dtype=np.uint32)
+    cols = np.array([c for lk in lookups for c, _ in lk] or [0], dtype=np.uint32)
+    tids = np.array([t for lk in lookups for _, t in lk] or [0], dtype=np.uint32)
+    N = table_values[0].shape[0]
+    tv = _a(np.concatenate([_a(t).reshape(N, 4) for t in table_values]))
+    tq = _a(np.concatenate([_a(t).reshape(N, 8) for t in table_qs]))
+    adv = _a(np.concatenate([_a(a).reshape(1 << k, 4) for a in advice])) if num_advice else np.zeros((1, 4), dtype=np.uint64)
+    g, g_lagrange, t_g1_lagrange, t_open0, b0_bound, l_active = map(_a, (g, g_lagrange, t_g1_lagrange, t_open0, b0_bound, l_active))
+    vk = _a(vk_repr).reshape(4)
+    st = xoshiro_state(seed)
+    points = num_advice + 7 * len(lookups) + 1 + 2 + 1
+    scalars = len({c for lk in lookups for c, _ in lk}) + 1 + 3 * len(lookups)
+    proof = np.zeros(32 * (points + scalars) + 64, dtype=np.uint8)
+    plen = C.c_size_t()
+    rc = L.cqo_create_proof(k, num_advice, len(lookups), widths.ctypes.data, cols.ctypes.data, tids.ctypes.data,
+                            len(table_values), N, tv.ctypes.data, tq.ctypes.data, g.ctypes.data, g_lagrange.ctypes.data,
+                            t_g1_lagrange.ctypes.data, t_open0.ctypes.data, b0_bound.ctypes.data, l_active.ctypes.data,
+                            vk.ctypes.data, adv.ctypes.data, st.ctypes.data, proof.ctypes.data, C.byref(plen))
+    if rc != 0:
+        raise RuntimeError(f"cqo_create_proof failed: {rc}")
+    return bytes(proof[: plen.value])
