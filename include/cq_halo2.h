@@ -88,6 +88,11 @@ int cq_best_multiexp_dev(cq_ctx* ctx, const uint64_t* coeffs_dev, const uint64_t
  * synchronisation for the whole batch; out_jac = count x 12 limbs on the host. */
 int cq_msm_batch_dev(cq_ctx* ctx, const uint64_t* const* coeffs_dev, const uint64_t* bases_dev, size_t len,
                      size_t count, uint64_t* out_jac);
+/* Host helpers for multi-GPU MSM sharding: sum of `count` Jacobian points (the per-rank partial
+ * results after an all-gather; EC addition is not an RCCL reduction op), and Curve::to_affine
+ * (derive/curve.rs:399-412). */
+int cq_g1_sum(const uint64_t* jac_points, size_t count, uint64_t out_jac[12]);
+int cq_g1_to_affine(const uint64_t jac[12], uint64_t out_affine[8]);
 /* Pippenger window width in bits (2..15), 0 = automatic.  Tuning knob; results do not depend on it. */
 int cq_msm_set_window(cq_ctx* ctx, uint32_t bits);
 

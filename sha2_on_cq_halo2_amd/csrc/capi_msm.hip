@@ -195,3 +195,30 @@ int cq_commit_lagrange_dev(cq_params* p, const uint64_t* poly_dev, size_t len, u
 }
 
 }  // extern "C"
+
+extern "C" {
+/* sum of `count` Jacobian points (host memory): the local EC sum after an all-gather of per-rank MSM
+ * partials (EC addition is not an RCCL reduction op). */
+int cq_g1_sum(const uint64_t* jac_points, size_t count, uint64_t out_jac[12]) {
+  if ((!jac_points && count) || !out_jac) return CQ_ERR_ARG;
+  G1Jac acc = G1Jac::identity();
+  for (size_t i = 0; i < count; i++) {
+    const uint64_t* p = jac_points + 12 * i;
+    G1Jac q = {Fq::from_limbs64(p), Fq::from_limbs64(p + 4), Fq::from_limbs64(p + 8)};
+    acc = jac_add(acc, q);
+  }
+  acc.x.to_limbs64(out_jac);
+  acc.y.to_limbs64(out_jac + 4);
+  acc.z.to_limbs64(out_jac + 8);
+  return CQ_OK;
+}
+/* `to_affine` (derive/curve.rs:399-412) on the host */
+int cq_g1_to_affine(const uint64_t jac[12], uint64_t out_affine[8]) {
+  if (!jac || !out_affine) return CQ_ERR_ARG;
+  G1Jac q = {Fq::from_limbs64(jac), Fq::from_limbs64(jac + 4), Fq::from_limbs64(jac + 8)};
+  G1Affine a = jac_to_affine(q);
+  a.x.to_limbs64(out_affine);
+  a.y.to_limbs64(out_affine + 4);
+  return CQ_OK;
+}
+}

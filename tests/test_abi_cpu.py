@@ -1,0 +1,61 @@
+"""CPU: the C-ABI library loads and exports every symbol include/cq_halo2.h declares (no compute
+calls without a GPU), and contexts fail loudly without a device."""
+import ctypes as C
+
+from sha2_on_cq_halo2_amd import header_symbols, load
+
+
+def test_every_declared_symbol_is_exported():
+    lib = load()
+    syms = header_symbols()
+    assert len(syms) > 50
+    missing = [s for s in syms if not hasattr(lib, s)]
+    assert missing == []
+
+
+def test_version_and_host_only_entry_points():
+    lib = load()
+    assert b"gfx950" in lib.cq_version()
+    # host-only helpers work without a GPU
+    st = (C.c_uint64 * 4)()
+    lib.cq_xoshiro256ss_seed(7, st)
+    from oracle.bn254 import Xoshiro256ss
+
+    ref = Xoshiro256ss(7)
+    assert list(st) == ref.s
+    assert [lib.cq_xoshiro256ss_next_u64(st) for _ in range(5)] == [ref.next_u64() for _ in range(5)]
+
+
+def test_g1_sum_host_helper_matches_oracle():
+    import numpy as np
+
+    from oracle import bn254 as B
+    from tests.util import random_points
+
+    lib = load()
+    pts = random_points(5, 3)
+    jac = np.zeros((5, 12), dtype=np.uint64)
+    jac[:, :8] = B.points_to_mont_limbs(pts)
+    jac[:, 8:] = B.to_mont_limbs([1], B.Q_MOD)[0]
+    out = np.zeros(12, dtype=np.uint64)
+    assert lib.cq_g1_sum(jac.ctypes.data, 5, out.ctypes.data) == 0
+    acc = None
+    for p in pts:
+        acc = B.g1_add(acc, p)
+    aff = np.zeros(8, dtype=np.uint64)
+    assert lib.cq_g1_to_affine(out.ctypes.data, aff.ctypes.data) == 0
+    assert B.points_from_mont_limbs(aff.reshape(1, 8))[0] == acc
+
+
+def test_no_gpu_is_an_error_not_a_fallback():
+    import torch
+
+    if torch.cuda.is_available():
+        return
+    from sha2_on_cq_halo2_amd import Context, CqError
+
+    try:
+        Context(0)
+        assert False, "Context() must fail without a GPU"
+    except CqError as e:
+        assert e.code == -3
