@@ -72,22 +72,35 @@ static __device__ __forceinline__ uint32_t table_find(const Fr* __restrict__ val
 __global__ __launch_bounds__(256) void cq_round1_kernel(CqRound1Args a, uint32_t u, uint32_t* __restrict__ m_counts,
                                                         uint32_t* __restrict__ err) {
   const uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;
-  if (row >= u) return;
+  const bool live = row < u;
   uint32_t idx = EMPTY;
-  for (uint32_t j = 0; j < a.width; j++) {
+  bool bad = false;
+  for (uint32_t j = 0; live && !bad && j < a.width; j++) {
     const Fr v = ld(a.cols[j] + row);
     const uint32_t ix = table_find(a.values[j], a.slots[j], a.nslots[j], v);
     if (ix == EMPTY) {
       atomicExch(err, 1u);  // "{:?} not in table" (:141)
-      return;
-    }
-    if (j && ix != idx) {
+      bad = true;
+    } else if (j && ix != idx) {
       atomicExch(err, 2u);  // "Vector lookup must be on the same table row" (:148)
-      return;
+      bad = true;
     }
     idx = ix;
   }
-  atomicAdd(&m_counts[idx], 1u);
+  // multiplicities: padded rows all hit the same entry, so aggregate equal indices within the wave
+  // before touching L2 (same-address atomics serialise)
+  bool pending = live && !bad;
+#pragma unroll 1
+  for (int round = 0; round < 4 && __ballot(pending); round++) {
+    const unsigned long long pend = __ballot(pending);
+    const int leader = __ffsll((long long)pend) - 1;
+    const uint32_t lidx = __shfl(idx, leader, 64);
+    const bool mine = pending && idx == lidx;
+    const unsigned long long grp = __ballot(mine);
+    if ((int)(threadIdx.x & 63) == leader) atomicAdd(&m_counts[lidx], (uint32_t)__popcll(grp));
+    if (mine) pending = false;
+  }
+  if (pending) atomicAdd(&m_counts[idx], 1u);
 }
 
 // ---- round 2 (static_lookup/prover.rs:245-257), dense over the table -----------------------------------

@@ -3,6 +3,7 @@
 // recurrence of the reference (cited per function).  All are HBM-bandwidth bound: one 16-byte-per-lane
 // coalesced read and write per element, arithmetic fused so every vector is touched once.
 #include "poly.hpp"
+#include <algorithm>
 #include "ctx.hpp"
 
 namespace cq {
@@ -22,8 +23,44 @@ static __device__ __forceinline__ void st(Fr* p, const Fr& r) {
 }
 
 // ---- eval_polynomial (arithmetic.rs:304-329) ------------------------------------------------------
-// One Horner run per chunk of L coefficients: S[c] = sum_{i<L} a[cL+i] z^i.  p(z) = S(z^L), so the
-// host applies the kernel again on S with z^L until one value is left (3 levels at n = 2^18).
+// Block-level Horner: a block folds EVAL_TILE = 2048 coefficients of one polynomial: each lane runs
+// Horner over 8 consecutive coefficients, then an 8-level LDS tree combines lane values with the
+// multipliers x^8, x^16, ... (v_t += y_s * v_{t+2^s}).  p(x) = S(x^2048) over the block sums S, so the
+// host applies the kernel again until one value per polynomial is left (2 levels at n = 2^18).
+// blockIdx.y selects the polynomial: all evaluations of a proof at one point go in one launch.
+__global__ __launch_bounds__(256) void block_eval_kernel(EvalBatchArgs args, uint32_t level_stride_in,
+                                                         const Fr* __restrict__ level_in, Fr* __restrict__ level_out,
+                                                         uint32_t out_stride, EvalPowers pw) {
+  __shared__ uint4 sh_lo[256], sh_hi[256];
+  const uint32_t poly = blockIdx.y;
+  const Fr* a = level_in ? level_in + (size_t)poly * level_stride_in : args.p[poly];
+  const uint32_t n = level_in ? args.cur_len[poly] : args.len[poly];
+  const uint32_t t = threadIdx.x;
+  const uint32_t base = blockIdx.x * EVAL_TILE + t * 8;
+  Fr v = Fr::zero();
+  if (base < n) {
+    const uint32_t hi = min(n, base + 8);
+    for (uint32_t i = hi; i-- > base;) v = v * pw.x + ld(a + i);
+  }
+#pragma unroll 1
+  for (uint32_t s = 0; s < 8; s++) {
+    sh_lo[t] = make_uint4(v.v.l[0], v.v.l[1], v.v.l[2], v.v.l[3]);
+    sh_hi[t] = make_uint4(v.v.l[4], v.v.l[5], v.v.l[6], v.v.l[7]);
+    __syncthreads();
+    const uint32_t d = 1u << s;
+    if ((t & ((d << 1) - 1)) == 0) {
+      Fr o;
+      uint4 lo = sh_lo[t + d], hi4 = sh_hi[t + d];
+      o.v.l[0] = lo.x; o.v.l[1] = lo.y; o.v.l[2] = lo.z; o.v.l[3] = lo.w;
+      o.v.l[4] = hi4.x; o.v.l[5] = hi4.y; o.v.l[6] = hi4.z; o.v.l[7] = hi4.w;
+      if (!o.is_zero()) v = v + pw.y[s] * o;
+    }
+    __syncthreads();
+  }
+  if (t == 0) st(level_out + (size_t)poly * out_stride + blockIdx.x, v);
+}
+
+// One Horner run per chunk of L coefficients (used by the division below).
 __global__ __launch_bounds__(256) void chunk_eval_kernel(const Fr* __restrict__ a, uint32_t n, Fr z, uint32_t L,
                                                          Fr* __restrict__ S) {
   const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -137,34 +174,64 @@ __global__ void fill_usable_rows_kernel(Fr* out, uint32_t n, uint32_t u) {
 // =================================================================================================
 static inline uint32_t blocks_for(uint32_t n) { return (n + 255) / 256; }
 
+// evaluates `count` polynomials (device pointers p[i], lengths len[i]) at z; results to the host
+int poly_eval_batch(cq_ctx* c, const Fr* const* p, const uint32_t* len, uint32_t count, const Fr& z, Fr* out_host) {
+  if (count == 0) return CQ_OK;
+  if (count > EVAL_MAX_BATCH) return c->fail(CQ_ERR_ARG, "eval: batch too large");
+  EvalBatchArgs args;
+  uint32_t maxlen = 0;
+  for (uint32_t i = 0; i < count; i++) {
+    args.p[i] = p[i];
+    args.len[i] = len[i];
+    args.cur_len[i] = len[i];
+    maxlen = std::max(maxlen, len[i]);
+  }
+  if (maxlen == 0) {
+    for (uint32_t i = 0; i < count; i++) out_host[i] = Fr::zero();
+    return CQ_OK;
+  }
+  const uint32_t nb0 = (maxlen + EVAL_TILE - 1) / EVAL_TILE;
+  void* scr;
+  int rc;
+  if ((rc = c->ensure_scratch(5, ((size_t)count * (nb0 + 8) * 2) * sizeof(Fr), &scr)) != CQ_OK) return rc;
+  Fr* buf[2] = {(Fr*)scr, (Fr*)scr + (size_t)count * (nb0 + 8)};
+  const uint32_t stride = nb0 + 8;
+  Fr x = z;
+  const Fr* level_in = nullptr;
+  int which = 0;
+  uint32_t curmax = maxlen;
+  while (true) {
+    EvalPowers pw;
+    pw.x = x;
+    Fr y = x.pow_u64(8);
+    for (int s2 = 0; s2 < 8; s2++) {
+      pw.y[s2] = y;
+      y = y.sqr();
+    }
+    const uint32_t nb = (curmax + EVAL_TILE - 1) / EVAL_TILE;
+    block_eval_kernel<<<dim3(nb, count), 256, 0, c->stream>>>(args, stride, level_in, buf[which], stride, pw);
+    for (uint32_t i = 0; i < count; i++) args.cur_len[i] = (args.cur_len[i] + EVAL_TILE - 1) / EVAL_TILE;
+    level_in = buf[which];
+    curmax = nb;
+    if (nb == 1) break;
+    which ^= 1;
+    x = y;  // x^(8 * 2^8) = x^2048
+  }
+  // results sit at level_in[poly * stride]; gather with one strided copy
+  if (hipMemcpy2DAsync(out_host, sizeof(Fr), level_in, (size_t)stride * sizeof(Fr), sizeof(Fr), count, hipMemcpyDeviceToHost,
+                       c->stream) != hipSuccess)
+    return c->fail(CQ_ERR_HIP, "eval: D2H failed");
+  if (hipStreamSynchronize(c->stream) != hipSuccess) return c->fail(CQ_ERR_HIP, "eval: sync failed");
+  // empty polynomials evaluate to zero (their blocks wrote zero already)
+  return CQ_OK;
+}
+
 int poly_eval(cq_ctx* c, const Fr* a, uint32_t n, const Fr& z, Fr* out_host) {
   if (n == 0) {
     *out_host = Fr::zero();
     return CQ_OK;
   }
-  void* scr;
-  int rc;
-  const uint32_t L = POLY_CHUNK;
-  const uint32_t n1 = (n + L - 1) / L;
-  if ((rc = c->ensure_scratch(5, ((size_t)n1 + L + 64) * sizeof(Fr) * 2, &scr)) != CQ_OK) return rc;
-  Fr* buf[2] = {(Fr*)scr, (Fr*)scr + n1 + 32};
-  const Fr* src = a;
-  uint32_t len = n;
-  Fr zz = z;
-  int which = 0;
-  while (true) {
-    const uint32_t nch = (len + L - 1) / L;
-    chunk_eval_kernel<<<blocks_for(nch), 256, 0, c->stream>>>(src, len, zz, L, buf[which]);
-    src = buf[which];
-    len = nch;
-    if (len == 1) break;
-    which ^= 1;
-    zz = zz.pow_u64(L);
-  }
-  if (hipMemcpyAsync(out_host, src, sizeof(Fr), hipMemcpyDeviceToHost, c->stream) != hipSuccess)
-    return c->fail(CQ_ERR_HIP, "eval: D2H failed");
-  if (hipStreamSynchronize(c->stream) != hipSuccess) return c->fail(CQ_ERR_HIP, "eval: sync failed");
-  return CQ_OK;
+  return poly_eval_batch(c, &a, &n, 1, z, out_host);
 }
 
 // q = (a(X) - a(z)) / (X - z), n-1 coefficients.  Recursion depth log_L(n).

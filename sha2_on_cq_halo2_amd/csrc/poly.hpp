@@ -21,6 +21,18 @@ struct LincombArgs {
   Fr sub_const;  // subtracted from coefficient 0
 };
 
+constexpr uint32_t EVAL_TILE = 2048;      // coefficients folded by one block of block_eval_kernel
+constexpr uint32_t EVAL_MAX_BATCH = 40;   // polynomials per batched evaluation
+struct EvalBatchArgs {
+  const Fr* p[EVAL_MAX_BATCH];
+  uint32_t len[EVAL_MAX_BATCH];
+  uint32_t cur_len[EVAL_MAX_BATCH];
+};
+struct EvalPowers {
+  Fr x;
+  Fr y[8];  // x^8, x^16, ..., x^1024
+};
+
 struct CqQuotientArgs {
   const Fr* b[CQ_MAX_LOOKUPS];
   const Fr* f[CQ_MAX_LOOKUPS];
@@ -32,6 +44,7 @@ struct CqQuotientArgs {
 };
 
 int poly_eval(cq_ctx* c, const Fr* a_dev, uint32_t n, const Fr& z, Fr* out_host);
+int poly_eval_batch(cq_ctx* c, const Fr* const* p_dev, const uint32_t* len, uint32_t count, const Fr& z, Fr* out_host);
 int poly_kate_division(cq_ctx* c, const Fr* a_dev, uint32_t n, const Fr& z, Fr* q_dev);
 int poly_batch_invert(cq_ctx* c, Fr* a_dev, uint32_t n);
 int poly_lincomb(cq_ctx* c, const LincombArgs& args, uint32_t n, Fr* out_dev);

@@ -12,6 +12,7 @@
 // Gates, fixed/instance columns, permutations and legacy lookups are "next" rows.
 // One deliberate omission: evaluation.rs:317-325 also transforms every advice polynomial to the
 // extended coset although no CQ-only term reads them; that dead work is not reproduced.
+#include <algorithm>
 #include <cstring>
 #include <vector>
 #include "blake2b.hpp"
@@ -145,7 +146,7 @@ size_t prover_arena_elems(const cq_pk* pk) {
   e += ext;            // h on the extended coset
   e += ext;            // h coefficients (n*(j-1) = 2n)
   e += 2 * n;          // gwc batch poly + witness
-  e += 3 * N + L * N * 2 + wsum * N;  // t, den, (spare), a, m_fr, a_scaled
+  e += N + (L * N + 8) + L * N * 2 + wsum * N;  // t, den, a, m_fr, a_scaled
   e += 2 * n;          // rng staging (64 B per element = 2 Fr)
   e += L * N / 8 + 64; // m_counts (u32) + error word
   return e + 1024;
@@ -184,8 +185,7 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, cq_rng_next_u
   Fr* gwc_batch = take(n);
   Fr* gwc_wit = take(n);
   Fr* t_comp = take(N);
-  Fr* den = take(N);
-  take(N);
+  Fr* den = take(L * N + 8);
   Fr* a_val = take(L * N);
   Fr* m_fr = take(L * N);
   size_t wsum = 0;
@@ -300,13 +300,27 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, cq_rng_next_u
         p = p * theta;
       }
       CQ_TRY(poly_lincomb(c, la, (uint32_t)N, t_comp));
-      CQ_TRY(cq_a_denominators(c, t_comp, m_counts + l * N, (uint32_t)N, beta, den));
-      CQ_TRY(poly_batch_invert(c, den, (uint32_t)N));
-      CQ_TRY(cq_a_values(c, den, m_counts + l * N, (uint32_t)N, tp, a_val + l * N, a_scaled + woff * N));
-      woff += w;
-      // B_r = 1/(f_r + beta), r < u ; 1/beta on the blinding rows (:261-269); iNTT -> b (:271-276)
+      CQ_TRY(cq_a_denominators(c, t_comp, m_counts + l * N, (uint32_t)N, beta, den + l * N));
+      // B_r = f_r + beta, r < u ; beta on the blinding rows (:261-269)
       CQ_TRY(poly_cq_b_denominators(c, f_lag + l * n, (uint32_t)n, u, beta, bpoly + l * n));
-      CQ_TRY(poly_batch_invert(c, bpoly + l * n, (uint32_t)n));
+    }
+    if (L) {
+      // all inversions of the round in two launches (one Fermat inversion per lane dominates the latency)
+      CQ_TRY(poly_batch_invert(c, den, (uint32_t)(L * N)));
+      CQ_TRY(poly_batch_invert(c, bpoly, (uint32_t)(L * n)));
+    }
+    woff = 0;
+    for (size_t l = 0; l < L; l++) {
+      const uint32_t w = (uint32_t)pk->lookups[l].cols.size();
+      CqThetaPowers tp;
+      tp.width = w;
+      Fr p = Fr::one();
+      for (int j = (int)w - 1; j >= 0; j--) {
+        tp.pow[j] = p;
+        p = p * theta;
+      }
+      CQ_TRY(cq_a_values(c, den + l * N, m_counts + l * N, (uint32_t)N, tp, a_val + l * N, a_scaled + woff * N));
+      woff += w;
     }
     if (L) {
       CQ_TRY(domain_lagrange_to_coeff(dom, bpoly, bpoly, (uint32_t)L, n, n));
@@ -417,19 +431,34 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, cq_rng_next_u
   const Fr x = tr.squeeze();  // prover.rs:629
   const Fr xn = x.pow_u64(n);
 
-  // ---- evaluations (prover.rs:654-719) ---------------------------------------------------------------
-  std::vector<Fr> advice_evals(pk->advice_queries.size());
-  for (size_t q = 0; q < pk->advice_queries.size(); q++) {
-    CQ_TRY(poly_eval(c, adv + (size_t)pk->advice_queries[q].first * n, (uint32_t)n, x, &advice_evals[q]));
-    tr.write_scalar(advice_evals[q]);
-  }
+  // ---- evaluations (prover.rs:654-719): every polynomial is opened at x, one batched launch ---------
+  const size_t pieces_n = pieces;
+  std::vector<Fr> advice_evals(pk->advice_queries.size()), b0_evals(L), f_evals(L), h_evals(pieces_n);
   Fr random_eval;
-  CQ_TRY(poly_eval(c, random_poly, (uint32_t)n, x, &random_eval));  // vanishing/prover.rs:145-146
-  tr.write_scalar(random_eval);
-  std::vector<Fr> b0_evals(L), f_evals(L);
+  {
+    std::vector<const Fr*> ps;
+    std::vector<uint32_t> ls;
+    for (auto& q : pk->advice_queries) { ps.push_back(adv + (size_t)q.first * n); ls.push_back((uint32_t)n); }
+    ps.push_back(random_poly); ls.push_back((uint32_t)n);
+    for (size_t l = 0; l < L; l++) {
+      ps.push_back(bpoly + l * n + 1); ls.push_back((uint32_t)(n - 1));  // b0 = (b - b(0))/X
+      ps.push_back(f_coeff + l * n); ls.push_back((uint32_t)n);
+    }
+    for (size_t i = 0; i < pieces_n; i++) { ps.push_back(h_coeff + i * n); ls.push_back((uint32_t)n); }
+    std::vector<Fr> ev(ps.size());
+    for (size_t off = 0; off < ps.size(); off += EVAL_MAX_BATCH) {
+      const uint32_t cnt = (uint32_t)std::min((size_t)EVAL_MAX_BATCH, ps.size() - off);
+      CQ_TRY(poly_eval_batch(c, ps.data() + off, ls.data() + off, cnt, x, ev.data() + off));
+    }
+    size_t e = 0;
+    for (size_t q = 0; q < advice_evals.size(); q++) advice_evals[q] = ev[e++];
+    random_eval = ev[e++];
+    for (size_t l = 0; l < L; l++) { b0_evals[l] = ev[e++]; f_evals[l] = ev[e++]; }
+    for (size_t i = 0; i < pieces_n; i++) h_evals[i] = ev[e++];
+  }
+  for (auto& v : advice_evals) tr.write_scalar(v);
+  tr.write_scalar(random_eval);  // vanishing/prover.rs:145-146
   for (size_t l = 0; l < L; l++) {  // static_lookup/prover.rs:360-370
-    CQ_TRY(poly_eval(c, bpoly + l * n + 1, (uint32_t)(n - 1), x, &b0_evals[l]));
-    CQ_TRY(poly_eval(c, f_coeff + l * n, (uint32_t)n, x, &f_evals[l]));
     tr.write_scalar(b0_evals[l]);
     tr.write_scalar(f_evals[l]);
     tr.write_scalar(a_at_zero[l]);
@@ -438,9 +467,7 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, cq_rng_next_u
   // ---- multiopen, GWC (gwc/prover.rs:42-91): every query is at x => one point group ---------------------
   {
     const Fr v = tr.squeeze();
-    // h(X) = sum_i xn^i h_i (vanishing/prover.rs:131-135); its evaluation is recomputed by get_eval
-    std::vector<Fr> h_evals(pieces);
-    for (size_t i = 0; i < pieces; i++) CQ_TRY(poly_eval(c, h_coeff + i * n, (uint32_t)n, x, &h_evals[i]));
+    // h(X) = sum_i xn^i h_i (vanishing/prover.rs:131-135); get_eval's value follows from the piece evals
     Fr h_eval = Fr::zero();
     for (size_t i = pieces; i-- > 0;) h_eval = h_eval * xn + h_evals[i];
     LincombArgs la;
