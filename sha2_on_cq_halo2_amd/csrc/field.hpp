@@ -21,6 +21,16 @@
 #define CQ_UNROLL
 #endif
 
+// Hides a value's known bit-width from the optimiser.  hipcc (ROCm 7.2) lowers 64-bit products of two
+// operands it can prove to be < 2^24 through its 24-bit multiply patterns and, on gfx950, produced wrong
+// high halves for `(x & 0xffffff) * constant` (the 24-bit mask was dropped); values that are 24 bits
+// wide by construction are therefore passed through this before being multiplied.
+#if defined(__AMDGCN__)
+#define CQ_OPAQUE32(x) asm volatile("" : "+v"(x))
+#else
+#define CQ_OPAQUE32(x) (void)(x)
+#endif
+
 namespace cq {
 
 struct alignas(16) U256 {
@@ -145,12 +155,82 @@ struct Fp {
   CQ_HD Fp neg() const { return zero() - *this; }
   CQ_HD Fp dbl() const { return *this + *this; }
 
+  // limb j of p in base 2^29
+  static constexpr uint32_t p29(int j) {
+    const int bit = 29 * j, w = bit >> 5, sh = bit & 31;
+    const uint64_t lo = P::MOD[w];
+    const uint64_t hi = (w + 1 < 8) ? P::MOD[w + 1] : 0;
+    return (uint32_t)(((lo | (hi << 32)) >> sh) & 0x1fffffffu);
+  }
+  // 8 x 32-bit words -> 9 x 29-bit limbs
+  static CQ_HD void unpack29(const uint32_t* x, uint32_t* a) {
+    a[0] = x[0] & 0x1fffffffu;
+    a[1] = ((x[0] >> 29) | (x[1] << 3)) & 0x1fffffffu;
+    a[2] = ((x[1] >> 26) | (x[2] << 6)) & 0x1fffffffu;
+    a[3] = ((x[2] >> 23) | (x[3] << 9)) & 0x1fffffffu;
+    a[4] = ((x[3] >> 20) | (x[4] << 12)) & 0x1fffffffu;
+    a[5] = ((x[4] >> 17) | (x[5] << 15)) & 0x1fffffffu;
+    a[6] = ((x[5] >> 14) | (x[6] << 18)) & 0x1fffffffu;
+    a[7] = ((x[6] >> 11) | (x[7] << 21)) & 0x1fffffffu;
+    a[8] = x[7] >> 8;
+  }
+
   // Montgomery product (same function as derive/field.rs:471-564); result < p.
   // Device: CIOS over 32-bit limbs (v_mad_u64_u32).  Host: CIOS over 64-bit limbs with a 128-bit
   // accumulator -- identical values, ~4x fewer multiplies for the host-side glue (window folding,
   // normalisation, transcript scalars).
   CQ_HD Fp operator*(const Fp& b) const {
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(CQ_MUL_CIOS32)
+    // Unsaturated 9 x 29-bit limbs: every partial product lands in a 64-bit column accumulator with a
+    // single v_mad_u64_u32 and no carry handling (9 products of < 2^58 plus 9 reduction products stay
+    // below 2^63).  Montgomery reduction runs digit-serially in base 2^29 for 8 digits and finishes with
+    // one 24-bit digit so that the overall divisor is exactly 2^256 (8*29 + 24): the value in memory
+    // keeps the reference's R = 2^256 form.  ~170 multiplies + ~170 simple ops, versus 136 + ~430 for
+    // the 32-bit CIOS below (whose carry plumbing the compiler turns into v_mov / 64-bit adds).
+    constexpr uint32_t M29 = 0x1fffffffu;
+    uint32_t A[9], B[9];
+    unpack29(v.l, A);
+    unpack29(b.v.l, B);
+    CQ_OPAQUE32(A[8]);
+    CQ_OPAQUE32(B[8]);
+    uint64_t c[18];
+    CQ_UNROLL for (int k = 0; k < 18; k++) c[k] = 0;
+    CQ_UNROLL for (int i = 0; i < 9; i++) {
+      CQ_UNROLL for (int j = 0; j < 9; j++) c[i + j] += (uint64_t)A[i] * B[j];
+    }
+    constexpr uint32_t INV29 = P::INV & M29;
+    CQ_UNROLL for (int i = 0; i < 8; i++) {
+      const uint32_t m = ((uint32_t)c[i] * INV29) & M29;
+      CQ_UNROLL for (int j = 0; j < 9; j++) c[i + j] += (uint64_t)m * p29(j);
+      c[i + 1] += c[i] >> 29;
+    }
+    {
+      uint32_t m = ((uint32_t)c[8] * INV29) & 0x00ffffffu;
+      CQ_OPAQUE32(m);
+      CQ_UNROLL for (int j = 0; j < 9; j++) c[8 + j] += (uint64_t)m * p29(j);
+    }
+    // V = sum_{k>=8} c[k] 2^(29(k-8)) has its low 24 bits clear; result = V >> 24 (< 2p)
+    uint32_t d[10];
+    uint64_t carry = 0;
+    CQ_UNROLL for (int k = 0; k < 10; k++) {
+      const uint64_t sres = c[8 + k] + carry;
+      d[k] = (uint32_t)sres & M29;
+      carry = sres >> 29;
+    }
+    uint32_t r29[9];
+    CQ_UNROLL for (int j = 0; j < 9; j++) r29[j] = (d[j] >> 24) | ((d[j + 1] << 5) & M29);
+    Fp r;
+    r.v.l[0] = r29[0] | (r29[1] << 29);
+    r.v.l[1] = (r29[1] >> 3) | (r29[2] << 26);
+    r.v.l[2] = (r29[2] >> 6) | (r29[3] << 23);
+    r.v.l[3] = (r29[3] >> 9) | (r29[4] << 20);
+    r.v.l[4] = (r29[4] >> 12) | (r29[5] << 17);
+    r.v.l[5] = (r29[5] >> 15) | (r29[6] << 14);
+    r.v.l[6] = (r29[6] >> 18) | (r29[7] << 11);
+    r.v.l[7] = (r29[7] >> 21) | (r29[8] << 8);
+    cond_sub_p(r.v.l, 0);
+    return r;
+#elif defined(__HIP_DEVICE_COMPILE__)
     uint32_t t[10];
     CQ_UNROLL for (int i = 0; i < 10; i++) t[i] = 0;
     CQ_UNROLL for (int i = 0; i < 8; i++) {
