@@ -93,6 +93,13 @@ int cq_msm_batch_dev(cq_ctx* ctx, const uint64_t* const* coeffs_dev, const uint6
  * (derive/curve.rs:399-412). */
 int cq_g1_sum(const uint64_t* jac_points, size_t count, uint64_t out_jac[12]);
 int cq_g1_to_affine(const uint64_t jac[12], uint64_t out_affine[8]);
+/* Fixed-base acceleration: builds per-window tables T[w][i] = 2^(c*w) * bases[i] (ceil(255/c) x n x 64 B of
+ * HBM) for a device-resident base array and registers them with the context; later multiexps over
+ * that array (or a prefix of it) then need a single bucket set and no window folding.  cq_params_*
+ * does this for g and g_lagrange unless disabled with cq_msm_set_precompute(ctx, 0).  Results are
+ * identical either way. */
+int cq_msm_precompute_dev(cq_ctx* ctx, const uint64_t* bases_dev, size_t n);
+int cq_msm_set_precompute(cq_ctx* ctx, int on);
 /* Pippenger window width in bits (2..15), 0 = automatic.  Tuning knob; results do not depend on it. */
 int cq_msm_set_window(cq_ctx* ctx, uint32_t bits);
 

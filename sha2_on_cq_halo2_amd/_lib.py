@@ -134,6 +134,8 @@ def _declare(lib):  # noqa: F811
     lib.cq_xoshiro256ss_next_u64.argtypes = [vp]
     lib.cq_buffer_rng_next_u64.restype = C.c_uint64
     lib.cq_buffer_rng_next_u64.argtypes = [vp]
+    lib.cq_msm_precompute_dev.argtypes = [vp, vp, C.c_size_t]
+    lib.cq_msm_set_precompute.argtypes = [vp, C.c_int]
     lib.cq_g1_sum.argtypes = [vp, C.c_size_t, vp]
     lib.cq_g1_to_affine.argtypes = [vp, vp]
     lib.cq_profile_enable.argtypes = [vp, C.c_int]

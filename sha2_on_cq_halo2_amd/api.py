@@ -524,3 +524,16 @@ class ProvingKey(_Handle):
     def create_proof_dev(self, advice_ptrs, rng_words=None, seed=None) -> bytes:
         fn, st = self._rng(rng_words, seed)
         return self._run(self.ctx.lib.cq_create_proof, list(advice_ptrs), fn, st)
+
+
+def _ctx_msm_precompute(self, bases_ptr: int, n: int):
+    """Registers per-window tables for a device-resident base array (fixed-base acceleration)."""
+    self._chk(self.lib.cq_msm_precompute_dev(self.h, bases_ptr, n))
+
+
+def _ctx_set_msm_precompute(self, on: bool):
+    self._chk(self.lib.cq_msm_set_precompute(self.h, 1 if on else 0))
+
+
+Context.msm_precompute = _ctx_msm_precompute
+Context.set_msm_precompute = _ctx_set_msm_precompute

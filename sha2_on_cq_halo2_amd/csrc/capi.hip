@@ -55,6 +55,7 @@ void cq_ctx_destroy(cq_ctx* c) {
     if (c->scratch[i]) hipFree(c->scratch[i]);
   if (c->pinned) hipHostFree(c->pinned);
   if (c->fb_table) hipFree(c->fb_table);
+  for (auto& t : c->msm_tables) hipFree(t.table);
   if (c->own_stream) hipStreamDestroy(c->stream);
   delete c;
 }

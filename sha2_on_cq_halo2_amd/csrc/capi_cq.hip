@@ -6,6 +6,7 @@
 #include "ctx.hpp"
 #include "prover.hpp"
 #include "setup.hpp"
+#include "msm.hpp"
 
 using namespace cq;
 
@@ -35,6 +36,11 @@ int cq_table_config_create(cq_ctx* c, size_t size, const uint64_t* g1_lagrange, 
   CQ_HIP(c, hipMemcpyAsync(t->g1_lagrange, g1_lagrange, bytes, hipMemcpyHostToDevice, c->stream));
   CQ_HIP(c, hipMemcpyAsync(t->g_lagrange_opening_at_0, opening_at_0, bytes, hipMemcpyHostToDevice, c->stream));
   CQ_HIP(c, hipStreamSynchronize(c->stream));
+  if (c->msm_precompute) {
+    int rc2;
+    if ((rc2 = msm_register_tables(c, t->g1_lagrange, size)) != CQ_OK) return rc2;
+    if ((rc2 = msm_register_tables(c, t->g_lagrange_opening_at_0, size)) != CQ_OK) return rc2;
+  }
   *out = t;
   return CQ_OK;
 }
@@ -59,6 +65,10 @@ int cq_table_config_setup_from_toxic_waste(cq_ctx* c, size_t size, const uint64_
   const Fr sf = Fr::from_limbs64(s);
   if ((rc = srs_powers_and_lagrange(c, t->log_n, sf, nullptr, t->g1_lagrange, tmp_sc, lag_sc)) != CQ_OK) return rc;
   if ((rc = srs_opening_at_zero(c, t->log_n, sf, lag_sc, tmp_sc, t->g_lagrange_opening_at_0)) != CQ_OK) return rc;
+  if (c->msm_precompute) {
+    if ((rc = msm_register_tables(c, t->g1_lagrange, size)) != CQ_OK) return rc;
+    if ((rc = msm_register_tables(c, t->g_lagrange_opening_at_0, size)) != CQ_OK) return rc;
+  }
   CQ_HIP(c, hipStreamSynchronize(c->stream));
   *out = t;
   return CQ_OK;
@@ -67,6 +77,8 @@ int cq_table_config_setup_from_toxic_waste(cq_ctx* c, size_t size, const uint64_
 void cq_table_config_destroy(cq_table_config* t) {
   if (!t) return;
   hipStreamSynchronize(t->ctx->stream);
+  msm_unregister_tables(t->ctx, t->g1_lagrange);
+  msm_unregister_tables(t->ctx, t->g_lagrange_opening_at_0);
   if (t->g1_lagrange) hipFree(t->g1_lagrange);
   if (t->g_lagrange_opening_at_0) hipFree(t->g_lagrange_opening_at_0);
   delete t;
@@ -246,7 +258,9 @@ int cq_pk_create(cq_ctx* c, cq_params* params, const cq_circuit* cs, cq_table_co
     for (size_t j = 0; j < lk.tables.size(); j++)
       CQ_HIP(c, hipMemcpyAsync(cat + j * N, lk.tables[j]->qs, N * sizeof(G1Affine), hipMemcpyDeviceToDevice, c->stream));
     pk->qs_concat.push_back(cat);
+    if (c->msm_precompute && (rc = msm_register_tables(c, cat, lk.tables.size() * N)) != CQ_OK) return rc;
   }
+  if (c->msm_precompute && (rc = msm_register_tables(c, pk->b0_g1_bound, n - 1)) != CQ_OK) return rc;
   CQ_HIP(c, hipStreamSynchronize(c->stream));
   *out = pk;
   return CQ_OK;
@@ -257,8 +271,12 @@ void cq_pk_destroy(cq_pk* pk) {
   hipStreamSynchronize(pk->ctx->stream);
   if (pk->domain) domain_destroy(pk->domain);
   if (pk->l_active_row) hipFree(pk->l_active_row);
+  msm_unregister_tables(pk->ctx, pk->b0_g1_bound);
   if (pk->own_b0 && pk->b0_g1_bound) hipFree(pk->b0_g1_bound);
-  for (auto p : pk->qs_concat) hipFree(p);
+  for (auto p : pk->qs_concat) {
+    msm_unregister_tables(pk->ctx, p);
+    hipFree(p);
+  }
   delete pk;
 }
 

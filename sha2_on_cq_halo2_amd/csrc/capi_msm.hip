@@ -15,6 +15,8 @@ static uint32_t pick_c(cq_ctx* c, uint32_t n) {
 }
 
 // Runs `count` MSMs of equal length (each with its own base array); results to host Jacobians.
+// Base arrays registered with cq_msm_precompute use their per-window tables (one bucket set per MSM,
+// no window folding on the host); MSMs are grouped so that one launch uses one mode.
 int cq_msm_multi(cq_ctx* c, const Fr* const* scalars, const G1Affine* const* bases, size_t len, size_t count,
                  uint64_t* out_jac) {
   if (len > 0x7fffffffull) return c->fail(CQ_ERR_ARG, "msm: len too large");
@@ -23,24 +25,40 @@ int cq_msm_multi(cq_ctx* c, const Fr* const* scalars, const G1Affine* const* bas
     memset(out_jac, 0, count * 12 * sizeof(uint64_t));
     return CQ_OK;
   }
-  const uint32_t cb = pick_c(c, n);
   size_t done = 0;
   while (done < count) {
-    uint32_t batch = (uint32_t)((count - done) < MSM_MAX_BATCH ? (count - done) : MSM_MAX_BATCH);
+    // maximal run of MSMs with the same mode / table geometry
+    const cq_ctx::MsmTable* t0 = c->find_msm_table(bases[done], len);
+    const bool pre = t0 != nullptr;
+    const uint32_t cb = pre ? t0->c : pick_c(c, n);
+    uint32_t batch = 1;
+    while (done + batch < count && batch < MSM_MAX_BATCH) {
+      const cq_ctx::MsmTable* t = c->find_msm_table(bases[done + batch], len);
+      if ((t != nullptr) != pre) break;
+      if (pre && t->c != cb) break;
+      batch++;
+    }
     // keep the workspace below ~8 GiB
-    while (batch > 1 && MsmLayout(n, cb, batch).total > ((size_t)8 << 30)) batch = (batch + 1) / 2;
-    MsmLayout L(n, cb, batch);
+    while (batch > 1 && MsmLayout(n, cb, batch, pre).total > ((size_t)8 << 30)) batch = (batch + 1) / 2;
+    MsmLayout L(n, cb, batch, pre);
+    std::vector<const G1Affine*> bp(batch);
+    std::vector<size_t> strides(batch, 0);
+    for (uint32_t j = 0; j < batch; j++) {
+      const cq_ctx::MsmTable* t = pre ? c->find_msm_table(bases[done + j], len) : nullptr;
+      bp[j] = pre ? (const G1Affine*)t->table : bases[done + j];
+      strides[j] = pre ? t->n : 0;
+    }
     void *ws, *wsums, *host;
     int rc;
     if ((rc = c->ensure_scratch(3, L.total, &ws)) != CQ_OK) return rc;
-    if ((rc = c->ensure_scratch(4, (size_t)batch * L.W * sizeof(G1Jac), &wsums)) != CQ_OK) return rc;
-    if ((rc = c->ensure_pinned((size_t)batch * L.W * sizeof(G1Jac), &host)) != CQ_OK) return rc;
-    int r = msm_run(c, scalars + done, bases + done, n, cb, batch, ws, (G1Jac*)wsums);
+    if ((rc = c->ensure_scratch(4, (size_t)batch * L.Wb * sizeof(G1Jac), &wsums)) != CQ_OK) return rc;
+    if ((rc = c->ensure_pinned((size_t)batch * L.Wb * sizeof(G1Jac), &host)) != CQ_OK) return rc;
+    int r = msm_run(c, scalars + done, bp.data(), n, cb, batch, pre, strides.data(), ws, (G1Jac*)wsums);
     if (r != 0) return c->fail(CQ_ERR_HIP, "msm launch failed");
-    CQ_HIP(c, hipMemcpyAsync(host, wsums, (size_t)batch * L.W * sizeof(G1Jac), hipMemcpyDeviceToHost, c->stream));
+    CQ_HIP(c, hipMemcpyAsync(host, wsums, (size_t)batch * L.Wb * sizeof(G1Jac), hipMemcpyDeviceToHost, c->stream));
     CQ_HIP(c, hipStreamSynchronize(c->stream));
     for (uint32_t j = 0; j < batch; j++) {
-      G1Jac r = msm_fold_windows((const G1Jac*)host + (size_t)j * L.W, L.W, cb);
+      G1Jac r = pre ? ((const G1Jac*)host)[j] : msm_fold_windows((const G1Jac*)host + (size_t)j * L.W, L.W, cb);
       uint64_t* o = out_jac + (done + j) * 12;
       r.x.to_limbs64(o);
       r.y.to_limbs64(o + 4);
@@ -51,6 +69,36 @@ int cq_msm_multi(cq_ctx* c, const Fr* const* scalars, const G1Affine* const* bas
   return CQ_OK;
 }
 
+void msm_unregister_tables(cq_ctx* c, const void* bases) {
+  for (size_t i = 0; i < c->msm_tables.size(); i++)
+    if (c->msm_tables[i].bases == bases) {
+      hipFree(c->msm_tables[i].table);
+      c->msm_tables.erase(c->msm_tables.begin() + i);
+      return;
+    }
+}
+
+// Builds and registers per-window tables T[w][i] = 2^(c*w) * bases[i] for a device-resident base array.
+// Memory: ceil(255/c) x n x 64 B (17 x the SRS for n >= 2^15) -- sized for 288 GB of HBM.
+int msm_register_tables(cq_ctx* c, const G1Affine* bases, size_t n) {
+  if (!bases || n == 0 || n > (1u << 26)) return CQ_OK;  // nothing to do / unsupported: plain mode
+  if (c->find_msm_table(bases, n)) return CQ_OK;
+  const uint32_t cb = pick_c(c, (uint32_t)n);
+  const uint32_t W = (255 + cb - 1) / cb;
+  if (W > 32) return CQ_OK;
+  void* table = nullptr;
+  if (hipMalloc(&table, (size_t)W * n * sizeof(G1Affine)) != hipSuccess) {
+    (void)hipGetLastError();
+    return CQ_OK;  // not enough memory: stay in plain mode
+  }
+  if (msm_precompute_tables(c, bases, (uint32_t)n, cb, (G1Affine*)table) != 0) {
+    hipFree(table);
+    return c->fail(CQ_ERR_HIP, "msm precompute failed");
+  }
+  c->msm_tables.push_back({bases, n, cb, table});
+  return CQ_OK;
+}
+
 static int msm_batch(cq_ctx* c, const Fr* const* scalars, const G1Affine* bases, size_t len, size_t count,
                      uint64_t* out_jac) {
   std::vector<const G1Affine*> bp(count, bases);
@@ -58,6 +106,18 @@ static int msm_batch(cq_ctx* c, const Fr* const* scalars, const G1Affine* bases,
 }
 
 extern "C" {
+
+int cq_msm_precompute_dev(cq_ctx* c, const uint64_t* bases_dev, size_t n) {
+  if (!c || !bases_dev) return CQ_ERR_ARG;
+  CQ_HIP(c, hipSetDevice(c->device));
+  return msm_register_tables(c, (const G1Affine*)bases_dev, n);
+}
+
+int cq_msm_set_precompute(cq_ctx* c, int on) {
+  if (!c) return CQ_ERR_ARG;
+  c->msm_precompute = on != 0;
+  return CQ_OK;
+}
 
 int cq_msm_set_window(cq_ctx* c, uint32_t bits) {
   if (!c || (bits != 0 && (bits < 2 || bits > 15))) return CQ_ERR_ARG;
@@ -115,6 +175,11 @@ int cq_params_create(cq_ctx* c, uint32_t k, const uint64_t* g, const uint64_t* g
   CQ_HIP(c, hipMemcpyAsync(p->g, g, bytes, hipMemcpyHostToDevice, c->stream));
   CQ_HIP(c, hipMemcpyAsync(p->g_lagrange, g_lagrange, bytes, hipMemcpyHostToDevice, c->stream));
   CQ_HIP(c, hipStreamSynchronize(c->stream));
+  if (c->msm_precompute) {
+    int rc2;
+    if ((rc2 = msm_register_tables(c, p->g, p->n)) != CQ_OK) return rc2;
+    if ((rc2 = msm_register_tables(c, p->g_lagrange, p->n)) != CQ_OK) return rc2;
+  }
   *out = p;
   return CQ_OK;
 }
@@ -139,6 +204,10 @@ int cq_params_setup_from_toxic_waste(cq_ctx* c, uint32_t k, const uint64_t s[4],
   if ((rc = c->ensure_scratch(1, p->n * sizeof(Fr), &tmp)) != CQ_OK) return rc;
   rc = srs_powers_and_lagrange(c, k, Fr::from_limbs64(s), p->g, p->g_lagrange, (Fr*)tmp, nullptr);
   if (rc != CQ_OK) return rc;
+  if (c->msm_precompute) {
+    if ((rc = msm_register_tables(c, p->g, p->n)) != CQ_OK) return rc;
+    if ((rc = msm_register_tables(c, p->g_lagrange, p->n)) != CQ_OK) return rc;
+  }
   CQ_HIP(c, hipStreamSynchronize(c->stream));
   *out = p;
   return CQ_OK;
@@ -154,6 +223,8 @@ int cq_fixed_base_mul_dev(cq_ctx* c, const uint64_t* scalars_dev, size_t n, uint
 void cq_params_destroy(cq_params* p) {
   if (!p) return;
   hipStreamSynchronize(p->ctx->stream);
+  msm_unregister_tables(p->ctx, p->g);
+  msm_unregister_tables(p->ctx, p->g_lagrange);
   hipFree(p->g);
   hipFree(p->g_lagrange);
   delete p;

@@ -20,7 +20,16 @@ struct cq_ctx {
   void* pinned = nullptr;  // small pinned host staging buffer
   size_t pinned_bytes = 0;
   uint32_t msm_c = 0;  // 0 = automatic window size
+  bool msm_precompute = true;  // build per-window tables for resident SRS arrays
   void* fb_table = nullptr;  // fixed-base table d*2^(8j)*G (setup.hip)
+  // precomputed MSM window tables, keyed by the base array they were derived from
+  struct MsmTable { const void* bases; size_t n; uint32_t c; void* table; };
+  std::vector<MsmTable> msm_tables;
+  const MsmTable* find_msm_table(const void* bases, size_t len) const {
+    for (auto& t : msm_tables)
+      if (t.bases == bases && len <= t.n) return &t;
+    return nullptr;
+  }
   // optional per-kernel timing with HIP events on `stream` (bench.py's roofline leg)
   struct ProfSpan { int id; hipEvent_t a, b; };
   bool prof_on = false;

@@ -62,17 +62,18 @@ static __device__ __forceinline__ uint32_t wave_atomic_inc(uint32_t* counters, u
 }
 
 // ---- pointer tables (per-MSM scalar / base arrays), written from a by-value kernel argument ------
-__global__ void msm_set_ptrs_kernel(MsmPtrs sc, MsmPtrs bs, const void** dst, uint32_t batch) {
+__global__ void msm_set_ptrs_kernel(MsmPtrs sc, MsmPtrs bs, MsmStrides st, const void** dst, uint32_t batch) {
   const uint32_t t = threadIdx.x;
   if (t < batch) {
     dst[t] = sc.p[t];
     dst[batch + t] = bs.p[t];
+    ((uint64_t*)(dst + 2 * batch))[t] = st.s[t];
   }
 }
 
 // ---- 1. digits + histogram -------------------------------------------------------------------
 __global__ __launch_bounds__(256) void msm_digits_kernel(const Fr* const* __restrict__ scalars, uint32_t n, uint32_t c,
-                                                         uint32_t nwin, uint16_t* __restrict__ digits,
+                                                         uint32_t nwin, uint32_t pre, uint16_t* __restrict__ digits,
                                                          uint32_t* __restrict__ counts) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t m = blockIdx.y;
@@ -102,7 +103,8 @@ __global__ __launch_bounds__(256) void msm_digits_kernel(const Fr* const* __rest
     }
     const size_t mw = (size_t)m * nwin + w;
     if (live) digits[mw * n + i] = (uint16_t)(d | (neg << 15));
-    wave_atomic_inc(counts, (uint32_t)(mw * M) + (d - 1), live && d != 0);
+    // precomputed-table mode folds every window into one bucket set per MSM
+    wave_atomic_inc(counts, (uint32_t)((pre ? (size_t)m : mw) * M) + (d - 1), live && d != 0);
   }
 }
 
@@ -213,17 +215,19 @@ __global__ __launch_bounds__(256) void msm_scan_apply_kernel(const uint32_t* __r
 
 // ---- 3. scatter (counting sort) ----------------------------------------------------------------
 __global__ __launch_bounds__(256) void msm_scatter_kernel(const uint16_t* __restrict__ digits, uint32_t n, uint32_t M,
-                                                          const uint32_t* __restrict__ off0,
+                                                          uint32_t nwin, uint32_t pre, const uint32_t* __restrict__ off0,
                                                           uint32_t* __restrict__ cursor, uint32_t* __restrict__ sorted) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t mw = blockIdx.y;  // msm * W + window
   const bool live = i < n;
   const uint16_t dg = live ? digits[(size_t)mw * n + i] : (uint16_t)0;
   const uint32_t d = dg & 0x7fffu;
-  const uint32_t g = mw * M + (d - 1);
+  const uint32_t w = mw % nwin;
+  const uint32_t g = (pre ? mw / nwin : mw) * M + (d - 1);
   const bool act = live && d != 0;
   const uint32_t rank = wave_atomic_inc(cursor, g, act);
-  if (act) sorted[off0[g] + rank] = i | ((uint32_t)(dg >> 15) << 31);
+  // entry: point index (26 bits) | window << 26 (precomputed-table mode) | sign << 31
+  if (act) sorted[off0[g] + rank] = i | (pre ? (w << 26) : 0u) | ((uint32_t)(dg >> 15) << 31);
 }
 
 // ---- 4. bucket accumulation ----------------------------------------------------------------
@@ -250,20 +254,25 @@ static __device__ __forceinline__ uint32_t owner_of(const uint32_t* __restrict__
 
 // level 1: lane j owns sub-list j of <= MSM_S1 point indices
 __global__ __launch_bounds__(MSM_ACC_THREADS) void msm_accumulate_kernel(
-    const G1Affine* const* __restrict__ bases, uint32_t buckets_per_msm, const uint32_t* __restrict__ sorted,
-    const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ off0, const uint32_t* __restrict__ t1,
-    const uint32_t* __restrict__ off1, uint32_t Bt, XYZZ* __restrict__ partial, XYZZ* __restrict__ buckets) {
+    const G1Affine* const* __restrict__ bases, uint32_t buckets_per_msm, uint32_t pre,
+    const uint64_t* __restrict__ table_strides, const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ off0,
+    const uint32_t* __restrict__ t1, const uint32_t* __restrict__ off1, uint32_t Bt, XYZZ* __restrict__ partial,
+    XYZZ* __restrict__ buckets) {
   const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= off1[Bt]) return;
   const uint32_t g = owner_of(off1, Bt, j);
-  const G1Affine* __restrict__ pts = bases[g / buckets_per_msm];
+  const uint32_t msm = g / buckets_per_msm;
+  const G1Affine* __restrict__ pts = bases[msm];
+  const size_t table_stride = pre ? (size_t)table_strides[msm] : 0;
   const uint32_t r = j - off1[g];
   const uint32_t lo = off0[g] + r * MSM_S1;
   const uint32_t hi = min(off0[g] + cnt[g], lo + MSM_S1);
   XYZZ acc = XYZZ::identity();
   for (uint32_t e = lo; e < hi; e++) {
     const uint32_t ix = sorted[e];
-    G1Affine p = load_affine(pts + (ix & 0x7fffffffu));
+    // precomputed mode: table[w][i] = 2^(c*w) * base[i]
+    const size_t at = pre ? (size_t)((ix >> 26) & 31u) * table_stride + (ix & 0x03ffffffu) : (size_t)(ix & 0x7fffffffu);
+    G1Affine p = load_affine(pts + at);
     if (ix >> 31) p = p.neg();
     xyzz_add_affine(acc, p);
   }
@@ -322,6 +331,36 @@ __global__ __launch_bounds__(MSM_ACC_THREADS) void msm_combine_short_kernel(
   XYZZ acc = prev[lo];
   for (uint32_t e = 1; e < tp; e++) xyzz_add(acc, prev[lo + e]);
   buckets[g] = acc;  // tp <= MSM_SHORT <= MSM_S2  =>  t_cur[g] == 1
+}
+
+// ---- precomputed window tables: next[i] = 2^c * prev[i] (affine in, affine out) ---------------------
+__global__ __launch_bounds__(256) void msm_pre_kernel(const G1Affine* __restrict__ prev, G1Affine* __restrict__ next, uint32_t n,
+                                                      uint32_t c) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const G1Affine p = load_affine(prev + i);
+  XYZZ a = xyzz_dbl_affine(p);
+  for (uint32_t k = 1; k < c; k++) a = xyzz_dbl(a);
+  G1Affine r = G1Affine::identity();
+  if (!a.is_identity()) {
+    const Fq iv = (a.zz * a.zzz).inv();
+    r.x = a.x * (iv * a.zzz);
+    r.y = a.y * (iv * a.zz);
+  }
+  uint4* q = reinterpret_cast<uint4*>(next + i);
+  q[0] = make_uint4(r.x.v.l[0], r.x.v.l[1], r.x.v.l[2], r.x.v.l[3]);
+  q[1] = make_uint4(r.x.v.l[4], r.x.v.l[5], r.x.v.l[6], r.x.v.l[7]);
+  q[2] = make_uint4(r.y.v.l[0], r.y.v.l[1], r.y.v.l[2], r.y.v.l[3]);
+  q[3] = make_uint4(r.y.v.l[4], r.y.v.l[5], r.y.v.l[6], r.y.v.l[7]);
+}
+
+int msm_precompute_tables(cq_ctx* ctx, const G1Affine* bases, uint32_t n, uint32_t c, G1Affine* table /* W*n */) {
+  const uint32_t W = (255 + c - 1) / c;
+  hipStream_t s = ctx->stream;
+  if (hipMemcpyAsync(table, bases, (size_t)n * sizeof(G1Affine), hipMemcpyDeviceToDevice, s) != hipSuccess) return -1;
+  for (uint32_t w = 1; w < W; w++)
+    msm_pre_kernel<<<(n + 255) / 256, 256, 0, s>>>(table + (size_t)(w - 1) * n, table + (size_t)w * n, n, c);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
 // ---- 5. reduction: sum_{b=1..M} b * B_b per window ------------------------------------------------
@@ -428,15 +467,17 @@ uint32_t msm_window_bits(uint32_t n) {
   return 2;
 }
 
-MsmLayout::MsmLayout(uint32_t n_, uint32_t c_, uint32_t batch_) : n(n_), c(c_), batch(batch_) {
+MsmLayout::MsmLayout(uint32_t n_, uint32_t c_, uint32_t batch_, bool pre_) : n(n_), c(c_), batch(batch_), pre(pre_) {
   W = (255 + c - 1) / c;  // signed digits need W*c >= 255 for 254-bit scalars
   M = 1u << (c - 1);
-  B = W * M;
+  Wb = pre ? 1 : W;       // bucket sets per MSM: one when every window has its own precomputed table
+  B = Wb * M;
   Bt = batch * B;
   levels = 1;
   {
     uint64_t cap = MSM_S1;
-    while (cap < n) { cap *= MSM_S2; levels++; }
+    const uint64_t maxlist = pre ? (uint64_t)n * W : n;  // longest possible bucket list
+    while (cap < maxlist) { cap *= MSM_S2; levels++; }
   }
   nseq = levels + 1;
   nblk = (Bt + 2047) / 2048;
@@ -445,7 +486,7 @@ MsmLayout::MsmLayout(uint32_t n_, uint32_t c_, uint32_t batch_) : n(n_), c(c_), 
   auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
   const uint64_t E = (uint64_t)batch * W * n;  // upper bound on (point,digit) entries
   size_t o = 0;
-  off_ptrs = o;    o = up(o + (size_t)2 * batch * sizeof(void*));
+  off_ptrs = o;    o = up(o + (size_t)3 * batch * sizeof(void*));
   off_digits = o;  o = up(o + (size_t)E * sizeof(uint16_t));
   off_counts = o;  o = up(o + (size_t)Bt * sizeof(uint32_t));
   off_cursor = o;  o = up(o + (size_t)Bt * sizeof(uint32_t));
@@ -466,14 +507,15 @@ MsmLayout::MsmLayout(uint32_t n_, uint32_t c_, uint32_t batch_) : n(n_), c(c_), 
   o = up(o + (size_t)tmax[0] * sizeof(XYZZ));
   off_part[1] = o;
   o = up(o + (size_t)(levels > 1 ? tmax[1] : 0) * sizeof(XYZZ));
-  off_pairs = o;   o = up(o + (size_t)batch * W * G * 2 * sizeof(XYZZ));
+  off_pairs = o;   o = up(o + (size_t)batch * Wb * G * 2 * sizeof(XYZZ));
   total = o;
 }
 
 int msm_run(cq_ctx* ctx, const Fr* const* scalars_host_ptrs, const G1Affine* const* bases_host_ptrs, uint32_t n,
-            uint32_t c, uint32_t batch, void* workspace, G1Jac* window_sums_dev) {
+            uint32_t c, uint32_t batch, bool pre, const size_t* table_strides, void* workspace, G1Jac* window_sums_dev) {
   hipStream_t s = ctx->stream;
-  MsmLayout L(n, c, batch);
+  MsmLayout L(n, c, batch, pre);
+  if (pre && (n > (1u << 26) || L.W > 32)) return -4;
   if (L.tmax[0] > 0xfffffff0ull || (uint64_t)batch * L.W * n > 0xfffffff0ull) return -3;
   char* ws = (char*)workspace;
   const Fr** d_scalars = (const Fr**)(ws + L.off_ptrs);
@@ -491,22 +533,25 @@ int msm_run(cq_ctx* ctx, const Fr* const* scalars_host_ptrs, const G1Affine* con
   const uint32_t M = L.M, W = L.W, Bt = L.Bt;
   if (batch == 0 || batch > MSM_MAX_BATCH) return -2;
   MsmPtrs sp, bp;
+  MsmStrides stv;
   for (uint32_t i = 0; i < MSM_MAX_BATCH; i++) {
     sp.p[i] = i < batch ? (const void*)scalars_host_ptrs[i] : nullptr;
     bp.p[i] = i < batch ? (const void*)bases_host_ptrs[i] : nullptr;
+    stv.s[i] = (i < batch && pre) ? (uint64_t)table_strides[i] : 0;
   }
-  msm_set_ptrs_kernel<<<1, 64, 0, s>>>(sp, bp, (const void**)d_scalars, batch);
+  msm_set_ptrs_kernel<<<1, 64, 0, s>>>(sp, bp, stv, (const void**)d_scalars, batch);
+  const uint64_t* d_strides = (const uint64_t*)((const void**)d_scalars + 2 * batch);
   // counts, cursor and buckets (identity = all zero) are adjacent: one memset
   if (hipMemsetAsync(counts, 0, L.zero_end - L.off_counts, s) != hipSuccess) return -1;
-  msm_digits_kernel<<<dim3((n + 255) / 256, batch), 256, 0, s>>>(d_scalars, n, c, W, digits, counts);
+  msm_digits_kernel<<<dim3((n + 255) / 256, batch), 256, 0, s>>>(d_scalars, n, c, W, pre ? 1u : 0u, digits, counts);
   msm_scan_reduce_kernel<<<L.nblk, 256, 0, s>>>(counts, Bt, L.nseq, blocksums);
   msm_scan_spine_kernel<<<1, 1024, 0, s>>>(blocksums, L.nblk, L.nseq);
   msm_scan_apply_kernel<<<L.nblk, 256, 0, s>>>(counts, Bt, L.nseq, blocksums, off, tk);
   const uint32_t* off0 = off;
-  msm_scatter_kernel<<<dim3((n + 255) / 256, batch * W), 256, 0, s>>>(digits, n, M, off0, cursor, sorted);
+  msm_scatter_kernel<<<dim3((n + 255) / 256, batch * W), 256, 0, s>>>(digits, n, M, W, pre ? 1u : 0u, off0, cursor, sorted);
   hipEvent_t pe = ctx->prof_begin(CQ_PROF_MSM_ACCUMULATE);
   msm_accumulate_kernel<<<(uint32_t)((L.tmax[0] + MSM_ACC_THREADS - 1) / MSM_ACC_THREADS), MSM_ACC_THREADS, 0, s>>>(
-      d_bases, L.B, sorted, counts, off0, tk, off + (size_t)(Bt + 1), Bt, part[0], buckets);
+      d_bases, L.B, pre ? 1u : 0u, d_strides, sorted, counts, off0, tk, off + (size_t)(Bt + 1), Bt, part[0], buckets);
   ctx->prof_end(pe);
   for (uint32_t k = 1; k < L.levels; k++) {
     const uint32_t* t_prev = tk + (size_t)(k - 1) * Bt;
@@ -519,8 +564,8 @@ int msm_run(cq_ctx* ctx, const Fr* const* scalars_host_ptrs, const G1Affine* con
     msm_combine_kernel<<<(uint32_t)((L.tmax[k] + 3) / 4), 256, 0, s>>>(part[(k - 1) & 1], t_prev, off_prev, t_cur, off_cur, Bt,
                                                                        part[k & 1], buckets);
   }
-  msm_group_reduce_kernel<<<dim3(L.G, batch * W), MSM_RED_THREADS, 0, s>>>(buckets, M, L.Mg, pairs);
-  msm_window_final_kernel<<<batch * W, MSM_RED_THREADS, 0, s>>>(pairs, L.G, L.Mg, window_sums_dev);
+  msm_group_reduce_kernel<<<dim3(L.G, batch * L.Wb), MSM_RED_THREADS, 0, s>>>(buckets, M, L.Mg, pairs);
+  msm_window_final_kernel<<<batch * L.Wb, MSM_RED_THREADS, 0, s>>>(pairs, L.G, L.Mg, window_sums_dev);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

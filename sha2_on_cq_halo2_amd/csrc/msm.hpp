@@ -15,28 +15,35 @@ constexpr uint32_t MSM_RED_THREADS = 256;
 #endif
 constexpr uint32_t MSM_S1 = CQ_MSM_S1;  // max point indices summed by one lane (level 1)
 constexpr uint32_t MSM_S2 = 256;        // max partial sums summed by one wave (levels >= 2)
-constexpr uint32_t MSM_SHORT = 8;        // level >= 2 lists up to this long are summed by one lane
+constexpr uint32_t MSM_SHORT = 64;       // level >= 2 lists up to this long are summed by one lane
 constexpr uint32_t MSM_RED_GROUP = 1024; // buckets folded by one reduce workgroup (4 per lane)
 constexpr uint32_t MSM_MAX_BATCH = 16;  // MSMs per launch
 
 struct MsmPtrs {
   const void* p[MSM_MAX_BATCH];
 };
+struct MsmStrides {
+  uint64_t s[MSM_MAX_BATCH];
+};
 
 // Workspace carve-up for `batch` MSMs of n terms each with c-bit signed windows.
 struct MsmLayout {
-  uint32_t n, c, batch, W, M, B, Bt, levels, nseq, nblk, Mg, G;
+  uint32_t n, c, batch, W, Wb, M, B, Bt, levels, nseq, nblk, Mg, G;
+  bool pre;
   uint64_t tmax[8];
   size_t off_ptrs, off_digits, off_counts, off_cursor, off_buckets, zero_end, off_blocksums, off_off, off_tk,
       off_sorted, off_part[2], off_pairs, total;
-  MsmLayout(uint32_t n_, uint32_t c_, uint32_t batch_);
+  MsmLayout(uint32_t n_, uint32_t c_, uint32_t batch_, bool pre_ = false);
 };
 
 uint32_t msm_window_bits(uint32_t n);
 // Enqueues the whole pipeline on ctx->stream.
 // `scalars` / `bases`: HOST arrays of `batch` device pointers; window_sums_dev receives batch*W points.
+// `pre`: every bases[j] points to a precomputed table [W][table_stride] with table[w][i] = 2^(c*w)*base[i]
+// (msm_precompute_tables); then window_sums_dev receives ONE point per MSM (the result itself).
 int msm_run(cq_ctx* ctx, const Fr* const* scalars, const G1Affine* const* bases, uint32_t n, uint32_t c,
-            uint32_t batch, void* workspace, G1Jac* window_sums_dev);
+            uint32_t batch, bool pre, const size_t* table_strides, void* workspace, G1Jac* window_sums_dev);
+int msm_precompute_tables(cq_ctx* ctx, const G1Affine* bases, uint32_t n, uint32_t c, G1Affine* table);
 // Host: sum_w 2^(c*w) * window_sums[w].
 G1Jac msm_fold_windows(const G1Jac* window_sums, uint32_t W, uint32_t c);
 
@@ -46,3 +53,6 @@ G1Jac msm_fold_windows(const G1Jac* window_sums, uint32_t W, uint32_t c);
 // (count x 12 limbs); one stream synchronisation per launch batch.
 int cq_msm_multi(cq_ctx* c, const cq::Fr* const* scalars, const cq::G1Affine* const* bases, size_t len, size_t count,
                  uint64_t* out_jac);
+
+int msm_register_tables(cq_ctx* c, const cq::G1Affine* bases, size_t n);
+void msm_unregister_tables(cq_ctx* c, const void* bases);

@@ -113,3 +113,29 @@ def test_msm_skewed_scalars_multilevel(ctx, kind):
     finally:
         ctx.set_msm_window(0)
     _check(ctx, sc, pts)
+
+
+@pytest.mark.parametrize("n,kind", [(700, "uniform"), (5000, "uniform"), (5000, "bits"), (40000, "uniform")])
+def test_msm_precomputed_tables_same_result(ctx, n, kind):
+    """Fixed-base mode (per-window tables, one bucket set) returns the same point as the plain
+    pipeline and as the oracle; also on a prefix of the registered array."""
+    from oracle import cbind as OC
+
+    pts = B.points_to_mont_limbs(random_points(min(n, 2048), 91))
+    pts = np.tile(pts, ((n + 2047) // 2048, 1))[:n]
+    rng = B.Xoshiro256ss(92)
+    if kind == "bits":
+        sc = B.to_mont_limbs([rng.next_u64() & 1 for _ in range(n)])
+    else:
+        rs = np.random.RandomState(n)
+        sc = rs.randint(0, 2**63, size=(n, 4), dtype=np.int64).astype(np.uint64)
+        sc[:, 3] &= np.uint64((1 << 60) - 1)
+    dsc, dpts = ctx.to_device(sc), ctx.to_device(pts)
+    plain = OC.g1_to_affine(ctx.best_multiexp_dev(dsc, dpts, n))
+    exp = OC.g1_to_affine(OC.best_multiexp(sc, pts))
+    assert np.array_equal(plain, exp)
+    ctx.msm_precompute(dpts.ptr, n)
+    pre = OC.g1_to_affine(ctx.best_multiexp_dev(dsc, dpts, n))
+    assert np.array_equal(pre, exp)
+    m = n - 7
+    assert np.array_equal(OC.g1_to_affine(ctx.best_multiexp_dev(dsc, dpts, m)), OC.g1_to_affine(OC.best_multiexp(sc[:m], pts[:m])))
