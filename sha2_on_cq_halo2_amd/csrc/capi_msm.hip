@@ -1,4 +1,5 @@
 // C ABI: best_multiexp and ParamsKZG::commit / commit_lagrange.  See include/cq_halo2.h.
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -14,37 +15,43 @@ static uint32_t pick_c(cq_ctx* c, uint32_t n) {
   return msm_window_bits(n);
 }
 
-// Runs `count` MSMs of equal length (each with its own base array); results to host Jacobians.
+// Runs `count` MSMs (each with its own base array and length); results to host Jacobians.
 // Base arrays registered with cq_msm_precompute use their per-window tables (one bucket set per MSM,
-// no window folding on the host); MSMs are grouped so that one launch uses one mode.
-int cq_msm_multi(cq_ctx* c, const Fr* const* scalars, const G1Affine* const* bases, size_t len, size_t count,
-                 uint64_t* out_jac) {
-  if (len > 0x7fffffffull) return c->fail(CQ_ERR_ARG, "msm: len too large");
-  const uint32_t n = (uint32_t)len;
-  if (n == 0 || count == 0) {
-    memset(out_jac, 0, count * 12 * sizeof(uint64_t));
-    return CQ_OK;
-  }
+// no window folding on the host) and may share a launch whatever their lengths; plain MSMs are
+// grouped by equal length.
+int cq_msm_multi_v(cq_ctx* c, const Fr* const* scalars, const G1Affine* const* bases, const size_t* lens, size_t count,
+                   uint64_t* out_jac) {
+  for (size_t j = 0; j < count; j++)
+    if (lens[j] > 0x7fffffffull) return c->fail(CQ_ERR_ARG, "msm: len too large");
   size_t done = 0;
   while (done < count) {
-    // maximal run of MSMs with the same mode / table geometry
-    const cq_ctx::MsmTable* t0 = c->find_msm_table(bases[done], len);
+    if (lens[done] == 0) {
+      memset(out_jac + done * 12, 0, 12 * sizeof(uint64_t));
+      done++;
+      continue;
+    }
+    const cq_ctx::MsmTable* t0 = c->find_msm_table(bases[done], lens[done]);
     const bool pre = t0 != nullptr;
-    const uint32_t cb = pre ? t0->c : pick_c(c, n);
+    uint32_t nmax = (uint32_t)lens[done];
     uint32_t batch = 1;
     while (done + batch < count && batch < MSM_MAX_BATCH) {
-      const cq_ctx::MsmTable* t = c->find_msm_table(bases[done + batch], len);
+      const size_t l = lens[done + batch];
+      if (l == 0) break;
+      const cq_ctx::MsmTable* t = c->find_msm_table(bases[done + batch], l);
       if ((t != nullptr) != pre) break;
-      if (pre && t->c != cb) break;
+      if (pre && t->c != t0->c) break;
+      if (!pre && l != lens[done]) break;
+      nmax = std::max(nmax, (uint32_t)l);
       batch++;
     }
+    const uint32_t cb = pre ? t0->c : pick_c(c, nmax);
     // keep the workspace below ~8 GiB
-    while (batch > 1 && MsmLayout(n, cb, batch, pre).total > ((size_t)8 << 30)) batch = (batch + 1) / 2;
-    MsmLayout L(n, cb, batch, pre);
+    while (batch > 1 && MsmLayout(nmax, cb, batch, pre).total > ((size_t)8 << 30)) batch = (batch + 1) / 2;
+    MsmLayout L(nmax, cb, batch, pre);
     std::vector<const G1Affine*> bp(batch);
     std::vector<size_t> strides(batch, 0);
     for (uint32_t j = 0; j < batch; j++) {
-      const cq_ctx::MsmTable* t = pre ? c->find_msm_table(bases[done + j], len) : nullptr;
+      const cq_ctx::MsmTable* t = pre ? c->find_msm_table(bases[done + j], lens[done + j]) : nullptr;
       bp[j] = pre ? (const G1Affine*)t->table : bases[done + j];
       strides[j] = pre ? t->n : 0;
     }
@@ -53,7 +60,7 @@ int cq_msm_multi(cq_ctx* c, const Fr* const* scalars, const G1Affine* const* bas
     if ((rc = c->ensure_scratch(3, L.total, &ws)) != CQ_OK) return rc;
     if ((rc = c->ensure_scratch(4, (size_t)batch * L.Wb * sizeof(G1Jac), &wsums)) != CQ_OK) return rc;
     if ((rc = c->ensure_pinned((size_t)batch * L.Wb * sizeof(G1Jac), &host)) != CQ_OK) return rc;
-    int r = msm_run(c, scalars + done, bp.data(), n, cb, batch, pre, strides.data(), ws, (G1Jac*)wsums);
+    int r = msm_run(c, scalars + done, bp.data(), lens + done, nmax, cb, batch, pre, strides.data(), ws, (G1Jac*)wsums);
     if (r != 0) return c->fail(CQ_ERR_HIP, "msm launch failed");
     CQ_HIP(c, hipMemcpyAsync(host, wsums, (size_t)batch * L.Wb * sizeof(G1Jac), hipMemcpyDeviceToHost, c->stream));
     CQ_HIP(c, hipStreamSynchronize(c->stream));
@@ -67,6 +74,12 @@ int cq_msm_multi(cq_ctx* c, const Fr* const* scalars, const G1Affine* const* bas
     done += batch;
   }
   return CQ_OK;
+}
+
+int cq_msm_multi(cq_ctx* c, const Fr* const* scalars, const G1Affine* const* bases, size_t len, size_t count,
+                 uint64_t* out_jac) {
+  std::vector<size_t> lens(count, len);
+  return cq_msm_multi_v(c, scalars, bases, lens.data(), count, out_jac);
 }
 
 void msm_unregister_tables(cq_ctx* c, const void* bases) {
@@ -83,9 +96,8 @@ void msm_unregister_tables(cq_ctx* c, const void* bases) {
 int msm_register_tables(cq_ctx* c, const G1Affine* bases, size_t n) {
   if (!bases || n == 0 || n > (1u << 26)) return CQ_OK;  // nothing to do / unsupported: plain mode
   if (c->find_msm_table(bases, n)) return CQ_OK;
-  const uint32_t cb = pick_c(c, (uint32_t)n);
+  const uint32_t cb = MSM_TABLE_C;
   const uint32_t W = (255 + cb - 1) / cb;
-  if (W > 32) return CQ_OK;
   void* table = nullptr;
   if (hipMalloc(&table, (size_t)W * n * sizeof(G1Affine)) != hipSuccess) {
     (void)hipGetLastError();

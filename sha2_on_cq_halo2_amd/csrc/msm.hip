@@ -62,49 +62,59 @@ static __device__ __forceinline__ uint32_t wave_atomic_inc(uint32_t* counters, u
 }
 
 // ---- pointer tables (per-MSM scalar / base arrays), written from a by-value kernel argument ------
-__global__ void msm_set_ptrs_kernel(MsmPtrs sc, MsmPtrs bs, MsmStrides st, const void** dst, uint32_t batch) {
+__global__ void msm_set_ptrs_kernel(MsmPtrs sc, MsmPtrs bs, MsmStrides st, MsmStrides ln, const void** dst, uint32_t batch) {
   const uint32_t t = threadIdx.x;
   if (t < batch) {
     dst[t] = sc.p[t];
     dst[batch + t] = bs.p[t];
     ((uint64_t*)(dst + 2 * batch))[t] = st.s[t];
+    ((uint64_t*)(dst + 3 * batch))[t] = ln.s[t];
   }
 }
 
 // ---- 1. digits + histogram -------------------------------------------------------------------
-__global__ __launch_bounds__(256) void msm_digits_kernel(const Fr* const* __restrict__ scalars, uint32_t n, uint32_t c,
-                                                         uint32_t nwin, uint32_t pre, uint16_t* __restrict__ digits,
-                                                         uint32_t* __restrict__ counts) {
+// signed c-bit digit of window w of the canonical scalar v, with the running carry
+static __device__ __forceinline__ uint32_t signed_digit(const U256& v, uint32_t w, uint32_t c, uint32_t& carry, uint32_t& neg) {
+  const uint32_t M = 1u << (c - 1);
+  const uint32_t bitpos = w * c;
+  const uint32_t word = bitpos >> 5, sh = bitpos & 31;
+  uint32_t raw = 0;
+  if (word < 8) {
+    uint64_t two = v.l[word];
+    if (word + 1 < 8) two |= (uint64_t)v.l[word + 1] << 32;
+    raw = (uint32_t)(two >> sh) & ((1u << c) - 1);
+  }
+  uint32_t d = raw + carry;
+  neg = 0;
+  carry = 0;
+  if (d > M) {
+    d = (1u << c) - d;
+    neg = 1;
+    carry = 1;
+  }
+  return d;
+}
+
+// One lane per scalar: every window's digit bumps the histogram; the value the atomic returns is the
+// entry's rank inside its bucket, kept for the scatter pass (so the sort needs one atomic per entry).
+__global__ __launch_bounds__(256) void msm_digits_kernel(const Fr* const* __restrict__ scalars, const uint64_t* __restrict__ lens,
+                                                         uint32_t nmax, uint32_t c, uint32_t nwin, uint32_t pre,
+                                                         uint32_t* __restrict__ ranks, uint32_t* __restrict__ counts) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t m = blockIdx.y;
-  const bool live = i < n;
+  const bool live = i < (uint32_t)lens[m];
   U256 v;
   if (live) v = scalars[m][i].to_canonical();
   else for (int k = 0; k < 8; k++) v.l[k] = 0;
   const uint32_t M = 1u << (c - 1);
-  const uint32_t mask = (1u << c) - 1;
-  uint32_t carry = 0;
+  uint32_t carry = 0, neg;
   for (uint32_t w = 0; w < nwin; w++) {
-    const uint32_t bitpos = w * c;
-    const uint32_t word = bitpos >> 5, sh = bitpos & 31;
-    uint32_t raw = 0;
-    if (word < 8) {
-      uint64_t two = v.l[word];
-      if (word + 1 < 8) two |= (uint64_t)v.l[word + 1] << 32;
-      raw = (uint32_t)(two >> sh) & mask;
-    }
-    uint32_t d = raw + carry;
-    uint32_t neg = 0;
-    carry = 0;
-    if (d > M) {
-      d = (1u << c) - d;
-      neg = 1;
-      carry = 1;
-    }
+    const uint32_t d = signed_digit(v, w, c, carry, neg);
     const size_t mw = (size_t)m * nwin + w;
-    if (live) digits[mw * n + i] = (uint16_t)(d | (neg << 15));
     // precomputed-table mode folds every window into one bucket set per MSM
-    wave_atomic_inc(counts, (uint32_t)((pre ? (size_t)m : mw) * M) + (d - 1), live && d != 0);
+    const bool act = live && d != 0;
+    const uint32_t rank = wave_atomic_inc(counts, (uint32_t)((pre ? (size_t)m : mw) * M) + (d - 1), act);
+    if (act) ranks[mw * nmax + i] = rank;
   }
 }
 
@@ -214,20 +224,25 @@ __global__ __launch_bounds__(256) void msm_scan_apply_kernel(const uint32_t* __r
 }
 
 // ---- 3. scatter (counting sort) ----------------------------------------------------------------
-__global__ __launch_bounds__(256) void msm_scatter_kernel(const uint16_t* __restrict__ digits, uint32_t n, uint32_t M,
-                                                          uint32_t nwin, uint32_t pre, const uint32_t* __restrict__ off0,
-                                                          uint32_t* __restrict__ cursor, uint32_t* __restrict__ sorted) {
+// Recomputes the digits (cheaper than storing them) and drops every entry at list start + rank.
+__global__ __launch_bounds__(256) void msm_scatter_kernel(const Fr* const* __restrict__ scalars, const uint64_t* __restrict__ lens,
+                                                          uint32_t nmax, uint32_t c, uint32_t nwin, uint32_t pre,
+                                                          const uint32_t* __restrict__ ranks, const uint32_t* __restrict__ off0,
+                                                          uint32_t* __restrict__ sorted) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  const uint32_t mw = blockIdx.y;  // msm * W + window
-  const bool live = i < n;
-  const uint16_t dg = live ? digits[(size_t)mw * n + i] : (uint16_t)0;
-  const uint32_t d = dg & 0x7fffu;
-  const uint32_t w = mw % nwin;
-  const uint32_t g = (pre ? mw / nwin : mw) * M + (d - 1);
-  const bool act = live && d != 0;
-  const uint32_t rank = wave_atomic_inc(cursor, g, act);
-  // entry: point index (26 bits) | window << 26 (precomputed-table mode) | sign << 31
-  if (act) sorted[off0[g] + rank] = i | (pre ? (w << 26) : 0u) | ((uint32_t)(dg >> 15) << 31);
+  const uint32_t m = blockIdx.y;
+  if (i >= (uint32_t)lens[m]) return;
+  const U256 v = scalars[m][i].to_canonical();
+  const uint32_t M = 1u << (c - 1);
+  uint32_t carry = 0, neg;
+  for (uint32_t w = 0; w < nwin; w++) {
+    const uint32_t d = signed_digit(v, w, c, carry, neg);
+    if (!d) continue;
+    const size_t mw = (size_t)m * nwin + w;
+    const uint32_t g = (uint32_t)((pre ? (size_t)m : mw) * M) + (d - 1);
+    // entry: point index (26 bits) | window << 26 (precomputed-table mode) | sign << 31
+    sorted[off0[g] + ranks[mw * nmax + i]] = i | (pre ? (w << 26) : 0u) | (neg << 31);
+  }
 }
 
 // ---- 4. bucket accumulation ----------------------------------------------------------------
@@ -486,10 +501,9 @@ MsmLayout::MsmLayout(uint32_t n_, uint32_t c_, uint32_t batch_, bool pre_) : n(n
   auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
   const uint64_t E = (uint64_t)batch * W * n;  // upper bound on (point,digit) entries
   size_t o = 0;
-  off_ptrs = o;    o = up(o + (size_t)3 * batch * sizeof(void*));
-  off_digits = o;  o = up(o + (size_t)E * sizeof(uint16_t));
+  off_ptrs = o;    o = up(o + (size_t)4 * batch * sizeof(void*));
+  off_ranks = o;   o = up(o + (size_t)E * sizeof(uint32_t));
   off_counts = o;  o = up(o + (size_t)Bt * sizeof(uint32_t));
-  off_cursor = o;  o = up(o + (size_t)Bt * sizeof(uint32_t));
   off_buckets = o; o = up(o + (size_t)Bt * sizeof(XYZZ));  // counts..buckets zeroed by one memset
   zero_end = o;
   off_blocksums = o; o = up(o + (size_t)nseq * nblk * sizeof(uint32_t));
@@ -511,8 +525,9 @@ MsmLayout::MsmLayout(uint32_t n_, uint32_t c_, uint32_t batch_, bool pre_) : n(n
   total = o;
 }
 
-int msm_run(cq_ctx* ctx, const Fr* const* scalars_host_ptrs, const G1Affine* const* bases_host_ptrs, uint32_t n,
-            uint32_t c, uint32_t batch, bool pre, const size_t* table_strides, void* workspace, G1Jac* window_sums_dev) {
+int msm_run(cq_ctx* ctx, const Fr* const* scalars_host_ptrs, const G1Affine* const* bases_host_ptrs, const size_t* lens,
+            uint32_t n, uint32_t c, uint32_t batch, bool pre, const size_t* table_strides, void* workspace,
+            G1Jac* window_sums_dev) {
   hipStream_t s = ctx->stream;
   MsmLayout L(n, c, batch, pre);
   if (pre && (n > (1u << 26) || L.W > 32)) return -4;
@@ -520,9 +535,8 @@ int msm_run(cq_ctx* ctx, const Fr* const* scalars_host_ptrs, const G1Affine* con
   char* ws = (char*)workspace;
   const Fr** d_scalars = (const Fr**)(ws + L.off_ptrs);
   const G1Affine** d_bases = (const G1Affine**)(ws + L.off_ptrs) + batch;
-  uint16_t* digits = (uint16_t*)(ws + L.off_digits);
+  uint32_t* ranks = (uint32_t*)(ws + L.off_ranks);
   uint32_t* counts = (uint32_t*)(ws + L.off_counts);
-  uint32_t* cursor = (uint32_t*)(ws + L.off_cursor);
   XYZZ* buckets = (XYZZ*)(ws + L.off_buckets);
   uint32_t* blocksums = (uint32_t*)(ws + L.off_blocksums);
   uint32_t* off = (uint32_t*)(ws + L.off_off);
@@ -533,22 +547,24 @@ int msm_run(cq_ctx* ctx, const Fr* const* scalars_host_ptrs, const G1Affine* con
   const uint32_t M = L.M, W = L.W, Bt = L.Bt;
   if (batch == 0 || batch > MSM_MAX_BATCH) return -2;
   MsmPtrs sp, bp;
-  MsmStrides stv;
+  MsmStrides stv, lnv;
   for (uint32_t i = 0; i < MSM_MAX_BATCH; i++) {
     sp.p[i] = i < batch ? (const void*)scalars_host_ptrs[i] : nullptr;
     bp.p[i] = i < batch ? (const void*)bases_host_ptrs[i] : nullptr;
     stv.s[i] = (i < batch && pre) ? (uint64_t)table_strides[i] : 0;
+    lnv.s[i] = i < batch ? (uint64_t)lens[i] : 0;
   }
-  msm_set_ptrs_kernel<<<1, 64, 0, s>>>(sp, bp, stv, (const void**)d_scalars, batch);
+  msm_set_ptrs_kernel<<<1, 64, 0, s>>>(sp, bp, stv, lnv, (const void**)d_scalars, batch);
   const uint64_t* d_strides = (const uint64_t*)((const void**)d_scalars + 2 * batch);
-  // counts, cursor and buckets (identity = all zero) are adjacent: one memset
+  const uint64_t* d_lens = (const uint64_t*)((const void**)d_scalars + 3 * batch);
+  // counts and buckets (identity = all zero) are adjacent: one memset
   if (hipMemsetAsync(counts, 0, L.zero_end - L.off_counts, s) != hipSuccess) return -1;
-  msm_digits_kernel<<<dim3((n + 255) / 256, batch), 256, 0, s>>>(d_scalars, n, c, W, pre ? 1u : 0u, digits, counts);
+  msm_digits_kernel<<<dim3((n + 255) / 256, batch), 256, 0, s>>>(d_scalars, d_lens, n, c, W, pre ? 1u : 0u, ranks, counts);
   msm_scan_reduce_kernel<<<L.nblk, 256, 0, s>>>(counts, Bt, L.nseq, blocksums);
   msm_scan_spine_kernel<<<1, 1024, 0, s>>>(blocksums, L.nblk, L.nseq);
   msm_scan_apply_kernel<<<L.nblk, 256, 0, s>>>(counts, Bt, L.nseq, blocksums, off, tk);
   const uint32_t* off0 = off;
-  msm_scatter_kernel<<<dim3((n + 255) / 256, batch * W), 256, 0, s>>>(digits, n, M, W, pre ? 1u : 0u, off0, cursor, sorted);
+  msm_scatter_kernel<<<dim3((n + 255) / 256, batch), 256, 0, s>>>(d_scalars, d_lens, n, c, W, pre ? 1u : 0u, ranks, off0, sorted);
   hipEvent_t pe = ctx->prof_begin(CQ_PROF_MSM_ACCUMULATE);
   msm_accumulate_kernel<<<(uint32_t)((L.tmax[0] + MSM_ACC_THREADS - 1) / MSM_ACC_THREADS), MSM_ACC_THREADS, 0, s>>>(
       d_bases, L.B, pre ? 1u : 0u, d_strides, sorted, counts, off0, tk, off + (size_t)(Bt + 1), Bt, part[0], buckets);

@@ -31,7 +31,7 @@ struct MsmLayout {
   uint32_t n, c, batch, W, Wb, M, B, Bt, levels, nseq, nblk, Mg, G;
   bool pre;
   uint64_t tmax[8];
-  size_t off_ptrs, off_digits, off_counts, off_cursor, off_buckets, zero_end, off_blocksums, off_off, off_tk,
+  size_t off_ptrs, off_ranks, off_counts, off_buckets, zero_end, off_blocksums, off_off, off_tk,
       off_sorted, off_part[2], off_pairs, total;
   MsmLayout(uint32_t n_, uint32_t c_, uint32_t batch_, bool pre_ = false);
 };
@@ -41,7 +41,8 @@ uint32_t msm_window_bits(uint32_t n);
 // `scalars` / `bases`: HOST arrays of `batch` device pointers; window_sums_dev receives batch*W points.
 // `pre`: every bases[j] points to a precomputed table [W][table_stride] with table[w][i] = 2^(c*w)*base[i]
 // (msm_precompute_tables); then window_sums_dev receives ONE point per MSM (the result itself).
-int msm_run(cq_ctx* ctx, const Fr* const* scalars, const G1Affine* const* bases, uint32_t n, uint32_t c,
+// lens[j] <= n: per-MSM lengths (one launch may mix lengths; n is the maximum)
+int msm_run(cq_ctx* ctx, const Fr* const* scalars, const G1Affine* const* bases, const size_t* lens, uint32_t n, uint32_t c,
             uint32_t batch, bool pre, const size_t* table_strides, void* workspace, G1Jac* window_sums_dev);
 int msm_precompute_tables(cq_ctx* ctx, const G1Affine* bases, uint32_t n, uint32_t c, G1Affine* table);
 // Host: sum_w 2^(c*w) * window_sums[w].
@@ -53,6 +54,10 @@ G1Jac msm_fold_windows(const G1Jac* window_sums, uint32_t W, uint32_t c);
 // (count x 12 limbs); one stream synchronisation per launch batch.
 int cq_msm_multi(cq_ctx* c, const cq::Fr* const* scalars, const cq::G1Affine* const* bases, size_t len, size_t count,
                  uint64_t* out_jac);
+// per-MSM lengths; MSMs over registered (precomputed) bases of any length share launches
+int cq_msm_multi_v(cq_ctx* c, const cq::Fr* const* scalars, const cq::G1Affine* const* bases, const size_t* lens, size_t count,
+                   uint64_t* out_jac);
+constexpr uint32_t MSM_TABLE_C = 15;  // window width of every precomputed table (so launches can mix lengths)
 
 int msm_register_tables(cq_ctx* c, const cq::G1Affine* bases, size_t n);
 void msm_unregister_tables(cq_ctx* c, const void* bases);

@@ -112,15 +112,21 @@ struct Rng {
 };
 
 // msms over device scalars; one host sync; results normalised
-int commit_batch(cq_ctx* c, const std::vector<const Fr*>& scalars, const std::vector<const G1Affine*>& bases, size_t len,
-                 std::vector<G1Affine>& out) {
+int commit_batch_v(cq_ctx* c, const std::vector<const Fr*>& scalars, const std::vector<const G1Affine*>& bases,
+                   const std::vector<size_t>& lens, std::vector<G1Affine>& out) {
   std::vector<uint64_t> jac(scalars.size() * 12);
-  int rc = cq_msm_multi(c, scalars.data(), bases.data(), len, scalars.size(), jac.data());
+  int rc = cq_msm_multi_v(c, scalars.data(), bases.data(), lens.data(), scalars.size(), jac.data());
   if (rc != CQ_OK) return rc;
   std::vector<G1Jac> j(scalars.size());
   for (size_t i = 0; i < scalars.size(); i++) j[i] = jac_from_limbs(jac.data() + 12 * i);
   batch_normalize(j, out);
   return CQ_OK;
+}
+
+int commit_batch(cq_ctx* c, const std::vector<const Fr*>& scalars, const std::vector<const G1Affine*>& bases, size_t len,
+                 std::vector<G1Affine>& out) {
+  std::vector<size_t> lens(scalars.size(), len);
+  return commit_batch_v(c, scalars, bases, lens, out);
 }
 
 }  // namespace
@@ -212,6 +218,15 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, cq_rng_next_u
     for (size_t a = 0; a < A; a++)
       CQ_HIP(c, hipMemcpyAsync(adv + a * n + u, (Fr*)pin + a * (n - u), (n - u) * sizeof(Fr), hipMemcpyHostToDevice, s));
     CQ_HIP(c, hipStreamSynchronize(s));  // pinned buffer is reused below
+    // The next draws from the RNG are the vanishing argument's n coefficients + 1 blind
+    // (vanishing/prover.rs:51-55): the CQ rounds in between draw nothing, so taking them now keeps the
+    // stream order and lets the random polynomial's commitment ride along with round 2's launch.
+    uint64_t* w = (uint64_t*)pin;
+    for (size_t i = 0; i < n; i++) rng.words(w + 8 * i);
+    (void)rng.fr();  // random_blind
+    CQ_HIP(c, hipMemcpyAsync(rng_dev, pin, (size_t)64 * n, hipMemcpyHostToDevice, s));
+    CQ_TRY(poly_from_u512(c, rng_dev, (uint32_t)n, random_poly));
+    CQ_HIP(c, hipStreamSynchronize(s));
   }
   // commit_lagrange per column (:356-360), batch_normalize (:363-366), write (:370-374)
   std::vector<G1Affine> pts;
@@ -261,17 +276,17 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, cq_rng_next_u
     if (herr == 2) return c->fail(CQ_ERR_LOOKUP, "Vector lookup must be on the same table row");
   }
   if (L) {
-    std::vector<const Fr*> sc(L);
-    std::vector<const G1Affine*> bs(L, pk->params->g_lagrange);
-    std::vector<G1Affine> fcm, mcm;
-    for (size_t l = 0; l < L; l++) sc[l] = f_lag + l * n;
-    CQ_TRY(commit_batch(c, sc, bs, n, fcm));  // f_cm (:165)
-    std::vector<const G1Affine*> bt(L, pk->table_cfg->g1_lagrange);
-    for (size_t l = 0; l < L; l++) sc[l] = m_fr + l * N;
-    CQ_TRY(commit_batch(c, sc, bt, N, mcm));  // m_cm (:167-172) as a dense MSM over the table SRS
+    // f_cm (:165) and m_cm (:167-172, as a dense MSM over the table SRS): one launch
+    std::vector<const Fr*> sc;
+    std::vector<const G1Affine*> bs;
+    std::vector<size_t> ln;
+    for (size_t l = 0; l < L; l++) { sc.push_back(f_lag + l * n); bs.push_back(pk->params->g_lagrange); ln.push_back(n); }
+    for (size_t l = 0; l < L; l++) { sc.push_back(m_fr + l * N); bs.push_back(pk->table_cfg->g1_lagrange); ln.push_back(N); }
+    std::vector<G1Affine> cm;
+    CQ_TRY(commit_batch_v(c, sc, bs, ln, cm));
     for (size_t l = 0; l < L; l++) {
-      if (!tr.write_point(fcm[l])) return c->fail(CQ_ERR_TRANSCRIPT, "f commitment is the identity");
-      if (!tr.write_point(mcm[l])) return c->fail(CQ_ERR_TRANSCRIPT, "m commitment is the identity");
+      if (!tr.write_point(cm[l])) return c->fail(CQ_ERR_TRANSCRIPT, "f commitment is the identity");
+      if (!tr.write_point(cm[L + l])) return c->fail(CQ_ERR_TRANSCRIPT, "m commitment is the identity");
     }
   }
   const Fr beta = tr.squeeze();   // prover.rs:529
@@ -280,6 +295,7 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, cq_rng_next_u
 
   // ---- CQ round 2 (static_lookup/prover.rs:187-342) -------------------------------------------------
   std::vector<Fr> a_at_zero(L);
+  G1Affine random_cm = G1Affine::identity();
   {
     size_t woff = 0;
     for (size_t l = 0; l < L; l++) {
@@ -327,43 +343,31 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, cq_rng_next_u
       CQ_TRY(domain_lagrange_to_coeff(dom, f_lag, f_coeff, (uint32_t)L, n, n));  // :326-334
     }
     // commitments: a, a0 (dense over the table SRS), q_a (over [qs_0|qs_1|...]), p, b0 (n-1 terms of b[1..])
-    std::vector<G1Affine> a_pts, qa_pts(L), pb_pts;
-    if (L) {
+    // and the vanishing argument's random polynomial (vanishing/prover.rs:58) in one batch of launches
+    std::vector<G1Affine> r2;
+    {
       std::vector<const Fr*> sc;
       std::vector<const G1Affine*> bs;
-      for (size_t l = 0; l < L; l++) {
-        sc.push_back(a_val + l * N);
-        bs.push_back(pk->table_cfg->g1_lagrange);
-        sc.push_back(a_val + l * N);
-        bs.push_back(pk->table_cfg->g_lagrange_opening_at_0);
-      }
-      CQ_TRY(commit_batch(c, sc, bs, N, a_pts));
+      std::vector<size_t> ln;
       woff = 0;
       for (size_t l = 0; l < L; l++) {
         const uint32_t w = (uint32_t)pk->lookups[l].cols.size();
-        std::vector<const Fr*> s1{a_scaled + woff * N};
-        std::vector<const G1Affine*> b1{pk->qs_concat[l]};
-        std::vector<G1Affine> o;
-        CQ_TRY(commit_batch(c, s1, b1, (size_t)w * N, o));
-        qa_pts[l] = o[0];
+        sc.push_back(a_val + l * N); bs.push_back(pk->table_cfg->g1_lagrange); ln.push_back(N);             // a
+        sc.push_back(a_scaled + woff * N); bs.push_back(pk->qs_concat[l]); ln.push_back((size_t)w * N);      // q_a
+        sc.push_back(a_val + l * N); bs.push_back(pk->table_cfg->g_lagrange_opening_at_0); ln.push_back(N);  // a0
+        sc.push_back(bpoly + l * n + 1); bs.push_back(pk->params->g); ln.push_back(n - 1);                   // b0 (:310)
+        sc.push_back(bpoly + l * n + 1); bs.push_back(pk->b0_g1_bound); ln.push_back(n - 1);                 // p (:299)
         woff += w;
       }
-      sc.clear();
-      bs.clear();
-      for (size_t l = 0; l < L; l++) {
-        sc.push_back(bpoly + l * n + 1);  // b0 = (b - b(0))/X : coefficients shifted down (:279)
-        bs.push_back(pk->b0_g1_bound);    // p_cm (:299)
-        sc.push_back(bpoly + l * n + 1);
-        bs.push_back(pk->params->g);       // b0_cm (:310); the padded top coefficient is zero
-      }
-      CQ_TRY(commit_batch(c, sc, bs, n - 1, pb_pts));
+      sc.push_back(random_poly); bs.push_back(pk->params->g); ln.push_back(n);
+      CQ_TRY(commit_batch_v(c, sc, bs, ln, r2));
     }
     for (size_t l = 0; l < L; l++) {
       // write order :306-313: a, q_a, a0, b0, p
-      if (!tr.write_point(a_pts[2 * l]) || !tr.write_point(qa_pts[l]) || !tr.write_point(a_pts[2 * l + 1]) ||
-          !tr.write_point(pb_pts[2 * l + 1]) || !tr.write_point(pb_pts[2 * l]))
-        return c->fail(CQ_ERR_TRANSCRIPT, "a CQ round-2 commitment is the identity");
+      for (size_t q = 0; q < 5; q++)
+        if (!tr.write_point(r2[5 * l + q])) return c->fail(CQ_ERR_TRANSCRIPT, "a CQ round-2 commitment is the identity");
     }
+    random_cm = r2[5 * L];
     // a(0) = (n*b(0) - (bf+1)/beta) / N   (:318-324)
     if (L) {
       std::vector<Fr> b0(L);
@@ -376,21 +380,8 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, cq_rng_next_u
     }
   }
 
-  // ---- vanishing::Argument::commit (vanishing/prover.rs:37-65) -------------------------------------
-  {
-    void* pin;
-    CQ_TRY(c->ensure_pinned((size_t)64 * n, &pin));
-    uint64_t* w = (uint64_t*)pin;
-    for (size_t i = 0; i < n; i++) rng.words(w + 8 * i);
-    (void)rng.fr();  // random_blind
-    CQ_HIP(c, hipMemcpyAsync(rng_dev, pin, (size_t)64 * n, hipMemcpyHostToDevice, s));
-    CQ_TRY(poly_from_u512(c, rng_dev, (uint32_t)n, random_poly));
-    std::vector<const Fr*> sc{random_poly};
-    std::vector<const G1Affine*> bs{pk->params->g};
-    std::vector<G1Affine> o;
-    CQ_TRY(commit_batch(c, sc, bs, n, o));
-    if (!tr.write_point(o[0])) return c->fail(CQ_ERR_TRANSCRIPT, "random poly commitment is the identity");
-  }
+  // ---- vanishing::Argument::commit (vanishing/prover.rs:37-65): drawn and committed above ---------
+  if (!tr.write_point(random_cm)) return c->fail(CQ_ERR_TRANSCRIPT, "random poly commitment is the identity");
   const Fr y = tr.squeeze();  // prover.rs:584
 
   // advice polys: lagrange_to_coeff (:587-603), in place
