@@ -54,6 +54,7 @@ void cq_ctx_destroy(cq_ctx* c) {
   for (int i = 0; i < cq_ctx::NSCRATCH; i++)
     if (c->scratch[i]) hipFree(c->scratch[i]);
   if (c->pinned) hipHostFree(c->pinned);
+  if (c->pinned_msm) hipHostFree(c->pinned_msm);
   if (c->fb_table) hipFree(c->fb_table);
   for (auto& t : c->msm_tables) hipFree(t.table);
   if (c->own_stream) hipStreamDestroy(c->stream);

@@ -19,14 +19,21 @@ static uint32_t pick_c(cq_ctx* c, uint32_t n) {
 // Base arrays registered with cq_msm_precompute use their per-window tables (one bucket set per MSM,
 // no window folding on the host) and may share a launch whatever their lengths; plain MSMs are
 // grouped by equal length.
-int cq_msm_multi_v(cq_ctx* c, const Fr* const* scalars, const G1Affine* const* bases, const size_t* lens, size_t count,
-                   uint64_t* out_jac) {
+int msm_multi_begin(cq_ctx* c, const Fr* const* scalars, const G1Affine* const* bases, const size_t* lens, size_t count,
+                    MsmPending& pend) {
+  pend.launches.clear();
+  pend.count = count;
   for (size_t j = 0; j < count; j++)
     if (lens[j] > 0x7fffffffull) return c->fail(CQ_ERR_ARG, "msm: len too large");
-  size_t done = 0;
+  // first pass: plan the launches and the result slots
+  size_t done = 0, slots = 0;
   while (done < count) {
+    MsmPending::Launch ln;
+    ln.first = done;
     if (lens[done] == 0) {
-      memset(out_jac + done * 12, 0, 12 * sizeof(uint64_t));
+      ln.batch = 1;
+      ln.empty = true;
+      pend.launches.push_back(ln);
       done++;
       continue;
     }
@@ -47,33 +54,72 @@ int cq_msm_multi_v(cq_ctx* c, const Fr* const* scalars, const G1Affine* const* b
     const uint32_t cb = pre ? t0->c : pick_c(c, nmax);
     // keep the workspace below ~8 GiB
     while (batch > 1 && MsmLayout(nmax, cb, batch, pre).total > ((size_t)8 << 30)) batch = (batch + 1) / 2;
+    ln.batch = batch;
+    ln.pre = pre;
+    ln.c = cb;
+    ln.nmax = nmax;
     MsmLayout L(nmax, cb, batch, pre);
-    std::vector<const G1Affine*> bp(batch);
-    std::vector<size_t> strides(batch, 0);
-    for (uint32_t j = 0; j < batch; j++) {
-      const cq_ctx::MsmTable* t = pre ? c->find_msm_table(bases[done + j], lens[done + j]) : nullptr;
-      bp[j] = pre ? (const G1Affine*)t->table : bases[done + j];
-      strides[j] = pre ? t->n : 0;
+    ln.W = L.W;
+    ln.Wb = L.Wb;
+    ln.slot = slots;
+    slots += (size_t)batch * L.Wb;
+    pend.launches.push_back(ln);
+    done += batch;
+  }
+  void *wsums = nullptr, *host = nullptr;
+  int rc;
+  if (slots) {
+    if ((rc = c->ensure_scratch(4, slots * sizeof(G1Jac), &wsums)) != CQ_OK) return rc;
+    if ((rc = c->ensure_pinned_msm(slots * sizeof(G1Jac), &host)) != CQ_OK) return rc;
+  }
+  pend.host = host;
+  pend.slots = slots;
+  for (auto& ln : pend.launches) {
+    if (ln.empty) continue;
+    MsmLayout L(ln.nmax, ln.c, ln.batch, ln.pre);
+    std::vector<const G1Affine*> bp(ln.batch);
+    std::vector<size_t> strides(ln.batch, 0);
+    for (uint32_t j = 0; j < ln.batch; j++) {
+      const cq_ctx::MsmTable* t = ln.pre ? c->find_msm_table(bases[ln.first + j], lens[ln.first + j]) : nullptr;
+      bp[j] = ln.pre ? (const G1Affine*)t->table : bases[ln.first + j];
+      strides[j] = ln.pre ? t->n : 0;
     }
-    void *ws, *wsums, *host;
-    int rc;
+    void* ws;
     if ((rc = c->ensure_scratch(3, L.total, &ws)) != CQ_OK) return rc;
-    if ((rc = c->ensure_scratch(4, (size_t)batch * L.Wb * sizeof(G1Jac), &wsums)) != CQ_OK) return rc;
-    if ((rc = c->ensure_pinned((size_t)batch * L.Wb * sizeof(G1Jac), &host)) != CQ_OK) return rc;
-    int r = msm_run(c, scalars + done, bp.data(), lens + done, nmax, cb, batch, pre, strides.data(), ws, (G1Jac*)wsums);
+    int r = msm_run(c, scalars + ln.first, bp.data(), lens + ln.first, ln.nmax, ln.c, ln.batch, ln.pre, strides.data(), ws,
+                    (G1Jac*)wsums + ln.slot);
     if (r != 0) return c->fail(CQ_ERR_HIP, "msm launch failed");
-    CQ_HIP(c, hipMemcpyAsync(host, wsums, (size_t)batch * L.Wb * sizeof(G1Jac), hipMemcpyDeviceToHost, c->stream));
-    CQ_HIP(c, hipStreamSynchronize(c->stream));
-    for (uint32_t j = 0; j < batch; j++) {
-      G1Jac r = pre ? ((const G1Jac*)host)[j] : msm_fold_windows((const G1Jac*)host + (size_t)j * L.W, L.W, cb);
-      uint64_t* o = out_jac + (done + j) * 12;
+  }
+  if (slots)
+    CQ_HIP(c, hipMemcpyAsync(host, wsums, slots * sizeof(G1Jac), hipMemcpyDeviceToHost, c->stream));
+  return CQ_OK;
+}
+
+int msm_multi_end(cq_ctx* c, MsmPending& pend, uint64_t* out_jac) {
+  CQ_HIP(c, hipStreamSynchronize(c->stream));
+  for (auto& ln : pend.launches) {
+    for (uint32_t j = 0; j < ln.batch; j++) {
+      uint64_t* o = out_jac + (ln.first + j) * 12;
+      if (ln.empty) {
+        memset(o, 0, 12 * sizeof(uint64_t));
+        continue;
+      }
+      const G1Jac* res = (const G1Jac*)pend.host + ln.slot;
+      G1Jac r = ln.pre ? res[j] : msm_fold_windows(res + (size_t)j * ln.W, ln.W, ln.c);
       r.x.to_limbs64(o);
       r.y.to_limbs64(o + 4);
       r.z.to_limbs64(o + 8);
     }
-    done += batch;
   }
   return CQ_OK;
+}
+
+int cq_msm_multi_v(cq_ctx* c, const Fr* const* scalars, const G1Affine* const* bases, const size_t* lens, size_t count,
+                   uint64_t* out_jac) {
+  MsmPending pend;
+  int rc = msm_multi_begin(c, scalars, bases, lens, count, pend);
+  if (rc != CQ_OK) return rc;
+  return msm_multi_end(c, pend, out_jac);
 }
 
 int cq_msm_multi(cq_ctx* c, const Fr* const* scalars, const G1Affine* const* bases, size_t len, size_t count,

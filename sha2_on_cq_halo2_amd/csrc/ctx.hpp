@@ -88,6 +88,24 @@ struct cq_ctx {
     *out = pinned;
     return CQ_OK;
   }
+  void* pinned_msm = nullptr;  // MSM results (kept apart from `pinned`, which stages RNG words)
+  size_t pinned_msm_bytes = 0;
+  int ensure_pinned_msm(size_t bytes, void** out) {
+    if (pinned_msm_bytes < bytes) {
+      if (pinned_msm) {
+        hipStreamSynchronize(stream);
+        hipHostFree(pinned_msm);
+        pinned_msm = nullptr;
+        pinned_msm_bytes = 0;
+      }
+      size_t want = bytes < 65536 ? 65536 : bytes;
+      hipError_t e = hipHostMalloc(&pinned_msm, want, hipHostMallocDefault);
+      if (e != hipSuccess) return hip_fail(e, "hipHostMalloc");
+      pinned_msm_bytes = want;
+    }
+    *out = pinned_msm;
+    return CQ_OK;
+  }
   const cq::NttTables* tables_for(uint32_t log_n, const cq::Fr& omega, int* rc);
 };
 

@@ -1,6 +1,7 @@
 // Internal interface of the MSM engine (see msm.hip).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <vector>
 #include "curve.hpp"
 
 struct cq_ctx;
@@ -57,6 +58,21 @@ int cq_msm_multi(cq_ctx* c, const cq::Fr* const* scalars, const cq::G1Affine* co
 // per-MSM lengths; MSMs over registered (precomputed) bases of any length share launches
 int cq_msm_multi_v(cq_ctx* c, const cq::Fr* const* scalars, const cq::G1Affine* const* bases, const size_t* lens, size_t count,
                    uint64_t* out_jac);
+// asynchronous form: begin() enqueues every launch and the device->host copy of the results,
+// end() waits for the stream and folds them
+struct MsmPending {
+  struct Launch {
+    size_t first = 0, slot = 0;
+    uint32_t batch = 0, c = 0, nmax = 0, W = 0, Wb = 0;
+    bool pre = false, empty = false;
+  };
+  std::vector<Launch> launches;
+  void* host = nullptr;
+  size_t slots = 0, count = 0;
+};
+int msm_multi_begin(cq_ctx* c, const cq::Fr* const* scalars, const cq::G1Affine* const* bases, const size_t* lens, size_t count,
+                    MsmPending& pend);
+int msm_multi_end(cq_ctx* c, MsmPending& pend, uint64_t* out_jac);
 constexpr uint32_t MSM_TABLE_C = 15;  // window width of every precomputed table (so launches can mix lengths)
 
 int msm_register_tables(cq_ctx* c, const cq::G1Affine* bases, size_t n);

@@ -218,25 +218,35 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, cq_rng_next_u
     for (size_t a = 0; a < A; a++)
       CQ_HIP(c, hipMemcpyAsync(adv + a * n + u, (Fr*)pin + a * (n - u), (n - u) * sizeof(Fr), hipMemcpyHostToDevice, s));
     CQ_HIP(c, hipStreamSynchronize(s));  // pinned buffer is reused below
+    // commit_lagrange per column (:356-360): enqueue now, collect after the host work below
+    std::vector<const Fr*> sc(A);
+    std::vector<const G1Affine*> bs(A, pk->params->g_lagrange);
+    std::vector<size_t> ln(A, n);
+    for (size_t a = 0; a < A; a++) sc[a] = adv + a * n;
+    MsmPending pend;
+    if (A) CQ_TRY(msm_multi_begin(c, sc.data(), bs.data(), ln.data(), A, pend));
     // The next draws from the RNG are the vanishing argument's n coefficients + 1 blind
     // (vanishing/prover.rs:51-55): the CQ rounds in between draw nothing, so taking them now keeps the
-    // stream order and lets the random polynomial's commitment ride along with round 2's launch.
+    // stream order, overlaps the host-side draws with the advice MSMs, and lets the random
+    // polynomial's commitment ride along with round 2's launch.
     uint64_t* w = (uint64_t*)pin;
     for (size_t i = 0; i < n; i++) rng.words(w + 8 * i);
     (void)rng.fr();  // random_blind
     CQ_HIP(c, hipMemcpyAsync(rng_dev, pin, (size_t)64 * n, hipMemcpyHostToDevice, s));
     CQ_TRY(poly_from_u512(c, rng_dev, (uint32_t)n, random_poly));
-    CQ_HIP(c, hipStreamSynchronize(s));
-  }
-  // commit_lagrange per column (:356-360), batch_normalize (:363-366), write (:370-374)
-  std::vector<G1Affine> pts;
-  {
-    std::vector<const Fr*> sc(A);
-    std::vector<const G1Affine*> bs(A, pk->params->g_lagrange);
-    for (size_t a = 0; a < A; a++) sc[a] = adv + a * n;
-    if (A) CQ_TRY(commit_batch(c, sc, bs, n, pts));
-    for (auto& p : pts)
-      if (!tr.write_point(p)) return c->fail(CQ_ERR_TRANSCRIPT, "advice commitment is the identity");
+    // batch_normalize (:363-366), write (:370-374)
+    if (A) {
+      std::vector<uint64_t> jac(A * 12);
+      CQ_TRY(msm_multi_end(c, pend, jac.data()));
+      std::vector<G1Jac> jv(A);
+      for (size_t a = 0; a < A; a++) jv[a] = jac_from_limbs(jac.data() + 12 * a);
+      std::vector<G1Affine> pts;
+      batch_normalize(jv, pts);
+      for (auto& p : pts)
+        if (!tr.write_point(p)) return c->fail(CQ_ERR_TRANSCRIPT, "advice commitment is the identity");
+    } else {
+      CQ_HIP(c, hipStreamSynchronize(s));
+    }
   }
   const Fr theta = tr.squeeze();  // :472
 
