@@ -135,7 +135,7 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
-            "traffic": None,
+            "traffic": pmc_traffic("msm_accumulate_kernel") if k == 18 else None,
             "launches": int(acc_calls),
             "avg_launch_ms": acc_ms / max(acc_calls, 1),
             "msm_kernel_mscalar_per_s": units / acc_s / 1e6 if acc_s > 0 else 0.0,
@@ -160,6 +160,19 @@ def main():
     ctx.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over the same
+    k=18 proof (profiles/README.md); None if the summary is missing.  FETCH_SIZE is taken at face value
+    (the gather of 64-B points is not the wide coalesced stream the gfx950 x2 correction applies to); the
+    doubled figure is kept alongside in the profile file."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic_k18_proof.json")
+    try:
+        with open(path) as f:
+            return json.load(f)["cq::" + kernel]["hbm_bytes_per_launch_raw"]
+    except Exception:
+        return None
 
 
 def cpu_baseline(ctx):
