@@ -144,6 +144,12 @@ int cq_params_create(cq_ctx* ctx, uint32_t k, const uint64_t* g, const uint64_t*
 int cq_params_setup_from_toxic_waste(cq_ctx* ctx, uint32_t k, const uint64_t s[4], cq_params** out);
 /* out[i] = scalars[i] * G1::generator(), device in / device out (affine). */
 int cq_fixed_base_mul_dev(cq_ctx* ctx, const uint64_t* scalars_dev, size_t n, uint64_t* out_affine_dev);
+/* ParamsKZG::read_custom / write_custom in the RawBytes layouts (commitment.rs:366-459):
+ * k:u32 LE | n x 64 B g | n x 64 B g_lagrange | 128 B g2 | 128 B s_g2.  read: `checked` != 0 validates
+ * every point (SerdeFormat::RawBytes), 0 = RawBytesUnchecked; the G2 tail is ignored.  write: emits the
+ * 4 + 128 n byte G1 part. */
+int cq_params_read_raw(cq_ctx* ctx, const uint8_t* buf, size_t len, int checked, cq_params** out);
+int cq_params_write_raw(cq_params* params, uint8_t* buf, size_t cap, size_t* written);
 void cq_params_destroy(cq_params* params);
 const uint64_t* cq_params_g_dev(const cq_params* params);
 const uint64_t* cq_params_g_lagrange_dev(const cq_params* params);
@@ -172,6 +178,10 @@ int cq_static_table_create(cq_ctx* ctx, size_t size, const uint64_t* values, con
  * (equal to StaticTableValues::new's O(N^2) result, static_lookup.rs:108-119; tests/benches). */
 int cq_static_table_setup_from_toxic_waste(cq_ctx* ctx, size_t size, const uint64_t* values, const uint64_t s[4],
                                            cq_static_table** out);
+/* StaticTableValues::new(values, srs_g1) (static_lookup.rs:78-126): the reference's own construction --
+ * iNTT of the values, one kate_division + (N-1)-term multiexp per root -- run on the GPU.
+ * `srs_g1`: `size` affine powers [s^i]_1 (host). */
+int cq_static_table_new(cq_ctx* ctx, size_t size, const uint64_t* values, const uint64_t* srs_g1, cq_static_table** out);
 void cq_static_table_destroy(cq_static_table* table);
 int cq_static_table_download_qs(cq_static_table* table, uint64_t* qs_affine);
 
@@ -213,6 +223,12 @@ int cq_create_proof_host(cq_pk* pk, const uint64_t* const* advice, cq_rng_next_u
  * 2*pairs device columns of `n` elements, zero-filled by the caller. */
 int cq_sha_witness_fill_dev(cq_ctx* ctx, const uint32_t* words_dev, size_t nwords, uint32_t pairs, size_t n,
                             uint64_t* const* cols_dev);
+/* sha/src/tables.rs generators, rows of four u64 written to device memory:
+ * create_{rot0,rot1,maj,ch}_table::<L> (tables.rs:105-133; kind 0..3), 2^(first+2*second) rows (x,y,z,f);
+ * create_decomposition_table::<L,K> (tables.rs:135-154), 2^k_bits rows (a,x,y,z). */
+int cq_sha_synthesis_table_dev(cq_ctx* ctx, int kind, uint32_t first_limb_len, uint32_t second_limb_len, uint64_t* out_dev);
+int cq_sha_decomposition_table_dev(cq_ctx* ctx, uint32_t first_limb_len, uint32_t second_limb_len, uint32_t k_bits,
+                                   uint64_t* out_dev);
 /* dense[i] = i, spread[i] = bit-spread(i) for i < size (device arrays of `size` elements). */
 int cq_sha_spread_table_dev(cq_ctx* ctx, size_t size, uint64_t* dense_dev, uint64_t* spread_dev);
 

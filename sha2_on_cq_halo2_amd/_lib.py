@@ -136,6 +136,11 @@ def _declare(lib):  # noqa: F811
     lib.cq_buffer_rng_next_u64.argtypes = [vp]
     lib.cq_msm_precompute_dev.argtypes = [vp, vp, C.c_size_t]
     lib.cq_msm_set_precompute.argtypes = [vp, C.c_int]
+    lib.cq_sha_synthesis_table_dev.argtypes = [vp, C.c_int, C.c_uint32, C.c_uint32, vp]
+    lib.cq_sha_decomposition_table_dev.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, vp]
+    lib.cq_static_table_new.argtypes = [vp, C.c_size_t, vp, vp, C.POINTER(vp)]
+    lib.cq_params_read_raw.argtypes = [vp, vp, C.c_size_t, C.c_int, C.POINTER(vp)]
+    lib.cq_params_write_raw.argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
     lib.cq_g1_sum.argtypes = [vp, C.c_size_t, vp]
     lib.cq_g1_to_affine.argtypes = [vp, vp]
     lib.cq_profile_enable.argtypes = [vp, C.c_int]

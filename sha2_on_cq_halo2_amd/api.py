@@ -537,3 +537,67 @@ def _ctx_set_msm_precompute(self, on: bool):
 
 Context.msm_precompute = _ctx_msm_precompute
 Context.set_msm_precompute = _ctx_set_msm_precompute
+
+
+def _static_table_new(cls, ctx: Context, values: np.ndarray, srs_g1: np.ndarray) -> "StaticTable":
+    """`StaticTableValues::new(values, srs_g1)` (static_lookup.rs:78-126), the reference's O(N^2) construction."""
+    self = cls.__new__(cls)
+    v, g = _fr(values), _g1(srs_g1)
+    assert v.shape[0] == g.shape[0]
+    self.ctx, self.size = ctx, v.shape[0]
+    h = C.c_void_p()
+    ctx._chk(ctx.lib.cq_static_table_new(ctx.h, self.size, v.ctypes.data, g.ctypes.data, C.byref(h)))
+    self.h = h
+    ctx._children.add(self)
+    return self
+
+
+StaticTable.new = classmethod(_static_table_new)
+
+
+def _params_read_raw(cls, ctx: Context, data: bytes, checked: bool = True) -> "ParamsKZG":
+    """`ParamsKZG::read_custom(reader, RawBytes | RawBytesUnchecked)` (kzg/commitment.rs:383-459)."""
+    self = cls.__new__(cls)
+    buf = np.frombuffer(data, dtype=np.uint8)
+    h = C.c_void_p()
+    ctx._chk(ctx.lib.cq_params_read_raw(ctx.h, buf.ctypes.data, buf.shape[0], 1 if checked else 0, C.byref(h)))
+    self.ctx = ctx
+    self.k = int.from_bytes(data[:4], "little")
+    self.n = 1 << self.k
+    self.h = h
+    ctx._children.add(self)
+    return self
+
+
+def _params_write_raw(self) -> bytes:
+    """G1 part of `ParamsKZG::write_custom(writer, RawBytes)` (kzg/commitment.rs:366-379)."""
+    buf = np.zeros(4 + 128 * self.n, dtype=np.uint8)
+    w = C.c_size_t()
+    self.ctx._chk(self.ctx.lib.cq_params_write_raw(self.h, buf.ctypes.data, buf.shape[0], C.byref(w)))
+    return buf[: w.value].tobytes()
+
+
+ParamsKZG.read_raw = classmethod(_params_read_raw)
+ParamsKZG.write_raw = _params_write_raw
+
+SHA_ROT0, SHA_ROT1, SHA_MAJ, SHA_CH = 0, 1, 2, 3
+
+
+def _ctx_sha_synthesis_table(self, kind: int, first: int, second: int) -> np.ndarray:
+    """`create_{rot0,rot1,maj,ch}_table::<L>` (sha/src/tables.rs:105-133): uint64[rows,4] = (x,y,z,f)."""
+    rows = 1 << (first + 2 * second)
+    buf = self.alloc(rows * 32)
+    self._chk(self.lib.cq_sha_synthesis_table_dev(self.h, kind, first, second, buf.ptr))
+    return buf.download((rows, 4))
+
+
+def _ctx_sha_decomposition_table(self, first: int, second: int, k_bits: int) -> np.ndarray:
+    """`create_decomposition_table::<L,K>` (sha/src/tables.rs:135-154): uint64[2^K,4] = (a,x,y,z)."""
+    rows = 1 << k_bits
+    buf = self.alloc(rows * 32)
+    self._chk(self.lib.cq_sha_decomposition_table_dev(self.h, first, second, k_bits, buf.ptr))
+    return buf.download((rows, 4))
+
+
+Context.sha_synthesis_table = _ctx_sha_synthesis_table
+Context.sha_decomposition_table = _ctx_sha_decomposition_table

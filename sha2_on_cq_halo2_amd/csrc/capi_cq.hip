@@ -338,6 +338,65 @@ int cq_sha_spread_table_dev(cq_ctx* c, size_t size, uint64_t* dense_dev, uint64_
   return sha_spread_table(c, (uint32_t)size, (Fr*)dense_dev, (Fr*)spread_dev);
 }
 
+// ---- sha/src/tables.rs generators ----------------------------------------------------------------------
+int cq_sha_synthesis_table_dev(cq_ctx* c, int kind, uint32_t first_limb_len, uint32_t second_limb_len, uint64_t* out_dev) {
+  if (!c || !out_dev || kind < 0 || kind > 3 || first_limb_len == 0 || second_limb_len == 0 ||
+      first_limb_len + 2 * second_limb_len > 28)
+    return CQ_ERR_ARG;
+  CQ_HIP(c, hipSetDevice(c->device));
+  return sha_synthesis_table(c, (uint32_t)kind, first_limb_len, second_limb_len, out_dev);
+}
+int cq_sha_decomposition_table_dev(cq_ctx* c, uint32_t first_limb_len, uint32_t second_limb_len, uint32_t k_bits,
+                                   uint64_t* out_dev) {
+  if (!c || !out_dev || k_bits > 28 || first_limb_len == 0 || second_limb_len == 0) return CQ_ERR_ARG;
+  CQ_HIP(c, hipSetDevice(c->device));
+  return sha_decomposition_table(c, first_limb_len, second_limb_len, k_bits, out_dev);
+}
+
+// ---- StaticTableValues::new (static_lookup.rs:78-126): the reference's O(N^2) construction on the GPU ----
+int cq_static_table_new(cq_ctx* c, size_t size, const uint64_t* values, const uint64_t* srs_g1, cq_static_table** out) {
+  if (!c || !values || !srs_g1 || !out || !is_pow2(size) || size > (1u << 20)) return CQ_ERR_ARG;
+  CQ_HIP(c, hipSetDevice(c->device));
+  int rc = table_alloc(c, size, values, out);
+  if (rc != CQ_OK) return rc;
+  cq_static_table* t = *out;
+  const uint32_t N = (uint32_t)size;
+  cq_domain* dom = nullptr;
+  if ((rc = domain_create(c, 2, log2u(size), &dom)) != CQ_OK) return rc;
+  const uint32_t group = 16;  // roots per MSM launch
+  G1Affine* srs = nullptr;
+  Fr *coeffs = nullptr, *quot = nullptr;
+  if (hipMalloc(&srs, size * sizeof(G1Affine)) != hipSuccess || hipMalloc(&coeffs, size * sizeof(Fr)) != hipSuccess ||
+      hipMalloc(&quot, (size_t)group * size * sizeof(Fr)) != hipSuccess)
+    return c->fail(CQ_ERR_HIP, "hipMalloc(static_table_new)");
+  CQ_HIP(c, hipMemcpyAsync(srs, srs_g1, size * sizeof(G1Affine), hipMemcpyHostToDevice, c->stream));
+  if (c->msm_precompute && (rc = msm_register_tables(c, srs, size)) != CQ_OK) return rc;
+  if ((rc = domain_lagrange_to_coeff(dom, t->values, coeffs, 1, size, size)) != CQ_OK) return rc;  // :99-105
+  std::vector<uint64_t> jac(group * 12);
+  std::vector<G1Affine> host_qs(size);
+  for (uint32_t first = 0; first < N; first += group) {
+    const uint32_t cnt = std::min(group, N - first);
+    if ((rc = cq_table_quotients(c, coeffs, N, dom->omega, dom->ifft_divisor, first, cnt, quot)) != CQ_OK) return rc;  // :111-115
+    std::vector<const Fr*> sc(cnt);
+    std::vector<const G1Affine*> bs(cnt, srs);
+    for (uint32_t r = 0; r < cnt; r++) sc[r] = quot + (size_t)r * N;
+    if ((rc = cq_msm_multi(c, sc.data(), bs.data(), N - 1, cnt, jac.data())) != CQ_OK) return rc;  // :117
+    for (uint32_t r = 0; r < cnt; r++) {
+      G1Jac q = {Fq::from_limbs64(jac.data() + 12 * r), Fq::from_limbs64(jac.data() + 12 * r + 4),
+                 Fq::from_limbs64(jac.data() + 12 * r + 8)};
+      host_qs[first + r] = jac_to_affine(q);
+    }
+  }
+  CQ_HIP(c, hipMemcpyAsync(t->qs, host_qs.data(), size * sizeof(G1Affine), hipMemcpyHostToDevice, c->stream));
+  CQ_HIP(c, hipStreamSynchronize(c->stream));
+  msm_unregister_tables(c, srs);
+  hipFree(srs);
+  hipFree(coeffs);
+  hipFree(quot);
+  domain_destroy(dom);
+  return CQ_OK;
+}
+
 // ---- harness RNGs ----------------------------------------------------------------------------------------
 void cq_xoshiro256ss_seed(uint64_t seed, uint64_t state[4]) {
   uint64_t z = seed;

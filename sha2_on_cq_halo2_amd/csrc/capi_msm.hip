@@ -278,6 +278,69 @@ int cq_fixed_base_mul_dev(cq_ctx* c, const uint64_t* scalars_dev, size_t n, uint
   return fixed_base_mul(c, (const Fr*)scalars_dev, (uint32_t)n, (G1Affine*)out_affine_dev);
 }
 
+/* ParamsKZG::read_custom with RawBytes / RawBytesUnchecked (kzg/commitment.rs:383-459):
+ * k:u32 LE | n x 64 B g | n x 64 B g_lagrange | [128 B g2 | 128 B s_g2, ignored] -- straight into HBM */
+int cq_params_read_raw(cq_ctx* c, const uint8_t* buf, size_t len, int checked, cq_params** out) {
+  if (!c || !buf || !out || len < 4) return CQ_ERR_ARG;
+  uint32_t k;
+  memcpy(&k, buf, 4);
+  if (k > FR_S) return c->fail(CQ_ERR_ARG, "params: k out of range");
+  const size_t n = (size_t)1 << k;
+  if (len < 4 + 2 * n * sizeof(G1Affine)) return c->fail(CQ_ERR_ARG, "params: buffer too short");
+  CQ_HIP(c, hipSetDevice(c->device));
+  cq_params* p = new cq_params();
+  p->ctx = c;
+  p->k = k;
+  p->n = n;
+  const size_t bytes = n * sizeof(G1Affine);
+  if (hipMalloc(&p->g, bytes) != hipSuccess || hipMalloc(&p->g_lagrange, bytes) != hipSuccess) {
+    delete p;
+    return c->fail(CQ_ERR_HIP, "hipMalloc(params)");
+  }
+  CQ_HIP(c, hipMemcpyAsync(p->g, buf + 4, bytes, hipMemcpyHostToDevice, c->stream));
+  CQ_HIP(c, hipMemcpyAsync(p->g_lagrange, buf + 4 + bytes, bytes, hipMemcpyHostToDevice, c->stream));
+  if (checked) {  // SerdeFormat::RawBytes: coordinates < q and on the curve
+    void* tmp;
+    int rc;
+    if ((rc = c->ensure_scratch(1, 64, &tmp)) != CQ_OK) return rc;
+    CQ_HIP(c, hipMemsetAsync(tmp, 0, 4, c->stream));
+    if ((rc = g1_validate(c, p->g, (uint32_t)n, (uint32_t*)tmp)) != CQ_OK) return rc;
+    if ((rc = g1_validate(c, p->g_lagrange, (uint32_t)n, (uint32_t*)tmp)) != CQ_OK) return rc;
+    uint32_t bad = 0;
+    CQ_HIP(c, hipMemcpyAsync(&bad, tmp, 4, hipMemcpyDeviceToHost, c->stream));
+    CQ_HIP(c, hipStreamSynchronize(c->stream));
+    if (bad) {
+      hipFree(p->g);
+      hipFree(p->g_lagrange);
+      delete p;
+      return c->fail(CQ_ERR_ARG, "params: invalid point encoding");
+    }
+  }
+  CQ_HIP(c, hipStreamSynchronize(c->stream));
+  if (c->msm_precompute) {
+    int rc2;
+    if ((rc2 = msm_register_tables(c, p->g, p->n)) != CQ_OK) return rc2;
+    if ((rc2 = msm_register_tables(c, p->g_lagrange, p->n)) != CQ_OK) return rc2;
+  }
+  *out = p;
+  return CQ_OK;
+}
+
+/* G1 part of ParamsKZG::write_custom(RawBytes) (commitment.rs:366-379): 4 + 128 n bytes; the caller
+ * appends its g2 / s_g2. */
+int cq_params_write_raw(cq_params* p, uint8_t* buf, size_t cap, size_t* written) {
+  if (!p || !buf || !written) return CQ_ERR_ARG;
+  cq_ctx* c = p->ctx;
+  const size_t bytes = p->n * sizeof(G1Affine);
+  if (cap < 4 + 2 * bytes) return c->fail(CQ_ERR_ARG, "params: output buffer too small");
+  memcpy(buf, &p->k, 4);
+  CQ_HIP(c, hipMemcpyAsync(buf + 4, p->g, bytes, hipMemcpyDeviceToHost, c->stream));
+  CQ_HIP(c, hipMemcpyAsync(buf + 4 + bytes, p->g_lagrange, bytes, hipMemcpyDeviceToHost, c->stream));
+  CQ_HIP(c, hipStreamSynchronize(c->stream));
+  *written = 4 + 2 * bytes;
+  return CQ_OK;
+}
+
 void cq_params_destroy(cq_params* p) {
   if (!p) return;
   hipStreamSynchronize(p->ctx->stream);

@@ -240,3 +240,117 @@ int sha_spread_table(cq_ctx* c, uint32_t N, Fr* dense, Fr* spread) {
 }
 
 }  // namespace cq
+
+// =================================================================================================
+// sha/src/tables.rs table generators (integer work; rows of four u64: (x, y, z, f(x,y,z)))
+// =================================================================================================
+namespace cq {
+
+// `rotation::<L, N>` (tables.rs:98-103) with the reference's quirk: Bits::BITS_LEN is 8 for u8, u16 AND u32
+// (tables.rs:30-38), so the word is truncated to its low 8 bits and rotated right within 8 bits.
+static __device__ __forceinline__ uint64_t rot8(uint64_t word, uint32_t n) {
+  const uint32_t w = (uint32_t)word & 0xffu;
+  const uint32_t r = n % 8;
+  return r ? (((w >> r) | (w << (8 - r))) & 0xffu) : w;
+}
+
+__global__ void sha_synthesis_table_kernel(uint32_t kind, uint32_t first, uint32_t second, uint64_t* __restrict__ out) {
+  const uint64_t rows = 1ull << (first + 2 * second);
+  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= rows) return;
+  // create_synthesis_table (tables.rs:78-89): x outermost, z innermost
+  const uint64_t z = t & ((1ull << second) - 1);
+  const uint64_t y = (t >> second) & ((1ull << second) - 1);
+  const uint64_t x = t >> (2 * second);
+  uint64_t f;
+  if (kind == 0 || kind == 1) {
+    const uint64_t xyz = (x << (2 * second)) | (y << second) | z;  // combine (:91-96)
+    f = kind == 0 ? (rot8(xyz, 2) ^ rot8(xyz, 13) ^ rot8(xyz, 22))   // create_rot0_table (:113-115)
+                  : (rot8(xyz, 6) ^ rot8(xyz, 11) ^ rot8(xyz, 25));  // create_rot1_table (:117-119)
+  } else if (kind == 2) {
+    f = (x & y) ^ (x & z) ^ (y & z);  // create_maj_table (:121-126)
+  } else {
+    f = (x & y) ^ ((~x) & z);  // create_ch_table (:128-133)
+  }
+  out[4 * t] = x;
+  out[4 * t + 1] = y;
+  out[4 * t + 2] = z;
+  out[4 * t + 3] = f;
+}
+
+// create_decomposition_table::<L, K> (tables.rs:135-154): rows (a, x, y, z) for a in [0, 2^K)
+__global__ void sha_decomposition_table_kernel(uint32_t first, uint32_t second, uint32_t kbits, uint64_t* __restrict__ out) {
+  const uint64_t a = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= (1ull << kbits)) return;
+  const uint32_t full = first + 2 * second;
+  const uint64_t a_mod = full >= 64 ? a : a % (1ull << full);
+  const uint64_t x = a_mod >> (2 * second);
+  const uint64_t y = (a_mod >> second) & ((1ull << second) - 1);
+  const uint64_t z = a_mod & ((1ull << second) - 1);
+  out[4 * a] = a;
+  out[4 * a + 1] = x;
+  out[4 * a + 2] = y;
+  out[4 * a + 3] = z;
+}
+
+int sha_synthesis_table(cq_ctx* c, uint32_t kind, uint32_t first, uint32_t second, uint64_t* out) {
+  const uint64_t rows = 1ull << (first + 2 * second);
+  sha_synthesis_table_kernel<<<(uint32_t)((rows + 255) / 256), 256, 0, c->stream>>>(kind, first, second, out);
+  return hipGetLastError() == hipSuccess ? CQ_OK : c->fail(CQ_ERR_HIP, "sha_synthesis_table launch failed");
+}
+int sha_decomposition_table(cq_ctx* c, uint32_t first, uint32_t second, uint32_t kbits, uint64_t* out) {
+  const uint64_t rows = 1ull << kbits;
+  sha_decomposition_table_kernel<<<(uint32_t)((rows + 255) / 256), 256, 0, c->stream>>>(first, second, kbits, out);
+  return hipGetLastError() == hipSuccess ? CQ_OK : c->fail(CQ_ERR_HIP, "sha_decomposition_table launch failed");
+}
+
+// ---- StaticTableValues::new (static_lookup.rs:99-119): scaled quotients for a group of roots ---------
+// row r: quotient of kate_division(table_coeffs, g) scaled by g/N, g = w^(first_root + r)
+__global__ void cq_table_quotients_kernel(const Fr* __restrict__ coeffs, uint32_t N, Fr omega, Fr n_inv, uint32_t first_root,
+                                          uint32_t nroots, Fr* __restrict__ out /* nroots x N, last column zero */) {
+  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= nroots) return;
+  const Fr g = omega.pow_u64(first_root + r);
+  const Fr scale = g * n_inv;
+  Fr* row = out + (size_t)r * N;
+  Fr carry = Fr::zero();
+  st(row + (N - 1), Fr::zero());
+  for (uint32_t i = N; i-- > 1;) {  // q_{i-1} = a_i + g q_i   (arithmetic.rs:361-368)
+    carry = ld(coeffs + i) + g * carry;
+    st(row + (i - 1), carry * scale);
+  }
+}
+
+int cq_table_quotients(cq_ctx* c, const Fr* coeffs, uint32_t N, const Fr& omega, const Fr& n_inv, uint32_t first_root,
+                       uint32_t nroots, Fr* out) {
+  cq_table_quotients_kernel<<<(nroots + 63) / 64, 64, 0, c->stream>>>(coeffs, N, omega, n_inv, first_root, nroots, out);
+  return hipGetLastError() == hipSuccess ? CQ_OK : c->fail(CQ_ERR_HIP, "table quotients launch failed");
+}
+
+// RawBytes check of an affine point array (derive/curve.rs read_raw): coordinates < q, on the curve or (0,0)
+__global__ void g1_validate_kernel(const G1Affine* __restrict__ pts, uint32_t n, uint32_t* __restrict__ bad) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint4* q = reinterpret_cast<const uint4*>(pts + i);
+  uint4 a = q[0], b = q[1], cc = q[2], d = q[3];
+  Fq x, y;
+  x.v.l[0] = a.x; x.v.l[1] = a.y; x.v.l[2] = a.z; x.v.l[3] = a.w; x.v.l[4] = b.x; x.v.l[5] = b.y; x.v.l[6] = b.z; x.v.l[7] = b.w;
+  y.v.l[0] = cc.x; y.v.l[1] = cc.y; y.v.l[2] = cc.z; y.v.l[3] = cc.w; y.v.l[4] = d.x; y.v.l[5] = d.y; y.v.l[6] = d.z; y.v.l[7] = d.w;
+  auto lt_mod = [](const Fq& v) {
+    for (int k = 7; k >= 0; k--) {
+      if (v.v.l[k] < FqP::MOD[k]) return true;
+      if (v.v.l[k] > FqP::MOD[k]) return false;
+    }
+    return false;
+  };
+  bool ok = lt_mod(x) && lt_mod(y);
+  if (ok && !(x.is_zero() && y.is_zero())) ok = (y.sqr() == x.sqr() * x + Fq::from_u64(3));
+  if (!ok) atomicExch(bad, 1u);
+}
+
+int g1_validate(cq_ctx* c, const G1Affine* pts, uint32_t n, uint32_t* bad_dev) {
+  if (n) g1_validate_kernel<<<(n + 255) / 256, 256, 0, c->stream>>>(pts, n, bad_dev);
+  return hipGetLastError() == hipSuccess ? CQ_OK : c->fail(CQ_ERR_HIP, "g1_validate launch failed");
+}
+
+}  // namespace cq

@@ -35,6 +35,11 @@ int cq_m_to_fr(cq_ctx* c, const uint32_t* m, uint32_t N, Fr* out);
 int cq_qs_scalars(cq_ctx* c, const Fr* values, uint32_t N, const Fr& ts, const Fr& s, const Fr& omega, const Fr& n_inv, Fr* out);
 int sha_witness_fill(cq_ctx* c, const uint32_t* words_dev, uint32_t nwords, uint32_t pairs, uint32_t n, const ShaCols& cols);
 int sha_spread_table(cq_ctx* c, uint32_t N, Fr* dense, Fr* spread);
+int sha_synthesis_table(cq_ctx* c, uint32_t kind, uint32_t first, uint32_t second, uint64_t* out);
+int sha_decomposition_table(cq_ctx* c, uint32_t first, uint32_t second, uint32_t kbits, uint64_t* out);
+int cq_table_quotients(cq_ctx* c, const Fr* coeffs, uint32_t N, const Fr& omega, const Fr& n_inv, uint32_t first_root,
+                       uint32_t nroots, Fr* out);
+int g1_validate(cq_ctx* c, const G1Affine* pts, uint32_t n, uint32_t* bad_dev);
 
 }  // namespace cq
 
