@@ -48,6 +48,10 @@ typedef struct cq_pk cq_pk;           /* ProvingKey slice read by the CQ-only pr
 /* `R: RngCore` of create_proof (plonk/prover.rs:65): the library calls next_u64 exactly as
  * `Fr::random` does (8 calls per scalar, low limb first, bn256/fr.rs:159-170). */
 typedef uint64_t (*cq_rng_next_u64)(void* state);
+/* Collective hook for MSM sharding (one process per GPU): gathers `bytes_per_rank` bytes from every rank
+ * into `recv` (world x bytes_per_rank, rank order).  The host application implements it with RCCL /
+ * torch.distributed; returns 0 on success. */
+typedef int (*cq_allgather_fn)(void* user, const void* send, void* recv, size_t bytes_per_rank);
 
 /* ---- context ------------------------------------------------------------------------- */
 /* `hip_stream` may be NULL (the library creates its own stream) or an existing hipStream_t
@@ -203,6 +207,11 @@ typedef struct {
  * points; device pointer if b0_on_device != 0, else host). */
 int cq_pk_create(cq_ctx* ctx, cq_params* params, const cq_circuit* circuit, cq_table_config* cfg,
                  const uint64_t* b0_g1_bound, int b0_on_device, cq_pk** out);
+/* Shards every commitment of cq_create_proof across `world` ranks by point range: rank r
+ * multiplies the slice shard(len, r, world) of each (scalars, bases) pair, the 96-byte Jacobian partials are
+ * all-gathered through `fn` and summed locally (EC addition is not an RCCL reduction op), so every rank
+ * derives the same transcript.  Every rank must hold the same witness and RNG stream. */
+int cq_pk_set_sharding(cq_pk* pk, uint32_t rank, uint32_t world, cq_allgather_fn fn, void* user);
 void cq_pk_destroy(cq_pk* pk);
 uint32_t cq_pk_usable_rows(const cq_pk* pk);
 size_t cq_pk_proof_size(const cq_pk* pk);

@@ -601,3 +601,36 @@ def _ctx_sha_decomposition_table(self, first: int, second: int, k_bits: int) -> 
 
 Context.sha_synthesis_table = _ctx_sha_synthesis_table
 Context.sha_decomposition_table = _ctx_sha_decomposition_table
+
+
+_ALLGATHER_T = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)
+
+
+def _pk_set_sharding(self, rank: int, world: int, group=None, device=None):
+    """Shards every commitment of `create_proof` across the ranks of a torch.distributed group
+    (cq_pk_set_sharding): the per-rank Jacobian partials travel through `all_gather` (RCCL with the
+    "nccl" backend when `device` is a cuda device, gloo on CPU tensors otherwise)."""
+    import torch
+    import torch.distributed as dist
+
+    def allgather(_user, send, recv, nbytes):
+        try:
+            src = (C.c_uint8 * nbytes).from_address(send)
+            t = torch.frombuffer(src, dtype=torch.uint8).clone()
+            if device is not None:
+                t = t.to(device)
+            outs = [torch.empty_like(t) for _ in range(world)]
+            dist.all_gather(outs, t, group=group)
+            dst = (C.c_uint8 * (nbytes * world)).from_address(recv)
+            flat = torch.cat([o.cpu() for o in outs]).numpy()
+            C.memmove(dst, flat.ctypes.data, nbytes * world)
+            return 0
+        except Exception:  # never unwind into C
+            return -1
+
+    self._allgather_cb = _ALLGATHER_T(allgather) if world > 1 else None
+    cb = C.cast(self._allgather_cb, C.c_void_p) if world > 1 else None
+    self.ctx._chk(self.ctx.lib.cq_pk_set_sharding(self.h, rank, world, cb, None))
+
+
+ProvingKey.set_sharding = _pk_set_sharding

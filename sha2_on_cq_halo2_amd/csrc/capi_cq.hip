@@ -266,6 +266,15 @@ int cq_pk_create(cq_ctx* c, cq_params* params, const cq_circuit* cs, cq_table_co
   return CQ_OK;
 }
 
+int cq_pk_set_sharding(cq_pk* pk, uint32_t rank, uint32_t world, cq_allgather_fn fn, void* user) {
+  if (!pk || world == 0 || rank >= world || (world > 1 && !fn)) return CQ_ERR_ARG;
+  pk->shard_rank = rank;
+  pk->shard_world = world;
+  pk->allgather = fn;
+  pk->allgather_user = user;
+  return CQ_OK;
+}
+
 void cq_pk_destroy(cq_pk* pk) {
   if (!pk) return;
   hipStreamSynchronize(pk->ctx->stream);

@@ -80,8 +80,9 @@ int msm_multi_begin(cq_ctx* c, const Fr* const* scalars, const G1Affine* const* 
     std::vector<const G1Affine*> bp(ln.batch);
     std::vector<size_t> strides(ln.batch, 0);
     for (uint32_t j = 0; j < ln.batch; j++) {
-      const cq_ctx::MsmTable* t = ln.pre ? c->find_msm_table(bases[ln.first + j], lens[ln.first + j]) : nullptr;
-      bp[j] = ln.pre ? (const G1Affine*)t->table : bases[ln.first + j];
+      size_t toff = 0;
+      const cq_ctx::MsmTable* t = ln.pre ? c->find_msm_table(bases[ln.first + j], lens[ln.first + j], &toff) : nullptr;
+      bp[j] = ln.pre ? (const G1Affine*)t->table + toff : bases[ln.first + j];
       strides[j] = ln.pre ? t->n : 0;
     }
     void* ws;
@@ -141,7 +142,12 @@ void msm_unregister_tables(cq_ctx* c, const void* bases) {
 // Memory: ceil(255/c) x n x 64 B (17 x the SRS for n >= 2^15) -- sized for 288 GB of HBM.
 int msm_register_tables(cq_ctx* c, const G1Affine* bases, size_t n) {
   if (!bases || n == 0 || n > (1u << 26)) return CQ_OK;  // nothing to do / unsupported: plain mode
-  if (c->find_msm_table(bases, n)) return CQ_OK;
+  {
+    size_t off = 0;
+    const cq_ctx::MsmTable* t = c->find_msm_table(bases, n, &off);
+    if (t && off == 0 && t->bases == bases) return CQ_OK;  // already registered (slices of it resolve to it too)
+    if (t) return CQ_OK;
+  }
   const uint32_t cb = MSM_TABLE_C;
   const uint32_t W = (255 + cb - 1) / cb;
   void* table = nullptr;

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <vector>
+#include "../../include/cq_halo2.h"
 #include "curve.hpp"
 #include "poly.hpp"
 
@@ -90,4 +91,9 @@ struct cq_pk {
   cq::Fr* l_active_row = nullptr;       // extended coset
   cq::Fr vk_repr;
   std::vector<cq::G1Affine*> qs_concat;  // per lookup: [qs_0 | qs_1 | ...] (width*N points)
+  // MSM sharding across ranks (one process per GPU): every rank commits its slice of each point range,
+  // partial results are all-gathered through the caller's collective and summed locally
+  uint32_t shard_rank = 0, shard_world = 1;
+  cq_allgather_fn allgather = nullptr;
+  void* allgather_user = nullptr;
 };

@@ -25,9 +25,17 @@ struct cq_ctx {
   // precomputed MSM window tables, keyed by the base array they were derived from
   struct MsmTable { const void* bases; size_t n; uint32_t c; void* table; };
   std::vector<MsmTable> msm_tables;
-  const MsmTable* find_msm_table(const void* bases, size_t len) const {
-    for (auto& t : msm_tables)
-      if (t.bases == bases && len <= t.n) return &t;
+  // `bases` may point anywhere inside a registered array (a rank's slice of the SRS); *offset = first point
+  const MsmTable* find_msm_table(const void* bases, size_t len, size_t* offset = nullptr) const {
+    for (auto& t : msm_tables) {
+      const char* b0 = (const char*)t.bases;
+      const char* b = (const char*)bases;
+      if (b < b0 || b >= b0 + t.n * 64) continue;
+      const size_t off = (size_t)(b - b0) / 64;
+      if ((size_t)(b - b0) % 64 || off + len > t.n) continue;
+      if (offset) *offset = off;
+      return &t;
+    }
     return nullptr;
   }
   // optional per-kernel timing with HIP events on `stream` (bench.py's roofline leg)

@@ -111,22 +111,72 @@ struct Rng {
   }
 };
 
-// msms over device scalars; one host sync; results normalised
-int commit_batch_v(cq_ctx* c, const std::vector<const Fr*>& scalars, const std::vector<const G1Affine*>& bases,
-                   const std::vector<size_t>& lens, std::vector<G1Affine>& out) {
-  std::vector<uint64_t> jac(scalars.size() * 12);
-  int rc = cq_msm_multi_v(c, scalars.data(), bases.data(), lens.data(), scalars.size(), jac.data());
-  if (rc != CQ_OK) return rc;
-  std::vector<G1Jac> j(scalars.size());
-  for (size_t i = 0; i < scalars.size(); i++) j[i] = jac_from_limbs(jac.data() + 12 * i);
-  batch_normalize(j, out);
-  return CQ_OK;
+// contiguous slice of an n-term multiexp owned by `rank` (sizes differ by at most one)
+void shard_range(size_t n, uint32_t rank, uint32_t world, size_t& lo, size_t& hi) {
+  const size_t base = n / world, rem = n % world;
+  lo = rank * base + std::min<size_t>(rank, rem);
+  hi = lo + base + (rank < rem ? 1 : 0);
 }
 
-int commit_batch(cq_ctx* c, const std::vector<const Fr*>& scalars, const std::vector<const G1Affine*>& bases, size_t len,
+// Commitments of one transcript round.  begin() enqueues the (possibly sharded) MSMs, end() waits,
+// exchanges partial sums between ranks when sharded, and normalises (batch_normalize).
+struct Commit {
+  const cq_pk* pk;
+  MsmPending pend;
+  size_t count = 0;
+  int begin(const cq_pk* pk_, const std::vector<const Fr*>& scalars, const std::vector<const G1Affine*>& bases,
+            const std::vector<size_t>& lens) {
+    pk = pk_;
+    count = scalars.size();
+    if (pk->shard_world <= 1) return msm_multi_begin(pk->ctx, scalars.data(), bases.data(), lens.data(), count, pend);
+    std::vector<const Fr*> sc(count);
+    std::vector<const G1Affine*> bs(count);
+    std::vector<size_t> ln(count);
+    for (size_t j = 0; j < count; j++) {
+      size_t lo, hi;
+      shard_range(lens[j], pk->shard_rank, pk->shard_world, lo, hi);
+      sc[j] = scalars[j] + lo;
+      bs[j] = bases[j] + lo;
+      ln[j] = hi - lo;
+    }
+    return msm_multi_begin(pk->ctx, sc.data(), bs.data(), ln.data(), count, pend);
+  }
+  int end(std::vector<G1Affine>& out) {
+    cq_ctx* c = pk->ctx;
+    std::vector<uint64_t> jac(count * 12);
+    int rc = msm_multi_end(c, pend, jac.data());
+    if (rc != CQ_OK) return rc;
+    std::vector<G1Jac> j(count);
+    if (pk->shard_world > 1) {
+      // all-gather of count x 96 B per rank, then the local EC sum (not an RCCL reduction op)
+      std::vector<uint64_t> all((size_t)pk->shard_world * count * 12);
+      if (pk->allgather(pk->allgather_user, jac.data(), all.data(), count * 12 * sizeof(uint64_t)) != 0)
+        return c->fail(CQ_ERR_INTERNAL, "allgather callback failed");
+      for (size_t i = 0; i < count; i++) {
+        G1Jac acc = G1Jac::identity();
+        for (uint32_t r = 0; r < pk->shard_world; r++) acc = jac_add(acc, jac_from_limbs(all.data() + ((size_t)r * count + i) * 12));
+        j[i] = acc;
+      }
+    } else {
+      for (size_t i = 0; i < count; i++) j[i] = jac_from_limbs(jac.data() + 12 * i);
+    }
+    batch_normalize(j, out);
+    return CQ_OK;
+  }
+};
+
+int commit_batch_v(const cq_pk* pk, const std::vector<const Fr*>& scalars, const std::vector<const G1Affine*>& bases,
+                   const std::vector<size_t>& lens, std::vector<G1Affine>& out) {
+  Commit cm;
+  int rc = cm.begin(pk, scalars, bases, lens);
+  if (rc != CQ_OK) return rc;
+  return cm.end(out);
+}
+
+int commit_batch(const cq_pk* pk, const std::vector<const Fr*>& scalars, const std::vector<const G1Affine*>& bases, size_t len,
                  std::vector<G1Affine>& out) {
   std::vector<size_t> lens(scalars.size(), len);
-  return commit_batch_v(c, scalars, bases, lens, out);
+  return commit_batch_v(pk, scalars, bases, lens, out);
 }
 
 }  // namespace
@@ -223,8 +273,8 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, cq_rng_next_u
     std::vector<const G1Affine*> bs(A, pk->params->g_lagrange);
     std::vector<size_t> ln(A, n);
     for (size_t a = 0; a < A; a++) sc[a] = adv + a * n;
-    MsmPending pend;
-    if (A) CQ_TRY(msm_multi_begin(c, sc.data(), bs.data(), ln.data(), A, pend));
+    Commit adv_cm;
+    if (A) CQ_TRY(adv_cm.begin(pk, sc, bs, ln));
     // The next draws from the RNG are the vanishing argument's n coefficients + 1 blind
     // (vanishing/prover.rs:51-55): the CQ rounds in between draw nothing, so taking them now keeps the
     // stream order, overlaps the host-side draws with the advice MSMs, and lets the random
@@ -236,12 +286,8 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, cq_rng_next_u
     CQ_TRY(poly_from_u512(c, rng_dev, (uint32_t)n, random_poly));
     // batch_normalize (:363-366), write (:370-374)
     if (A) {
-      std::vector<uint64_t> jac(A * 12);
-      CQ_TRY(msm_multi_end(c, pend, jac.data()));
-      std::vector<G1Jac> jv(A);
-      for (size_t a = 0; a < A; a++) jv[a] = jac_from_limbs(jac.data() + 12 * a);
       std::vector<G1Affine> pts;
-      batch_normalize(jv, pts);
+      CQ_TRY(adv_cm.end(pts));
       for (auto& p : pts)
         if (!tr.write_point(p)) return c->fail(CQ_ERR_TRANSCRIPT, "advice commitment is the identity");
     } else {
@@ -293,7 +339,7 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, cq_rng_next_u
     for (size_t l = 0; l < L; l++) { sc.push_back(f_lag + l * n); bs.push_back(pk->params->g_lagrange); ln.push_back(n); }
     for (size_t l = 0; l < L; l++) { sc.push_back(m_fr + l * N); bs.push_back(pk->table_cfg->g1_lagrange); ln.push_back(N); }
     std::vector<G1Affine> cm;
-    CQ_TRY(commit_batch_v(c, sc, bs, ln, cm));
+    CQ_TRY(commit_batch_v(pk, sc, bs, ln, cm));
     for (size_t l = 0; l < L; l++) {
       if (!tr.write_point(cm[l])) return c->fail(CQ_ERR_TRANSCRIPT, "f commitment is the identity");
       if (!tr.write_point(cm[L + l])) return c->fail(CQ_ERR_TRANSCRIPT, "m commitment is the identity");
@@ -370,7 +416,7 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, cq_rng_next_u
         woff += w;
       }
       sc.push_back(random_poly); bs.push_back(pk->params->g); ln.push_back(n);
-      CQ_TRY(commit_batch_v(c, sc, bs, ln, r2));
+      CQ_TRY(commit_batch_v(pk, sc, bs, ln, r2));
     }
     for (size_t l = 0; l < L; l++) {
       // write order :306-313: a, q_a, a0, b0, p
@@ -425,7 +471,7 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, cq_rng_next_u
     std::vector<const G1Affine*> bs(pieces, pk->params->g);
     for (size_t i = 0; i < pieces; i++) sc[i] = h_coeff + i * n;
     std::vector<G1Affine> o;
-    CQ_TRY(commit_batch(c, sc, bs, n, o));
+    CQ_TRY(commit_batch(pk, sc, bs, n, o));
     for (auto& p : o)
       if (!tr.write_point(p)) return c->fail(CQ_ERR_TRANSCRIPT, "h piece commitment is the identity");
   }
@@ -512,7 +558,7 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, cq_rng_next_u
     std::vector<const Fr*> sc{gwc_wit};
     std::vector<const G1Affine*> bs{pk->params->g};
     std::vector<G1Affine> o;
-    CQ_TRY(commit_batch(c, sc, bs, n - 1, o));
+    CQ_TRY(commit_batch(pk, sc, bs, n - 1, o));
     if (!tr.write_point(o[0])) return c->fail(CQ_ERR_TRANSCRIPT, "opening witness commitment is the identity");
   }
   proof_out.swap(tr.proof);
