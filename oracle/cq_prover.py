@@ -1,11 +1,12 @@
-"""TEST INFRASTRUCTURE ONLY -- CPU oracle restating `create_proof` for CQ-only circuits.
+"""TEST INFRASTRUCTURE ONLY -- CPU oracle restating `create_proof`.
 
-Follows `halo2_proofs/src/plonk/prover.rs:51-779` for a constraint system that has
-advice columns and static (CQ) lookups only -- no gates, fixed/instance columns,
-permutations or legacy lookups (exactly the shape of the reference's one CQ
-end-to-end test, `halo2_proofs/tests/my_test.rs`).  Sub-arguments:
-`plonk/static_lookup/prover.rs`, `plonk/vanishing/prover.rs`,
-`plonk/evaluation.rs:533-548`, `poly/kzg/multiopen/gwc/prover.rs`, `transcript.rs`.
+Follows `halo2_proofs/src/plonk/prover.rs:51-779` for one circuit with advice, fixed and instance
+columns, custom gates, the permutation argument and static (CQ) lookups -- everything the
+reference prover does except legacy (plookup-style) lookups, multi-phase challenges and
+SHPLONK.  The reference's one CQ end-to-end test (`halo2_proofs/tests/my_test.rs`) is the
+advice + static-lookup subset.  Sub-arguments: `plonk/static_lookup/prover.rs`,
+`plonk/permutation/prover.rs` (oracle/plonk.py), `plonk/vanishing/prover.rs`,
+`plonk/evaluation.rs:285-551`, `poly/kzg/multiopen/gwc/prover.rs`, `transcript.rs`.
 
 Parity status: the arithmetic underneath is pinned by the reference's KATs
 (`oracle/bn254.py`); the proof byte stream itself is "parity unpinned" against
@@ -32,6 +33,8 @@ from .bn254 import (
     to_jac,
     to_repr,
 )
+from .plonk import (ADVICE, FIXED, INSTANCE, build_permutation_pk, expr_degree, expr_eval, expr_queries,
+                    permutation_commit, permutation_h_terms, rotation_idx)
 from .poly import EvaluationDomain, best_multiexp, eval_polynomial, kate_division
 
 P = R_MOD
@@ -70,23 +73,50 @@ class Blake2bWrite:
 
 @dataclass
 class CqCircuit:
-    """Shape descriptor standing in for `ConstraintSystem` (plonk/circuit.rs) on CQ-only
-    circuits.  `lookups[l]` = list of (advice column, table id): one input expression
-    `advice[col]@Rotation::cur()` per table column, as `lookup_static` registers them
-    (plonk/circuit.rs:1579-1602)."""
+    """Shape descriptor standing in for `ConstraintSystem` (plonk/circuit.rs).  `lookups[l]` =
+    list of (advice column, table id): one input expression `advice[col]@Rotation::cur()` per table
+    column, as `lookup_static` registers them (plonk/circuit.rs:1579-1602).
+
+    General-PLONK part (all empty for a CQ-only circuit): `gates` = the gate polynomials in
+    `cs.gates` order (oracle/plonk.py expressions; selectors already folded into fixed columns as
+    in `vk.cs`), `perm_columns` = `cs.permutation.columns` as (kind, index), fixed / instance
+    column counts.  `queries` optionally pins the (advice, fixed, instance) query lists; by default
+    they are registered as a `configure` that calls enable_equality, then create_gate, then
+    lookup_static would (first-seen order, circuit.rs:1619-1681)."""
 
     k: int
     num_advice: int
     lookups: list
+    num_fixed: int = 0
+    num_instance: int = 0
+    gates: list = field(default_factory=list)
+    perm_columns: list = field(default_factory=list)
+    queries: dict = None
+
+    def _all_queries(self):
+        if self.queries is not None:
+            return self.queries
+        q = []
+        for kind, idx in self.perm_columns:  # enable_equality -> query_any_index(col, cur) (circuit.rs:1523-1527)
+            if (kind, idx, 0) not in q:
+                q.append((kind, idx, 0))
+        for g in self.gates:
+            expr_queries(g, q)
+        for lk in self.lookups:
+            for col, _ in lk:
+                if (ADVICE, col, 0) not in q:
+                    q.append((ADVICE, col, 0))
+        return {kind: [(c, r) for (t, c, r) in q if t == kind] for kind in (ADVICE, FIXED, INSTANCE)}
 
     def advice_queries(self):
         """plonk/circuit.rs:1619-1633: queries in first-seen order."""
-        q = []
-        for lk in self.lookups:
-            for col, _ in lk:
-                if (col, 0) not in q:
-                    q.append((col, 0))
-        return q
+        return self._all_queries()[ADVICE]
+
+    def fixed_queries(self):
+        return self._all_queries()[FIXED]
+
+    def instance_queries(self):
+        return self._all_queries()[INSTANCE]
 
     def blinding_factors(self) -> int:
         """plonk/circuit.rs:2022-2047."""
@@ -97,8 +127,12 @@ class CqCircuit:
         return max(3, factors) + 2
 
     def degree(self) -> int:
-        """plonk/circuit.rs:1979-2018 with static_lookup.rs:181-190 (input degree 1)."""
-        return 3
+        """plonk/circuit.rs:1979-2018: permutation 3 (permutation.rs:40-75), static lookups 3
+        (static_lookup.rs:181-190), gates by their polynomials."""
+        d = 3
+        for g in self.gates:
+            d = max(d, expr_degree(g))
+        return d
 
 
 @dataclass
@@ -112,10 +146,20 @@ class ProvingKey:
     table_cfg: object  # TableSRS (g1_lagrange, g_lagrange_opening_at_0), static_lookup.rs:47-66
     b0_g1_bound: list
     vk_repr: int  # opaque transcript_repr (plonk.rs:221-232)
+    l0: list = None  # keygen.rs:340-345
+    l_last: list = None  # :357-363
+    fixed_values: list = field(default_factory=list)  # :320-326
+    fixed_polys: list = field(default_factory=list)  # :328-331
+    fixed_cosets: list = field(default_factory=list)  # :333-336
+    permutations: list = field(default_factory=list)  # permutation/keygen.rs:151-208
+    perm_polys: list = field(default_factory=list)
+    perm_cosets: list = field(default_factory=list)
 
 
-def keygen_pk(circuit: CqCircuit, tables: dict, table_cfg, b0_g1_bound, vk_repr: int) -> ProvingKey:
-    """plonk/keygen.rs:344-373 restricted to l_active_row."""
+def keygen_pk(circuit: CqCircuit, tables: dict, table_cfg, b0_g1_bound, vk_repr: int, fixed=(), perm_mapping=None) -> ProvingKey:
+    """plonk/keygen.rs:278-397.  `fixed`: the assigned fixed columns (n values each, after
+    `compress_selectors`); `perm_mapping`: `Assembly.mapping` after the circuit's copy constraints
+    (identity if None)."""
     dom = EvaluationDomain(circuit.degree(), circuit.k)
     n = dom.n
     bf = circuit.blinding_factors()
@@ -124,11 +168,23 @@ def keygen_pk(circuit: CqCircuit, tables: dict, table_cfg, b0_g1_bound, vk_repr:
         l_blind[i] = 1
     l_last = [0] * n
     l_last[n - bf - 1] = 1
+    l0 = [0] * n
+    l0[0] = 1
     lb = dom.coeff_to_extended(dom.lagrange_to_coeff(l_blind))
     ll = dom.coeff_to_extended(dom.lagrange_to_coeff(l_last))
+    l0e = dom.coeff_to_extended(dom.lagrange_to_coeff(l0))
     l_active = [(1 - (a + b)) % P for a, b in zip(ll, lb)]
-    assert len(b0_g1_bound) == n - 1
-    return ProvingKey(circuit, dom, l_active, tables, table_cfg, b0_g1_bound, vk_repr)
+    assert len(b0_g1_bound) == n - 1 or not circuit.lookups
+    assert len(fixed) == circuit.num_fixed
+    fixed_values = [[v % P for v in col] + [0] * (n - len(col)) for col in fixed]
+    fixed_polys = [dom.lagrange_to_coeff(c) for c in fixed_values]
+    fixed_cosets = [dom.coeff_to_extended(c) for c in fixed_polys]
+    if perm_mapping is None:
+        perm_mapping = [[(i, j) for j in range(n)] for i in range(len(circuit.perm_columns))]
+    assert len(perm_mapping) == len(circuit.perm_columns)
+    perms, ppolys, pcosets = build_permutation_pk(dom, perm_mapping)
+    return ProvingKey(circuit, dom, l_active, tables, table_cfg, b0_g1_bound, vk_repr, l0e, ll, fixed_values,
+                      fixed_polys, fixed_cosets, perms, ppolys, pcosets)
 
 
 @dataclass
@@ -142,8 +198,8 @@ class ProofTrace:
     polys: dict = field(default_factory=dict)
 
 
-def create_proof(params, pk: ProvingKey, advice_usable, rng, msm=None) -> ProofTrace:
-    """plonk/prover.rs:51-779 for a single CQ-only circuit.
+def create_proof(params, pk: ProvingKey, advice_usable, rng, msm=None, instances=()) -> ProofTrace:
+    """plonk/prover.rs:51-779 for a single circuit (ProverGWC: QUERY_INSTANCE = false).
 
     `advice_usable[c]` = the assigned values of advice column c on rows 0..u (shorter
     lists are zero-padded: unassigned cells are zero, prover.rs:424).
@@ -164,7 +220,18 @@ def create_proof(params, pk: ProvingKey, advice_usable, rng, msm=None) -> ProofT
     # prover.rs:85
     tr.common_scalar(pk.vk_repr)
 
-    # ---- phase 0 advice (prover.rs:299-391); no instances -------------------
+    # ---- instance columns (prover.rs:100-131); absorbed as scalars (:305-312) ---
+    assert len(instances) == cs.num_instance, "InvalidInstances"
+    instance_values = []
+    for vals in instances:
+        assert len(vals) <= u, "InstanceTooLarge"
+        instance_values.append([v % P for v in vals] + [0] * (n - len(vals)))
+    instance_polys = [dom.lagrange_to_coeff(v) for v in instance_values]
+    for vals in instances:
+        for v in vals:
+            tr.common_scalar(v % P)
+
+    # ---- phase 0 advice (prover.rs:299-391) ---------------------------------
     advice = []
     for c in range(cs.num_advice):
         col = list(advice_usable[c]) + [0] * (u - len(advice_usable[c]))
@@ -222,6 +289,19 @@ def create_proof(params, pk: ProvingKey, advice_usable, rng, msm=None) -> ProofT
     out.challenges["beta"] = beta
     out.challenges["gamma"] = gamma
 
+    # ---- permutation commit (permutation/prover.rs:47-198) ------------------
+    def column_values(col):
+        kind, idx = col
+        return {ADVICE: advice, FIXED: pk.fixed_values, INSTANCE: instance_values}[kind][idx]
+
+    perm_sets = []
+    if cs.perm_columns:
+        for z, _blind in permutation_commit(dom, cs.degree(), bf, cs.perm_columns, column_values, pk.permutations, beta, gamma, rng):
+            z_cm = commit_affine(msm(z, params.g_lagrange))
+            tr.write_point(z_cm)
+            perm_sets.append(dom.lagrange_to_coeff(z))
+            out.points.setdefault("perm_z", []).append(z_cm)
+
     # ---- CQ round 2 (static_lookup/prover.rs:187-342) ----------------------
     logd = []
     size_n = pk.table_cfg.size
@@ -277,10 +357,24 @@ def create_proof(params, pk: ProvingKey, advice_usable, rng, msm=None) -> ProofT
 
     advice_polys = [dom.lagrange_to_coeff(a) for a in advice]  # :587-603
 
-    # ---- evaluate_h (evaluation.rs:285-551): no gates => only the CQ term ---
-    # (advice cosets are computed by the reference at :317-325 but feed nothing here)
+    # ---- evaluate_h (evaluation.rs:285-551): gates, permutation, CQ terms ---
     ext = dom.extended_len
+    rot_scale = 1 << (dom.extended_k - dom.k)
     h = [0] * ext
+    advice_cosets = instance_cosets = None
+    if cs.gates or cs.perm_columns:
+        advice_cosets = [dom.coeff_to_extended(p_) for p_ in advice_polys]  # :317-335
+        instance_cosets = [dom.coeff_to_extended(p_) for p_ in instance_polys]
+        src = {ADVICE: advice_cosets, FIXED: pk.fixed_cosets, INSTANCE: instance_cosets}
+        for idx in range(ext):  # custom gates, Horner in y (:226-235, :348-365)
+            get = lambda kind, col, rot: src[kind][col][rotation_idx(idx, rot, rot_scale, ext)]
+            v = h[idx]
+            for g in cs.gates:
+                v = (v * y + expr_eval(g, get)) % P
+            h[idx] = v
+        z_cosets = [dom.coeff_to_extended(z) for z in perm_sets]
+        h = permutation_h_terms(dom, cs.degree(), bf, cs.perm_columns, lambda col: src[col[0]][col[1]], pk.perm_cosets,
+                                z_cosets, pk.l0, pk.l_last, pk.l_active_row, beta, gamma, y, h)
     for (b_poly, _b0, f_coeff, _a0) in logd:  # :533-548
         b_coset = dom.coeff_to_extended(b_poly)
         f_coset = dom.coeff_to_extended(f_coeff)
@@ -310,11 +404,22 @@ def create_proof(params, pk: ProvingKey, advice_usable, rng, msm=None) -> ProofT
     aq = cs.advice_queries()
     for col, rot in aq:
         tr.write_scalar(eval_polynomial(advice_polys[col], dom.rotate_omega(x, rot)))
+    for col, rot in cs.fixed_queries():  # :674-687
+        tr.write_scalar(eval_polynomial(pk.fixed_polys[col], dom.rotate_omega(x, rot)))
     # vanishing.evaluate (vanishing/prover.rs:124-153)
     h_poly = [0] * n
     for piece in reversed(h_pieces):
         h_poly = [(a * xn + b) % P for a, b in zip(h_poly, piece)]
     tr.write_scalar(eval_polynomial(random_poly, x))
+    for sp in pk.perm_polys:  # permutation::ProvingKey::evaluate (permutation/prover.rs:227-239)
+        tr.write_scalar(eval_polynomial(sp, x))
+    x_next = dom.rotate_omega(x, 1)
+    x_last = dom.rotate_omega(x, -(bf + 1))
+    for si, z in enumerate(perm_sets):  # Constructed::evaluate (:243-290)
+        tr.write_scalar(eval_polynomial(z, x))
+        tr.write_scalar(eval_polynomial(z, x_next))
+        if si + 1 < len(perm_sets):
+            tr.write_scalar(eval_polynomial(z, x_last))
     for (b_poly, b0, f_coeff, a_at_zero) in logd:  # static_lookup/prover.rs:360-370
         tr.write_scalar(eval_polynomial(b0, x))
         tr.write_scalar(eval_polynomial(f_coeff, x))
@@ -324,9 +429,18 @@ def create_proof(params, pk: ProvingKey, advice_usable, rng, msm=None) -> ProofT
     queries = []
     for col, rot in aq:
         queries.append((dom.rotate_omega(x, rot), advice_polys[col]))
+    for z in perm_sets:  # Evaluated::open (permutation/prover.rs:294-344)
+        queries.append((x, z))
+        queries.append((x_next, z))
+    for z in reversed(perm_sets[:-1]):
+        queries.append((x_last, z))
     for (b_poly, b0, f_coeff, _a) in logd:
         queries.append((x, b0))
         queries.append((x, f_coeff))
+    for col, rot in cs.fixed_queries():
+        queries.append((dom.rotate_omega(x, rot), pk.fixed_polys[col]))
+    for sp in pk.perm_polys:  # permutation::ProvingKey::open (:215-225)
+        queries.append((x, sp))
     queries.append((x, h_poly))
     queries.append((x, random_poly))
     v = tr.squeeze_challenge_scalar()

@@ -1,4 +1,4 @@
-"""TEST INFRASTRUCTURE ONLY -- acceptance oracle for CQ-only proofs.
+"""TEST INFRASTRUCTURE ONLY -- acceptance oracle for the proofs of oracle/cq_prover.py.
 
 Restates `plonk/verifier.rs:34-489`, `plonk/vanishing/verifier.rs`,
 `plonk/static_lookup/verifier.rs:117-221` and `poly/kzg/multiopen/gwc/verifier.rs:48-128`
@@ -27,6 +27,8 @@ from .bn254 import (
     to_jac,
     to_repr,
 )
+from .bn254 import FR_DELTA
+from .plonk import ADVICE, FIXED, expr_eval
 from .poly import EvaluationDomain
 
 P = R_MOD
@@ -93,12 +95,14 @@ def _eq(J1, J2):
 
 
 def verify_proof(proof: bytes, circuit, vk_repr: int, s: int, tables: dict, table_size: int,
-                 srs_g1_len: int) -> bool:
+                 srs_g1_len: int, instances=(), fixed_commitments=(), perm_commitments=()) -> bool:
     """Returns True iff every verifier equation holds.
 
     tables: id -> list of table values (given order); the committed table polynomial
     `t` interpolates the values in SORTED order (static_lookup.rs:139-146).
     srs_g1_len: the `srs_g1_len` handed to `StaticTableValues::commit` (static_lookup.rs:149).
+    instances: the public inputs per instance column; fixed_commitments / perm_commitments: the
+    verifying key's `fixed_commitments` and `permutation.commitments` (affine points).
     """
     cs = circuit
     dom = EvaluationDomain(cs.degree(), cs.k)
@@ -106,11 +110,17 @@ def verify_proof(proof: bytes, circuit, vk_repr: int, s: int, tables: dict, tabl
     bf = cs.blinding_factors()
     tr = Blake2bRead(proof)
     tr.common_scalar(vk_repr)
+    for vals in instances:  # verifier.rs:93-101
+        for v_ in vals:
+            tr.common_scalar(v_ % P)
     advice_cm = [tr.read_point() for _ in range(cs.num_advice)]
     theta = tr.squeeze()
     lk1 = [(tr.read_point(), tr.read_point()) for _ in cs.lookups]  # f, m
     beta = tr.squeeze()
-    _gamma = tr.squeeze()
+    gamma = tr.squeeze()
+    chunk_len = cs.degree() - 2
+    n_sets = (len(cs.perm_columns) + chunk_len - 1) // chunk_len
+    perm_z_cm = [tr.read_point() for _ in range(n_sets)]  # permutation/verifier.rs:37-57
     lk2 = [tuple(tr.read_point() for _ in range(5)) for _ in cs.lookups]  # a, qa, a0, b0, p
     random_cm = tr.read_point()
     y = tr.squeeze()
@@ -118,7 +128,15 @@ def verify_proof(proof: bytes, circuit, vk_repr: int, s: int, tables: dict, tabl
     x = tr.squeeze()
     aq = cs.advice_queries()
     advice_evals = [tr.read_scalar() for _ in aq]
+    fq = cs.fixed_queries()
+    fixed_evals = [tr.read_scalar() for _ in fq]
     random_eval = tr.read_scalar()
+    perm_common_evals = [tr.read_scalar() for _ in cs.perm_columns]  # permutation/verifier.rs:60-70
+    perm_evals = []
+    for si in range(n_sets):  # :73-105
+        ze, zn = tr.read_scalar(), tr.read_scalar()
+        zl = tr.read_scalar() if si + 1 < n_sets else None
+        perm_evals.append((ze, zn, zl))
     lk_evals = [(tr.read_scalar(), tr.read_scalar(), tr.read_scalar()) for _ in cs.lookups]
 
     xn = pow(x, n, P)
@@ -131,10 +149,52 @@ def verify_proof(proof: bytes, circuit, vk_repr: int, s: int, tables: dict, tabl
         l_evals.append(dom.rotate_omega(inv_mod((x - wr) % P, P) * common % P, r))
     l_last = l_evals[0]
     l_blind = sum(l_evals[1 : 1 + bf]) % P
+    l_0 = l_evals[1 + bf]
     active = (1 - (l_last + l_blind)) % P
+
+    # instance evaluations from the public inputs (verifier.rs:208-248): p(w^r x) = sum_i v_i l_i(w^r x)
+    iq = cs.instance_queries()
+    instance_evals = []
+    for col, rot in iq:
+        pt = dom.rotate_omega(x, rot)
+        ptn = pow(pt, n, P)
+        acc = 0
+        for i, v_ in enumerate(instances[col]):
+            wi = dom.rotate_omega(1, i)
+            li = (ptn - 1) * dom.barycentric_weight % P * wi % P * inv_mod((pt - wi) % P, P) % P
+            acc = (acc + v_ * li) % P
+        instance_evals.append(acc)
+
+    def query_eval(kind, col, rot):
+        if kind == ADVICE:
+            return advice_evals[aq.index((col, rot))]
+        if kind == FIXED:
+            return fixed_evals[fq.index((col, rot))]
+        return instance_evals[iq.index((col, rot))]
 
     # expressions (static_lookup/verifier.rs:182-221), folded by y (vanishing/verifier.rs:105-106)
     h_eval = 0
+    for g in cs.gates:  # verifier.rs:300-323
+        h_eval = (h_eval * y + expr_eval(g, query_eval)) % P
+    if n_sets:  # permutation/verifier.rs:108-206
+        exprs = [l_0 * (1 - perm_evals[0][0]) % P,
+                 (perm_evals[-1][0] * perm_evals[-1][0] - perm_evals[-1][0]) * l_last % P]
+        for si in range(1, n_sets):
+            exprs.append((perm_evals[si][0] - perm_evals[si - 1][2]) * l_0 % P)
+        for si in range(n_sets):
+            cols = cs.perm_columns[si * chunk_len : (si + 1) * chunk_len]
+            sig = perm_common_evals[si * chunk_len : (si + 1) * chunk_len]
+            left = perm_evals[si][1]
+            for (kind, idx), se in zip(cols, sig):
+                left = left * ((query_eval(kind, idx, 0) + beta * se + gamma) % P) % P
+            right = perm_evals[si][0]
+            cur_delta = beta * x % P * pow(FR_DELTA, si * chunk_len, P) % P
+            for kind, idx in cols:
+                right = right * ((query_eval(kind, idx, 0) + cur_delta + gamma) % P) % P
+                cur_delta = cur_delta * FR_DELTA % P
+            exprs.append((left - right) * active % P)
+        for e in exprs:
+            h_eval = (h_eval * y + e) % P
     beta_inv = inv_mod(beta, P)
     n_inv = inv_mod(n % P, P)
     for (b0_eval, f_eval, a_at_zero) in lk_evals:
@@ -151,9 +211,20 @@ def verify_proof(proof: bytes, circuit, vk_repr: int, s: int, tables: dict, tabl
     queries = []
     for (col, rot), ev in zip(aq, advice_evals):
         queries.append((dom.rotate_omega(x, rot), to_jac(advice_cm[col]), ev))
+    x_next = dom.rotate_omega(x, 1)
+    x_last = dom.rotate_omega(x, -(bf + 1))
+    for zc, (ze, zn, _zl) in zip(perm_z_cm, perm_evals):  # permutation/verifier.rs:208-252
+        queries.append((x, to_jac(zc), ze))
+        queries.append((x_next, to_jac(zc), zn))
+    for zc, (_ze, _zn, zl) in reversed(list(zip(perm_z_cm, perm_evals))[:-1]):
+        queries.append((x_last, to_jac(zc), zl))
     for (f_cm, _m), (a, qa, a0, b0, p_), (b0_eval, f_eval, _az) in zip(lk1, lk2, lk_evals):
         queries.append((x, to_jac(b0), b0_eval))
         queries.append((x, to_jac(f_cm), f_eval))
+    for (col, rot), ev in zip(fq, fixed_evals):  # verifier.rs:447-459
+        queries.append((dom.rotate_omega(x, rot), to_jac(fixed_commitments[col]), ev))
+    for cm_, ev in zip(perm_commitments, perm_common_evals):  # permutation/verifier.rs:255-268
+        queries.append((x, to_jac(cm_), ev))
     queries.append((x, h_commitment, expected_h_eval))
     queries.append((x, to_jac(random_cm), random_eval))
 

@@ -1,0 +1,247 @@
+"""TEST INFRASTRUCTURE ONLY -- constraint-system pieces of the CPU oracle beyond CQ lookups.
+
+Restates, with Python ints, the parts of the reference a general (gates + fixed/instance
+columns + copy constraints) circuit adds to the CQ-only path:
+
+* `Expression` (plonk/circuit.rs:780-1100) as nested tuples, its degree and evaluation
+  (`evaluate`, plonk/evaluation.rs:776-818; `get_rotation_idx` :37-39);
+* `permutation::keygen::Assembly` (plonk/permutation/keygen.rs:14-113) and `build_pk` (:151-208);
+* `permutation::Argument::commit` (plonk/permutation/prover.rs:47-198);
+* the permutation terms of `evaluate_h` (plonk/evaluation.rs:367-459).
+
+Parity status: no reference test pins any of these numerically (the permutation argument is only
+exercised end to end, `halo2_proofs/tests/plonk_api.rs`, with OsRng) -> "parity unpinned" beyond
+the verifier-side identities checked in `tests/test_oracle_plonk.py`.
+"""
+from __future__ import annotations
+
+from .bn254 import FR_DELTA, R_MOD, fr_random
+from .poly import batch_invert
+
+P = R_MOD
+
+ADVICE, FIXED, INSTANCE = "advice", "fixed", "instance"
+
+
+# ---- Expression -----------------------------------------------------------------------------------
+def const(v):
+    return ("const", v % P)
+
+
+def adv(col, rot=0):
+    return (ADVICE, col, rot)
+
+
+def fix(col, rot=0):
+    return (FIXED, col, rot)
+
+
+def inst(col, rot=0):
+    return (INSTANCE, col, rot)
+
+
+def neg(a):
+    return ("neg", a)
+
+
+def add(a, b):
+    return ("add", a, b)
+
+
+def sub(a, b):
+    """`a - b` is `a + (-b)` (circuit.rs:1105-1110)."""
+    return ("add", a, ("neg", b))
+
+
+def mul(a, b):
+    return ("mul", a, b)
+
+
+def scale(a, v):
+    return ("scale", a, v % P)
+
+
+def expr_degree(e) -> int:
+    """circuit.rs:1040-1056."""
+    t = e[0]
+    if t == "const":
+        return 0
+    if t in (ADVICE, FIXED, INSTANCE):
+        return 1
+    if t in ("neg", "scale"):
+        return expr_degree(e[1])
+    if t == "add":
+        return max(expr_degree(e[1]), expr_degree(e[2]))
+    if t == "mul":
+        return expr_degree(e[1]) + expr_degree(e[2])
+    raise ValueError(t)
+
+
+def expr_queries(e, out):
+    """Column queries in traversal order (the order `meta.query_*` calls register them in)."""
+    t = e[0]
+    if t in (ADVICE, FIXED, INSTANCE):
+        if (t, e[1], e[2]) not in out:
+            out.append((t, e[1], e[2]))
+    elif t in ("neg", "scale"):
+        expr_queries(e[1], out)
+    elif t in ("add", "mul"):
+        expr_queries(e[1], out)
+        expr_queries(e[2], out)
+
+
+def expr_eval(e, get):
+    """`Expression::evaluate` (circuit.rs:880-960); `get(kind, col, rot)` resolves a query."""
+    t = e[0]
+    if t == "const":
+        return e[1]
+    if t in (ADVICE, FIXED, INSTANCE):
+        return get(t, e[1], e[2])
+    if t == "neg":
+        return (-expr_eval(e[1], get)) % P
+    if t == "add":
+        return (expr_eval(e[1], get) + expr_eval(e[2], get)) % P
+    if t == "mul":
+        return expr_eval(e[1], get) * expr_eval(e[2], get) % P
+    if t == "scale":
+        return expr_eval(e[1], get) * e[2] % P
+    raise ValueError(t)
+
+
+def rotation_idx(idx: int, rot: int, rot_scale: int, size: int) -> int:
+    """evaluation.rs:37-39."""
+    return (idx + rot * rot_scale) % size
+
+
+# ---- permutation keygen ---------------------------------------------------------------------------
+class Assembly:
+    """permutation/keygen.rs:14-113: cycles of equal cells kept as a mapping + union-by-size."""
+
+    def __init__(self, n: int, columns):
+        self.columns = list(columns)
+        m = len(self.columns)
+        self.mapping = [[(i, j) for j in range(n)] for i in range(m)]
+        self.aux = [[(i, j) for j in range(n)] for i in range(m)]
+        self.sizes = [[1] * n for _ in range(m)]
+
+    def copy(self, left_column, left_row, right_column, right_row):
+        lc = self.columns.index(left_column)
+        rc = self.columns.index(right_column)
+        if left_row >= len(self.mapping[lc]) or right_row >= len(self.mapping[rc]):
+            raise IndexError("BoundsFailure")
+        left_cycle = self.aux[lc][left_row]
+        right_cycle = self.aux[rc][right_row]
+        if left_cycle == right_cycle:
+            return
+        if self.sizes[left_cycle[0]][left_cycle[1]] < self.sizes[right_cycle[0]][right_cycle[1]]:
+            left_cycle, right_cycle = right_cycle, left_cycle
+        self.sizes[left_cycle[0]][left_cycle[1]] += self.sizes[right_cycle[0]][right_cycle[1]]
+        i = right_cycle
+        while True:
+            self.aux[i[0]][i[1]] = left_cycle
+            i = self.mapping[i[0]][i[1]]
+            if i == right_cycle:
+                break
+        self.mapping[lc][left_row], self.mapping[rc][right_row] = self.mapping[rc][right_row], self.mapping[lc][left_row]
+
+
+def build_permutation_pk(dom, mapping):
+    """permutation/keygen.rs:151-208 -> (permutations, polys, cosets)."""
+    n = dom.n
+    omega_powers = [1] * n
+    for i in range(1, n):
+        omega_powers[i] = omega_powers[i - 1] * dom.omega % P
+    deltaomega = []
+    cur = 1
+    for _ in mapping:
+        deltaomega.append([o * cur % P for o in omega_powers])
+        cur = cur * FR_DELTA % P
+    perms, polys, cosets = [], [], []
+    for col in mapping:
+        lag = [deltaomega[pi][pj] for (pi, pj) in col]
+        perms.append(lag)
+        poly = dom.lagrange_to_coeff(lag)
+        polys.append(poly)
+        cosets.append(dom.coeff_to_extended(poly))
+    return perms, polys, cosets
+
+
+# ---- permutation prover ---------------------------------------------------------------------------
+def permutation_commit(dom, cs_degree, bf, columns, column_values, permutations, beta, gamma, rng):
+    """permutation/prover.rs:47-198 up to the Lagrange values of every z.
+
+    columns: the argument's columns; column_values(col) -> the n Lagrange values of that column.
+    Returns [(z_lagrange, blind)] per set, drawing `bf` blinding rows + 1 blind per set from rng."""
+    n = dom.n
+    assert cs_degree >= 3
+    chunk_len = cs_degree - 2
+    deltaomega = 1
+    last_z = 1
+    sets = []
+    for c0 in range(0, len(columns), chunk_len):
+        cols = columns[c0 : c0 + chunk_len]
+        perms = permutations[c0 : c0 + chunk_len]
+        modified = [1] * n
+        for col, perm in zip(cols, perms):  # :106-121
+            vals = column_values(col)
+            modified = [m * ((beta * s + gamma + v) % P) % P for m, s, v in zip(modified, perm, vals)]
+        modified = batch_invert(modified)  # :124
+        for col in cols:  # :128-147
+            vals = column_values(col)
+            dw = deltaomega
+            out = []
+            for m, v in zip(modified, vals):
+                out.append(m * ((dw * beta + gamma + v) % P) % P)
+                dw = dw * dom.omega % P
+            modified = out
+            deltaomega = deltaomega * FR_DELTA % P
+        z = [last_z]  # :160-166
+        for row in range(1, n):
+            z.append(z[row - 1] * modified[row - 1] % P)
+        for r in range(n - bf, n):  # :169-171
+            z[r] = fr_random(rng)
+        last_z = z[n - (bf + 1)]  # :173
+        blind = fr_random(rng)  # :175
+        sets.append((z, blind))
+    return sets
+
+
+def permutation_h_terms(dom, cs_degree, bf, columns, column_coset, perm_cosets, z_cosets, l0, l_last, l_active, beta,
+                        gamma, y, h):
+    """evaluation.rs:367-459: folds the permutation constraints into `h` (extended coset), in place."""
+    if not z_cosets:
+        return h
+    size = dom.extended_len
+    rot_scale = 1 << (dom.extended_k - dom.k)
+    chunk_len = cs_degree - 2
+    from .bn254 import FR_ZETA
+
+    delta_start = beta * FR_ZETA % P
+    last_rotation = -(bf + 1)
+    chunks = [columns[i : i + chunk_len] for i in range(0, len(columns), chunk_len)]
+    beta_term = 1
+    first, last = z_cosets[0], z_cosets[-1]
+    out = list(h)
+    for idx in range(size):
+        r_next = rotation_idx(idx, 1, rot_scale, size)
+        r_last = rotation_idx(idx, last_rotation, rot_scale, size)
+        v = out[idx]
+        v = (v * y + (1 - first[idx]) * l0[idx]) % P
+        v = (v * y + (last[idx] * last[idx] - last[idx]) * l_last[idx]) % P
+        for si in range(1, len(z_cosets)):
+            v = (v * y + (z_cosets[si][idx] - z_cosets[si - 1][r_last]) * l0[idx]) % P
+        current_delta = delta_start * beta_term % P
+        ci = 0
+        for si, cols in enumerate(chunks):
+            left = z_cosets[si][r_next]
+            for col in cols:
+                left = left * ((column_coset(col)[idx] + beta * perm_cosets[ci][idx] + gamma) % P) % P
+                ci += 1
+            right = z_cosets[si][idx]
+            for col in cols:
+                right = right * ((column_coset(col)[idx] + current_delta + gamma) % P) % P
+                current_delta = current_delta * FR_DELTA % P
+            v = (v * y + (left - right) * l_active[idx]) % P
+        out[idx] = v
+        beta_term = beta_term * dom.extended_omega % P
+    return out

@@ -1,0 +1,93 @@
+"""Synthetic general-PLONK circuits shared by the oracle tests (CPU) and the parity tests (GPU).
+
+The reference has no circuit with golden outputs for gates + copy constraints (its `plonk_api.rs`
+test draws from OsRng and only checks acceptance), so these small circuits are built here: an
+add/mul chain with next/prev rotations, a scaled-constant gate, an instance column, a fixed column
+inside the permutation, optionally a degree-5 gate (-> extended domain 4n, 3 columns per permutation
+set) and optionally a static (CQ) lookup next to them.
+"""
+from oracle import bn254 as B
+from oracle import cq_prover as CP
+from oracle import kzg
+from oracle import plonk as PL
+
+P = B.R_MOD
+A, F, I = PL.ADVICE, PL.FIXED, PL.INSTANCE
+TABLE = [0, 1, 6, 8, 10, 12, 14, 16, 18, 20, 22, 24, 26, 28, 30, 32]
+
+
+def chain_circuit(k, degree5=False, with_lookup=False, seed=1):
+    """Returns dict(circuit, fixed, advice, instances, mapping, tables)."""
+    n = 1 << k
+    q_add, q_mul, q_next, q_prev, q_fix, kc = range(6)
+    num_fixed = 6
+    a, b, c = PL.adv(0), PL.adv(1), PL.adv(2)
+    gates = [
+        PL.mul(PL.fix(q_add), PL.sub(PL.add(a, b), c)),
+        PL.mul(PL.fix(q_mul), PL.sub(PL.mul(a, b), c)),
+        PL.mul(PL.fix(q_next), PL.sub(PL.adv(0, 1), c)),
+        PL.mul(PL.fix(q_prev), PL.sub(a, PL.adv(2, -1))),
+        PL.mul(PL.fix(q_fix), PL.sub(PL.sub(PL.scale(a, 3), PL.fix(kc)), PL.const(5))),
+    ]
+    if degree5:
+        q_pow = num_fixed
+        num_fixed += 1
+        gates.append(PL.mul(PL.fix(q_pow), PL.sub(PL.mul(PL.mul(a, a), PL.mul(a, a)), c)))
+    num_advice = 4 if with_lookup else 3
+    lookups = [[(3, "t")]] if with_lookup else []
+    perm_columns = [(A, 0), (A, 1), (A, 2), (I, 0), (F, kc)]
+    circuit = CP.CqCircuit(k, num_advice, lookups, num_fixed, 1, gates, perm_columns)
+    bf = circuit.blinding_factors()
+    u = n - (bf + 1)
+    R = u - 2  # chain rows
+    rng = B.Xoshiro256ss(seed)
+    fixed = [[0] * n for _ in range(num_fixed)]
+    adv = [[0] * u for _ in range(num_advice)]
+    asm = PL.Assembly(n, perm_columns)
+    av, bv = B.fr_random(rng), B.fr_random(rng)
+    for r in range(R):
+        kind = "pow" if (degree5 and r % 5 == 4) else ("mul" if r % 2 else "add")
+        if kind == "add":
+            cv = (av + bv) % P
+            fixed[q_add][r] = 1
+        elif kind == "mul":
+            cv = av * bv % P
+            fixed[q_mul][r] = 1
+        else:
+            cv = pow(av, 4, P)
+            fixed[q_pow][r] = 1
+        adv[0][r], adv[1][r], adv[2][r] = av, bv, cv
+        if r + 1 < R:
+            fixed[q_next][r] = 1
+            fixed[q_prev][r + 1] = 1
+            asm.copy((A, 1), r + 1, (A, 0), r)  # b[r+1] == a[r]
+            av, bv = cv, av
+    # a fixed-constant row: kc = 3a - 5 on row 0
+    fixed[q_fix][0] = 1
+    fixed[kc][0] = (3 * adv[0][0] - 5) % P
+    fixed[kc][1] = adv[1][0]
+    asm.copy((F, kc), 1, (A, 1), 0)  # b[0] equals a constant
+    instances = [[adv[0][0], adv[2][R - 1]]]
+    asm.copy((I, 0), 0, (A, 0), 0)
+    asm.copy((I, 0), 1, (A, 2), R - 1)
+    asm.copy((A, 2), 3, (A, 2), 3)  # self copy: no-op (keygen.rs:75-77)
+    if with_lookup:
+        for r in range(u):
+            adv[3][r] = TABLE[(r * 7 + 3) % len(TABLE)]
+    return dict(circuit=circuit, fixed=fixed, advice=adv, instances=instances, mapping=asm.mapping,
+                tables={"t": TABLE} if with_lookup else {})
+
+
+def oracle_env(k, s_seed=0x6371, **kw):
+    """Oracle-side params / pk for `chain_circuit` (SRS layout of tests/my_test.rs:179-205: table SRS over the
+    table-sized domain, b0_g1_bound = [s^(n+1+i)]_1, srs_g1_len = 2n)."""
+    fx = chain_circuit(k, **kw)
+    s = B.fr_random(B.Xoshiro256ss(s_seed))
+    params = kzg.ParamsKZG(k, s)
+    n = 1 << k
+    tsrs = kzg.TableSRS(len(TABLE) - 1, s)
+    tabs = {name: kzg.StaticTableValues(v, tsrs.g1) for name, v in fx["tables"].items()}
+    b0 = kzg._powers_g1(s, 2 * n)[n + 1:]
+    pk = CP.keygen_pk(fx["circuit"], tabs, tsrs, b0, 424242, fixed=fx["fixed"], perm_mapping=fx["mapping"])
+    fx.update(s=s, params=params, pk=pk, tsrs=tsrs, tabs=tabs, srs_g1_len=2 * n)
+    return fx
