@@ -189,10 +189,62 @@ int cq_static_table_new(cq_ctx* ctx, size_t size, const uint64_t* values, const 
 void cq_static_table_destroy(cq_static_table* table);
 int cq_static_table_download_qs(cq_static_table* table, uint64_t* qs_affine);
 
-/* Shape of a CQ-only constraint system (stands in for ConstraintSystem, plonk/circuit.rs):
+/* Gate polynomials (`Expression`, plonk/circuit.rs:780-1100, as stored in vk.cs.gates after selector
+ * compression) cross the boundary as postfix programs of u32 words: word = op | arg << 8.  A column query
+ * (arg = column index) is followed by one word holding the rotation as int32.  CONST pushes
+ * constants[arg], SCALE multiplies the top of the stack by constants[arg] (Expression::Scaled),
+ * NEG/ADD/MUL are Expression::Negated/Sum/Product.  Each program must leave exactly one value. */
+#define CQ_GATE_CONST 0u
+#define CQ_GATE_ADVICE 1u
+#define CQ_GATE_FIXED 2u
+#define CQ_GATE_INSTANCE 3u
+#define CQ_GATE_NEG 4u
+#define CQ_GATE_ADD 5u
+#define CQ_GATE_MUL 6u
+#define CQ_GATE_SCALE 7u
+/* column kinds (`Any`, plonk/circuit.rs:141-160) */
+#define CQ_COL_ADVICE 0u
+#define CQ_COL_FIXED 1u
+#define CQ_COL_INSTANCE 2u
+
+/* The part of ConstraintSystem / ProvingKey a general circuit adds to the CQ-only shape: fixed and
+ * instance columns, custom gates, the permutation argument.  All host pointers, read during
+ * cq_pk_create only. */
+typedef struct {
+  uint32_t num_fixed;               /* cs.num_fixed_columns (+ compressed selector columns) */
+  uint32_t num_instance;            /* cs.num_instance_columns */
+  const uint64_t* const* fixed;     /* pk.fixed_values: num_fixed columns of 2^k elements (keygen.rs:320-326) */
+  uint32_t cs_degree;               /* vk.cs_degree = cs.degree() (circuit.rs:1979-2018); 0 = 3 */
+  uint32_t blinding_factors;        /* cs.blinding_factors() (circuit.rs:2022-2047); 0 = derive from advice queries */
+  /* cs.advice_queries / cs.fixed_queries in registration order; evaluations are written in this order
+   * (prover.rs:654-687).  When num_advice_queries == 0 the advice queries are derived as for a CQ-only
+   * circuit (one query at Rotation::cur() per lookup input, first-seen order). */
+  uint32_t num_advice_queries;
+  const uint32_t* advice_query_columns;
+  const int32_t* advice_query_rotations;
+  uint32_t num_fixed_queries;
+  const uint32_t* fixed_query_columns;
+  const int32_t* fixed_query_rotations;
+  /* gate polynomials in cs.gates order (evaluation.rs:226-235) */
+  uint32_t num_gate_polys;
+  const uint32_t* gate_program_lens;   /* words per polynomial */
+  const uint32_t* gate_programs;       /* concatenated */
+  uint32_t num_constants;
+  const uint64_t* constants;           /* num_constants field elements */
+  /* cs.permutation.columns (permutation.rs:20-38) and permutation::keygen::Assembly.mapping
+   * (permutation/keygen.rs:14-20): for column position c and row r, mapping[(c * 2^k + r) * 2] =
+   * permuted column position, [.. + 1] = permuted row.  NULL mapping = identity (no copy constraints). */
+  uint32_t num_perm_columns;
+  const uint32_t* perm_column_kinds;   /* CQ_COL_* */
+  const uint32_t* perm_column_indices;
+  const uint32_t* perm_mapping;
+} cq_plonk;
+
+/* Shape of the constraint system (stands in for ConstraintSystem, plonk/circuit.rs):
  * `num_advice` advice columns; lookup l has `lookup_widths[l]` (input, table) pairs; inputs are
  * advice[column] @ Rotation::cur() (lookup_static, circuit.rs:1579-1602), flattened in
- * lookup_columns / lookup_tables.  vk_repr = VerifyingKey::transcript_repr (plonk.rs:221-232). */
+ * lookup_columns / lookup_tables.  vk_repr = VerifyingKey::transcript_repr (plonk.rs:221-232).
+ * `plonk` = NULL for a CQ-only circuit (advice columns + static lookups). */
 typedef struct {
   uint32_t k;
   uint32_t num_advice;
@@ -201,10 +253,21 @@ typedef struct {
   const uint32_t* lookup_columns;
   cq_static_table* const* lookup_tables;
   uint64_t vk_repr[4];
+  const cq_plonk* plonk;
 } cq_circuit;
-/* keygen_pk (plonk/keygen.rs:278-397) restricted to what the CQ-only prover reads: the domain,
- * l_active_row on the extended coset (:366-373), the table config and `b0_g1_bound` (n-1 affine
- * points; device pointer if b0_on_device != 0, else host). */
+
+/* permutation::keygen::Assembly (permutation/keygen.rs:14-113): the copy-constraint bookkeeping keygen
+ * runs while synthesizing; `mapping` (columns * n * 2 words, layout above) starts as the identity from
+ * cq_permutation_assembly_init.  cq_permutation_assembly_copy merges the two cells' cycles exactly as
+ * Assembly::copy (:43-112); CQ_ERR_ARG on an out-of-range column / row (Error::BoundsFailure).
+ * `aux` and `sizes`: caller-provided scratch of columns*n*2 and columns*n words. */
+void cq_permutation_assembly_init(uint32_t columns, uint32_t n, uint32_t* mapping, uint32_t* aux, uint32_t* sizes);
+int cq_permutation_assembly_copy(uint32_t columns, uint32_t n, uint32_t* mapping, uint32_t* aux, uint32_t* sizes,
+                                 uint32_t left_column, uint32_t left_row, uint32_t right_column, uint32_t right_row);
+/* keygen_pk (plonk/keygen.rs:278-397): the domain, l0 / l_last / l_active_row on the extended coset
+ * (:338-373), fixed polys and cosets (:328-336), the permutation proving key (permutation/keygen.rs:151-208),
+ * the table config and `b0_g1_bound` (n-1 affine points; device pointer if b0_on_device != 0, else
+ * host; may be NULL when the circuit has no static lookup, as may `cfg`). */
 int cq_pk_create(cq_ctx* ctx, cq_params* params, const cq_circuit* circuit, cq_table_config* cfg,
                  const uint64_t* b0_g1_bound, int b0_on_device, cq_pk** out);
 /* Shards every commitment of cq_create_proof across `world` ranks by point range: rank r
@@ -224,6 +287,17 @@ int cq_create_proof(cq_pk* pk, const uint64_t* const* advice_dev, cq_rng_next_u6
 /* Same with host-resident advice columns (uploaded first). */
 int cq_create_proof_host(cq_pk* pk, const uint64_t* const* advice, cq_rng_next_u64 rng, void* rng_state,
                          uint8_t* proof, size_t proof_cap, size_t* proof_len);
+/* create_proof with public inputs (`instances: &[&[Fr]]`, prover.rs:64): `instances[c]` = HOST pointer to
+ * `instance_lens[c]` elements of instance column c (CQ_ERR_ARG if longer than usable_rows: "InstanceTooLarge",
+ * :108-110).  ProverGWC has QUERY_INSTANCE = false: the values are absorbed into the transcript (:305-312)
+ * and no instance commitment / evaluation is written.  `advice_on_device` selects the two variants above. */
+int cq_create_proof_instances(cq_pk* pk, const uint64_t* const* advice, int advice_on_device,
+                              const uint64_t* const* instances, const size_t* instance_lens, cq_rng_next_u64 rng,
+                              void* rng_state, uint8_t* proof, size_t proof_cap, size_t* proof_len);
+/* The verifying-key commitments the prover's key implies: commit_lagrange of every fixed column
+ * (keygen.rs:247-250) and of every permutation polynomial (permutation/keygen.rs:115-149), as affine
+ * points (num_fixed x 8 and num_perm_columns x 8 words). */
+int cq_pk_vk_commitments(cq_pk* pk, uint64_t* fixed_commitments, uint64_t* permutation_commitments);
 
 /* ---- sha/src/tables.rs: SHA-256 word -> limb witness fill ----------------------------------------- */
 /* Decomposes `nwords` 32-bit words (device) into 12/10/10-bit limbs (LongLimbs, tables.rs:70-75,

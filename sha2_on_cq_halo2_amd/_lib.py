@@ -127,6 +127,13 @@ def _declare(lib):  # noqa: F811
     lib.cq_pk_proof_size.argtypes = [vp]
     lib.cq_create_proof.argtypes = [vp, vp, vp, vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
     lib.cq_create_proof_host.argtypes = [vp, vp, vp, vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
+    lib.cq_create_proof_instances.argtypes = [vp, vp, C.c_int, vp, vp, vp, vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
+    lib.cq_pk_vk_commitments.argtypes = [vp, vp, vp]
+    u32p = C.POINTER(C.c_uint32)
+    lib.cq_permutation_assembly_init.restype = None
+    lib.cq_permutation_assembly_init.argtypes = [C.c_uint32, C.c_uint32, u32p, u32p, u32p]
+    lib.cq_permutation_assembly_copy.argtypes = [C.c_uint32, C.c_uint32, u32p, u32p, u32p, C.c_uint32, C.c_uint32,
+                                                 C.c_uint32, C.c_uint32]
     lib.cq_sha_witness_fill_dev.argtypes = [vp, vp, C.c_size_t, C.c_uint32, C.c_size_t, vp]
     lib.cq_sha_spread_table_dev.argtypes = [vp, C.c_size_t, vp, vp]
     lib.cq_xoshiro256ss_seed.restype = None

@@ -439,6 +439,31 @@ class StaticTable(_Handle):
         return q
 
 
+class _CqPlonk(C.Structure):
+    _fields_ = [
+        ("num_fixed", C.c_uint32),
+        ("num_instance", C.c_uint32),
+        ("fixed", C.POINTER(C.c_void_p)),
+        ("cs_degree", C.c_uint32),
+        ("blinding_factors", C.c_uint32),
+        ("num_advice_queries", C.c_uint32),
+        ("advice_query_columns", C.POINTER(C.c_uint32)),
+        ("advice_query_rotations", C.POINTER(C.c_int32)),
+        ("num_fixed_queries", C.c_uint32),
+        ("fixed_query_columns", C.POINTER(C.c_uint32)),
+        ("fixed_query_rotations", C.POINTER(C.c_int32)),
+        ("num_gate_polys", C.c_uint32),
+        ("gate_program_lens", C.POINTER(C.c_uint32)),
+        ("gate_programs", C.POINTER(C.c_uint32)),
+        ("num_constants", C.c_uint32),
+        ("constants", C.POINTER(C.c_uint64)),
+        ("num_perm_columns", C.c_uint32),
+        ("perm_column_kinds", C.POINTER(C.c_uint32)),
+        ("perm_column_indices", C.POINTER(C.c_uint32)),
+        ("perm_mapping", C.POINTER(C.c_uint32)),
+    ]
+
+
 class _CqCircuit(C.Structure):
     _fields_ = [
         ("k", C.c_uint32),
@@ -448,7 +473,56 @@ class _CqCircuit(C.Structure):
         ("lookup_columns", C.POINTER(C.c_uint32)),
         ("lookup_tables", C.POINTER(C.c_void_p)),
         ("vk_repr", C.c_uint64 * 4),
+        ("plonk", C.POINTER(_CqPlonk)),
     ]
+
+
+def _lower_plonk(cs, fixed, mapping, keep: list) -> _CqPlonk:
+    """`ConstraintSystem` (+ the keygen outputs `fixed_values`, `Assembly.mapping`) -> cq_plonk arrays."""
+    pl = _CqPlonk()
+    n_fixed = cs.num_fixed_columns
+    fixed = [_fr(f) for f in (fixed or [])]
+    assert len(fixed) == n_fixed, "one value column per fixed column (pk.fixed_values)"
+    fptrs = (C.c_void_p * max(n_fixed, 1))(*[f.ctypes.data for f in fixed])
+    keep += [fixed, fptrs]
+    pl.num_fixed, pl.num_instance = n_fixed, cs.num_instance_columns
+    pl.fixed = C.cast(fptrs, C.POINTER(C.c_void_p))
+    pl.cs_degree, pl.blinding_factors = cs.degree(), cs.blinding_factors()
+
+    def u32(vals):
+        a = (C.c_uint32 * max(len(vals), 1))(*vals)
+        keep.append(a)
+        return C.cast(a, C.POINTER(C.c_uint32))
+
+    def i32(vals):
+        a = (C.c_int32 * max(len(vals), 1))(*vals)
+        keep.append(a)
+        return C.cast(a, C.POINTER(C.c_int32))
+
+    pl.num_advice_queries = len(cs.advice_queries)
+    pl.advice_query_columns, pl.advice_query_rotations = u32([c for c, _ in cs.advice_queries]), i32([r for _, r in cs.advice_queries])
+    pl.num_fixed_queries = len(cs.fixed_queries)
+    pl.fixed_query_columns, pl.fixed_query_rotations = u32([c for c, _ in cs.fixed_queries]), i32([r for _, r in cs.fixed_queries])
+    constants, lens, words = [], [], []
+    for g in cs.gates:
+        prog = g.compile(constants)
+        lens.append(len(prog))
+        words += prog
+    pl.num_gate_polys, pl.gate_program_lens, pl.gate_programs = len(lens), u32(lens), u32(words)
+    cst = np.zeros((max(len(constants), 1), 4), dtype=np.uint64)
+    for i, v in enumerate(constants):
+        cst[i] = fr_to_mont(v)
+    keep.append(cst)
+    pl.num_constants, pl.constants = len(constants), cst.ctypes.data_as(C.POINTER(C.c_uint64))
+    pl.num_perm_columns = len(cs.permutation_columns)
+    pl.perm_column_kinds = u32([c.kind for c in cs.permutation_columns])
+    pl.perm_column_indices = u32([c.index for c in cs.permutation_columns])
+    if mapping is not None:
+        m = np.ascontiguousarray(mapping, dtype=np.uint32)
+        assert m.shape == (len(cs.permutation_columns), fixed[0].shape[0] if fixed else m.shape[1], 2)
+        keep.append(m)
+        pl.perm_mapping = m.ctypes.data_as(C.POINTER(C.c_uint32))
+    return pl
 
 
 class _BufferRng(C.Structure):
@@ -456,50 +530,80 @@ class _BufferRng(C.Structure):
 
 
 class ProvingKey(_Handle):
-    """The slice of `ProvingKey` (plonk.rs:291-308) that `create_proof` reads for a CQ-only circuit.
+    """The slice of `ProvingKey` (plonk.rs:291-308) that `create_proof` reads.
 
-    lookups: list of lookups, each a list of (advice column, StaticTable)."""
+    lookups: list of lookups, each a list of (advice column, StaticTable).  For a general circuit pass
+    `cs` (a `plonk.ConstraintSystem`: gates, fixed / instance columns, permutation columns; its static
+    lookups and advice column count replace `lookups` / `num_advice`), `fixed` (pk.fixed_values) and
+    `permutation` (`Assembly.mapping`); table_cfg / b0_g1_bound may be None without static lookups."""
 
     _destroy = "cq_pk_destroy"
 
     def __init__(self, ctx: Context, params: ParamsKZG, k: int, num_advice: int, lookups, table_cfg: TableConfig,
-                 b0_g1_bound, vk_repr: np.ndarray):
+                 b0_g1_bound, vk_repr: np.ndarray, cs=None, fixed=None, permutation=None):
         self.ctx, self.params, self.k = ctx, params, k
-        self._keep = (params, table_cfg, [t for lk in lookups for _, t in lk])
+        self.cs = cs
+        if cs is not None:
+            num_advice, lookups = cs.num_advice_columns, cs.static_lookups
+        self._keep = [params, table_cfg, [t for lk in lookups for _, t in lk]]
         widths = (C.c_uint32 * max(len(lookups), 1))(*[len(lk) for lk in lookups])
         flat_cols = [c for lk in lookups for c, _ in lk]
         flat_tabs = [t.h.value if isinstance(t.h, C.c_void_p) else t.h for lk in lookups for _, t in lk]
         cols = (C.c_uint32 * max(len(flat_cols), 1))(*flat_cols)
         tabs = (C.c_void_p * max(len(flat_tabs), 1))(*flat_tabs)
-        cs = _CqCircuit()
-        cs.k, cs.num_advice, cs.num_lookups = k, num_advice, len(lookups)
-        cs.lookup_widths = C.cast(widths, C.POINTER(C.c_uint32))
-        cs.lookup_columns = C.cast(cols, C.POINTER(C.c_uint32))
-        cs.lookup_tables = C.cast(tabs, C.POINTER(C.c_void_p))
+        cs_ = _CqCircuit()
+        cs_.k, cs_.num_advice, cs_.num_lookups = k, num_advice, len(lookups)
+        cs_.lookup_widths = C.cast(widths, C.POINTER(C.c_uint32))
+        cs_.lookup_columns = C.cast(cols, C.POINTER(C.c_uint32))
+        cs_.lookup_tables = C.cast(tabs, C.POINTER(C.c_void_p))
         vr = np.ascontiguousarray(vk_repr, dtype=np.uint64).reshape(4)
         for i in range(4):
-            cs.vk_repr[i] = int(vr[i])
+            cs_.vk_repr[i] = int(vr[i])
+        if cs is not None:
+            pl = _lower_plonk(cs, fixed, permutation, self._keep)
+            self._keep.append(pl)
+            cs_.plonk = C.pointer(pl)
         h = C.c_void_p()
-        if isinstance(b0_g1_bound, (int,)):
+        if b0_g1_bound is None:
+            b0_ptr, on_dev = None, 0
+        elif isinstance(b0_g1_bound, (int,)):
             b0_ptr, on_dev = b0_g1_bound, 1
         else:
             b0 = _g1(b0_g1_bound)
             assert b0.shape[0] == (1 << k) - 1, "b0_g1_bound must hold n-1 points (arithmetic.rs:133)"
             self._b0 = b0
             b0_ptr, on_dev = b0.ctypes.data, 0
-        ctx._chk(ctx.lib.cq_pk_create(ctx.h, params.h, C.byref(cs), table_cfg.h, b0_ptr, on_dev, C.byref(h)))
+        ctx._chk(ctx.lib.cq_pk_create(ctx.h, params.h, C.byref(cs_), table_cfg.h if table_cfg is not None else None, b0_ptr, on_dev,
+                                       C.byref(h)))
         self.h = h
         self.num_advice = num_advice
         self.usable_rows = ctx.lib.cq_pk_usable_rows(h)
         self.proof_size = ctx.lib.cq_pk_proof_size(h)
         ctx._children.add(self)
 
-    def _run(self, fn, ptrs, rng_fn, rng_state) -> bytes:
+    def _run(self, fn, ptrs, rng_fn, rng_state, instances=None, on_device=False) -> bytes:
         arr = (C.c_void_p * max(len(ptrs), 1))(*ptrs)
         proof = (C.c_uint8 * self.proof_size)()
         plen = C.c_size_t()
-        self.ctx._chk(fn(self.h, arr, rng_fn, rng_state, proof, self.proof_size, C.byref(plen)))
+        if instances is None:
+            self.ctx._chk(fn(self.h, arr, rng_fn, rng_state, proof, self.proof_size, C.byref(plen)))
+        else:  # `instances: &[&[Fr]]` (prover.rs:64)
+            cols = [_fr(i) if len(i) else np.zeros((0, 4), dtype=np.uint64) for i in instances]
+            iptr = (C.c_void_p * max(len(cols), 1))(*[c.ctypes.data for c in cols])
+            ilen = (C.c_size_t * max(len(cols), 1))(*[c.shape[0] for c in cols])
+            self.ctx._chk(self.ctx.lib.cq_create_proof_instances(self.h, arr, 1 if on_device else 0, iptr, ilen, rng_fn, rng_state,
+                                                                 proof, self.proof_size, C.byref(plen)))
         return bytes(proof[: plen.value])
+
+    def vk_commitments(self):
+        """(fixed_commitments, permutation commitments) of the matching verifying key: uint64[.,8] affine points
+        (keygen.rs:247-250, permutation/keygen.rs:115-149)."""
+        nf = self.cs.num_fixed_columns if self.cs is not None else 0
+        npc = len(self.cs.permutation_columns) if self.cs is not None else 0
+        f = np.zeros((max(nf, 1), 8), dtype=np.uint64)
+        p = np.zeros((max(npc, 1), 8), dtype=np.uint64)
+        self.ctx._chk(self.ctx.lib.cq_pk_vk_commitments(self.h, f.ctypes.data, p.ctypes.data))
+        return f[:nf], p[:npc]
 
     def _rng(self, rng_words=None, seed=None):
         lib = self.ctx.lib
@@ -513,17 +617,18 @@ class ProvingKey(_Handle):
         self._rng_keep = st
         return C.cast(lib.cq_xoshiro256ss_next_u64, C.c_void_p), C.cast(st, C.c_void_p)
 
-    def create_proof(self, advice, rng_words=None, seed=None) -> bytes:
+    def create_proof(self, advice, rng_words=None, seed=None, instances=None) -> bytes:
         """`create_proof` (plonk/prover.rs:51) with host advice columns (uint64[n,4] each; rows
-        beyond the usable rows are ignored).  RNG: a pre-drawn u64 stream or a xoshiro256** seed."""
+        beyond the usable rows are ignored) and public inputs `instances` (uint64[len,4] per instance
+        column).  RNG: a pre-drawn u64 stream or a xoshiro256** seed."""
         cols = [np.ascontiguousarray(a, dtype=np.uint64) for a in advice]
         assert len(cols) == self.num_advice and all(c.shape == (1 << self.k, 4) for c in cols)
         fn, st = self._rng(rng_words, seed)
-        return self._run(self.ctx.lib.cq_create_proof_host, [c.ctypes.data for c in cols], fn, st)
+        return self._run(self.ctx.lib.cq_create_proof_host, [c.ctypes.data for c in cols], fn, st, instances)
 
-    def create_proof_dev(self, advice_ptrs, rng_words=None, seed=None) -> bytes:
+    def create_proof_dev(self, advice_ptrs, rng_words=None, seed=None, instances=None) -> bytes:
         fn, st = self._rng(rng_words, seed)
-        return self._run(self.ctx.lib.cq_create_proof, list(advice_ptrs), fn, st)
+        return self._run(self.ctx.lib.cq_create_proof, list(advice_ptrs), fn, st, instances, on_device=True)
 
 
 def _ctx_msm_precompute(self, bases_ptr: int, n: int):

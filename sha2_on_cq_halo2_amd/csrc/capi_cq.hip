@@ -4,6 +4,7 @@
 #include <vector>
 #include "cq.hpp"
 #include "ctx.hpp"
+#include "plonk.hpp"
 #include "prover.hpp"
 #include "setup.hpp"
 #include "msm.hpp"
@@ -171,12 +172,20 @@ int cq_static_table_download_qs(cq_static_table* t, uint64_t* qs_affine) {
 }
 
 // ---- proving key -------------------------------------------------------------------------------------
+// frees whatever a partially built key owns; `rc` is passed through
+static int pk_abort(cq_pk* pk, int rc) {
+  cq_pk_destroy(pk);
+  return rc;
+}
+
 int cq_pk_create(cq_ctx* c, cq_params* params, const cq_circuit* cs, cq_table_config* cfg, const uint64_t* b0_g1_bound,
                  int b0_on_device, cq_pk** out) {
-  if (!c || !params || !cs || !cfg || !b0_g1_bound || !out) return CQ_ERR_ARG;
+  if (!c || !params || !cs || !out) return CQ_ERR_ARG;
+  if (cs->num_lookups && (!cfg || !b0_g1_bound)) return c->fail(CQ_ERR_ARG, "pk: static lookups need a table config and b0_g1_bound");
   if (cs->k != params->k) return c->fail(CQ_ERR_ARG, "pk: circuit k differs from params k");
   if (cs->num_lookups > CQ_MAX_LOOKUPS) return c->fail(CQ_ERR_ARG, "pk: too many lookups");
   CQ_HIP(c, hipSetDevice(c->device));
+  const cq_plonk* pl = cs->plonk;
   cq_pk* pk = new cq_pk();
   pk->ctx = c;
   pk->params = params;
@@ -184,83 +193,179 @@ int cq_pk_create(cq_ctx* c, cq_params* params, const cq_circuit* cs, cq_table_co
   pk->num_advice = cs->num_advice;
   pk->table_cfg = cfg;
   pk->vk_repr = Fr::from_limbs64(cs->vk_repr);
+  const size_t n = (size_t)1 << pk->k;
   size_t off = 0;
-  std::vector<uint32_t> per_col(cs->num_advice, 0);
   for (uint32_t l = 0; l < cs->num_lookups; l++) {
     cq_lookup_desc d;
     const uint32_t w = cs->lookup_widths[l];
-    if (w == 0 || w > CQ_MAX_WIDTH) {
-      delete pk;
-      return c->fail(CQ_ERR_ARG, "pk: lookup width out of range");
-    }
+    if (w == 0 || w > CQ_MAX_WIDTH) return pk_abort(pk, c->fail(CQ_ERR_ARG, "pk: lookup width out of range"));
     for (uint32_t j = 0; j < w; j++) {
       const uint32_t col = cs->lookup_columns[off + j];
       cq_static_table* t = cs->lookup_tables[off + j];
-      if (col >= cs->num_advice || !t) {
-        delete pk;
-        return c->fail(CQ_ERR_ARG, "pk: bad lookup column / table");
-      }
-      if (t->N != cfg->N) {  // "Tables should all be of the same size" (static_lookup/prover.rs:81-83)
-        delete pk;
-        return c->fail(CQ_ERR_ARG, "pk: table size differs from the table config");
-      }
+      if (col >= cs->num_advice || !t) return pk_abort(pk, c->fail(CQ_ERR_ARG, "pk: bad lookup column / table"));
+      // "Tables should all be of the same size" (static_lookup/prover.rs:81-83)
+      if (t->N != cfg->N) return pk_abort(pk, c->fail(CQ_ERR_ARG, "pk: table size differs from the table config"));
       d.cols.push_back(col);
       d.tables.push_back(t);
       // query_advice_index (plonk/circuit.rs:1619-1633)
-      if (std::find(pk->advice_queries.begin(), pk->advice_queries.end(), std::make_pair(col, 0u)) == pk->advice_queries.end()) {
-        pk->advice_queries.push_back({col, 0u});
-        per_col[col]++;
-      }
+      if (!(pl && pl->num_advice_queries) &&
+          std::find(pk->advice_queries.begin(), pk->advice_queries.end(), std::make_pair(col, (int32_t)0)) == pk->advice_queries.end())
+        pk->advice_queries.push_back({col, 0});
     }
     off += w;
     pk->lookups.push_back(d);
   }
-  // blinding_factors (plonk/circuit.rs:2022-2047)
-  uint32_t factors = 1;
-  for (uint32_t v : per_col) factors = std::max(factors, v);
-  if (per_col.empty()) factors = 1;
-  factors = std::max(3u, factors);
-  pk->bf = factors + 2;
-  const size_t n = (size_t)1 << pk->k;
-  if (n < (size_t)pk->bf + 3) {  // minimum_rows (circuit.rs:2051-2059)
-    delete pk;
-    return c->fail(CQ_ERR_ARG, "pk: not enough rows available");
+  if (pl) {
+    pk->num_fixed = pl->num_fixed;
+    pk->num_instance = pl->num_instance;
+    pk->cs_degree = pl->cs_degree ? pl->cs_degree : 3;
+    if (pk->cs_degree < 3 || pk->cs_degree - 2 > PERM_MAX_CHUNK) return pk_abort(pk, c->fail(CQ_ERR_ARG, "pk: cs_degree out of range"));
+    if (pl->num_perm_columns > PERM_MAX_COLUMNS) return pk_abort(pk, c->fail(CQ_ERR_ARG, "pk: too many permutation columns"));
+    if ((pl->num_fixed && !pl->fixed) || (pl->num_gate_polys && (!pl->gate_program_lens || !pl->gate_programs)) ||
+        (pl->num_constants && !pl->constants) || (pl->num_perm_columns && (!pl->perm_column_kinds || !pl->perm_column_indices)))
+      return pk_abort(pk, c->fail(CQ_ERR_ARG, "pk: null pointer in cq_plonk"));
+    for (uint32_t q = 0; q < pl->num_advice_queries; q++) {
+      if (pl->advice_query_columns[q] >= cs->num_advice) return pk_abort(pk, c->fail(CQ_ERR_ARG, "pk: advice query column out of range"));
+      pk->advice_queries.push_back({pl->advice_query_columns[q], pl->advice_query_rotations[q]});
+    }
+    for (uint32_t q = 0; q < pl->num_fixed_queries; q++) {
+      if (pl->fixed_query_columns[q] >= pl->num_fixed) return pk_abort(pk, c->fail(CQ_ERR_ARG, "pk: fixed query column out of range"));
+      pk->fixed_queries.push_back({pl->fixed_query_columns[q], pl->fixed_query_rotations[q]});
+    }
+    for (uint32_t q = 0; q < pl->num_perm_columns; q++) {
+      const uint32_t kind = pl->perm_column_kinds[q], idx = pl->perm_column_indices[q];
+      const uint32_t lim = kind == CQ_COL_ADVICE ? cs->num_advice : kind == CQ_COL_FIXED ? pl->num_fixed : kind == CQ_COL_INSTANCE ? pl->num_instance : 0;
+      if (idx >= lim) return pk_abort(pk, c->fail(CQ_ERR_ARG, "pk: permutation column out of range"));
+      pk->perm_columns.push_back({kind, idx});
+    }
   }
+  // blinding_factors (plonk/circuit.rs:2022-2047)
+  if (pl && pl->blinding_factors) {
+    pk->bf = pl->blinding_factors;
+  } else {
+    std::vector<uint32_t> per_col(cs->num_advice, 0);
+    for (auto& q : pk->advice_queries) per_col[q.first]++;
+    uint32_t factors = 1;
+    for (uint32_t v : per_col) factors = std::max(factors, v);
+    pk->bf = std::max(3u, factors) + 2;
+  }
+  if (n < (size_t)pk->bf + 3)  // minimum_rows (circuit.rs:2051-2059)
+    return pk_abort(pk, c->fail(CQ_ERR_ARG, "pk: not enough rows available"));
   pk->u = (uint32_t)(n - (pk->bf + 1));
   int rc;
-  // degree 3 = max(3, 2 + input degree 1) (static_lookup.rs:181-190)
-  if ((rc = domain_create(c, 3, pk->k, &pk->domain)) != CQ_OK) {
-    delete pk;
-    return rc;
-  }
+  // extended domain for cs.degree(): 3 for permutation / static lookups (static_lookup.rs:181-190), more with gates
+  if ((rc = domain_create(c, pk->cs_degree, pk->k, &pk->domain)) != CQ_OK) return pk_abort(pk, rc);
+  const size_t ext = pk->domain->ext();
+  void* tmp;
+  if ((rc = c->ensure_scratch(1, n * sizeof(Fr), &tmp)) != CQ_OK) return pk_abort(pk, rc);
   // l_active_row = 1 - (l_last + l_blind) on the extended coset (keygen.rs:344-373); by linearity it is
   // the coset extension of the indicator of the usable rows
-  const size_t ext = pk->domain->ext();
-  if (hipMalloc(&pk->l_active_row, ext * sizeof(Fr)) != hipSuccess) return c->fail(CQ_ERR_HIP, "hipMalloc(l_active_row)");
-  void* tmp;
-  if ((rc = c->ensure_scratch(1, n * sizeof(Fr), &tmp)) != CQ_OK) return rc;
-  if ((rc = poly_fill_usable_rows(c, (Fr*)tmp, (uint32_t)n, pk->u)) != CQ_OK) return rc;
-  if ((rc = domain_lagrange_to_coeff(pk->domain, (Fr*)tmp, (Fr*)tmp, 1, n, n)) != CQ_OK) return rc;
-  if ((rc = domain_coeff_to_extended(pk->domain, (Fr*)tmp, pk->l_active_row, 1, n, ext)) != CQ_OK) return rc;
+  if (hipMalloc(&pk->l_active_row, ext * sizeof(Fr)) != hipSuccess) return pk_abort(pk, c->fail(CQ_ERR_HIP, "hipMalloc(l_active_row)"));
+  if ((rc = poly_fill_usable_rows(c, (Fr*)tmp, (uint32_t)n, pk->u)) != CQ_OK) return pk_abort(pk, rc);
+  if ((rc = domain_lagrange_to_coeff(pk->domain, (Fr*)tmp, (Fr*)tmp, 1, n, n)) != CQ_OK) return pk_abort(pk, rc);
+  if ((rc = domain_coeff_to_extended(pk->domain, (Fr*)tmp, pk->l_active_row, 1, n, ext)) != CQ_OK) return pk_abort(pk, rc);
+  if (pk->general()) {
+    // l0 (keygen.rs:340-345) and l_last (:357-363): unit vectors at rows 0 and n - bf - 1
+    const Fr one = Fr::one();
+    for (int which = 0; which < 2; which++) {
+      Fr** dst = which ? &pk->l_last : &pk->l0;
+      if (hipMalloc(dst, ext * sizeof(Fr)) != hipSuccess) return pk_abort(pk, c->fail(CQ_ERR_HIP, "hipMalloc(l0/l_last)"));
+      CQ_HIP(c, hipMemsetAsync(tmp, 0, n * sizeof(Fr), c->stream));
+      CQ_HIP(c, hipMemcpyAsync((Fr*)tmp + (which ? n - pk->bf - 1 : 0), &one, sizeof(Fr), hipMemcpyHostToDevice, c->stream));
+      CQ_HIP(c, hipStreamSynchronize(c->stream));
+      if ((rc = domain_lagrange_to_coeff(pk->domain, (Fr*)tmp, (Fr*)tmp, 1, n, n)) != CQ_OK) return pk_abort(pk, rc);
+      if ((rc = domain_coeff_to_extended(pk->domain, (Fr*)tmp, *dst, 1, n, ext)) != CQ_OK) return pk_abort(pk, rc);
+    }
+  }
+  if (pk->num_fixed) {
+    const size_t F = pk->num_fixed;
+    if (hipMalloc(&pk->fixed_values, F * n * sizeof(Fr)) != hipSuccess || hipMalloc(&pk->fixed_polys, F * n * sizeof(Fr)) != hipSuccess ||
+        hipMalloc(&pk->fixed_cosets, F * ext * sizeof(Fr)) != hipSuccess)
+      return pk_abort(pk, c->fail(CQ_ERR_HIP, "hipMalloc(fixed columns)"));
+    for (size_t f = 0; f < F; f++)
+      CQ_HIP(c, hipMemcpyAsync(pk->fixed_values + f * n, pl->fixed[f], n * sizeof(Fr), hipMemcpyHostToDevice, c->stream));
+    if ((rc = domain_lagrange_to_coeff(pk->domain, pk->fixed_values, pk->fixed_polys, (uint32_t)F, n, n)) != CQ_OK) return pk_abort(pk, rc);
+    if ((rc = domain_coeff_to_extended(pk->domain, pk->fixed_polys, pk->fixed_cosets, (uint32_t)F, n, ext)) != CQ_OK) return pk_abort(pk, rc);
+  }
+  if (pl && pl->num_gate_polys) {
+    const char* why = nullptr;
+    size_t words = 0;
+    if (!gate_program_check(pl->gate_program_lens, pl->gate_programs, pl->num_gate_polys, pl->num_constants, cs->num_advice,
+                            pl->num_fixed, pl->num_instance, &why, &words))
+      return pk_abort(pk, c->fail(CQ_ERR_ARG, why));
+    std::vector<uint32_t> blob;
+    size_t o = 0;
+    for (uint32_t g = 0; g < pl->num_gate_polys; g++) {
+      blob.push_back(pl->gate_program_lens[g]);
+      blob.insert(blob.end(), pl->gate_programs + o, pl->gate_programs + o + pl->gate_program_lens[g]);
+      o += pl->gate_program_lens[g];
+    }
+    pk->num_gate_polys = pl->num_gate_polys;
+    if (hipMalloc(&pk->gate_prog, blob.size() * sizeof(uint32_t)) != hipSuccess) return pk_abort(pk, c->fail(CQ_ERR_HIP, "hipMalloc(gate program)"));
+    CQ_HIP(c, hipMemcpy(pk->gate_prog, blob.data(), blob.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    if (hipMalloc(&pk->constants, std::max<size_t>(pl->num_constants, 1) * sizeof(Fr)) != hipSuccess)
+      return pk_abort(pk, c->fail(CQ_ERR_HIP, "hipMalloc(gate constants)"));
+    if (pl->num_constants) CQ_HIP(c, hipMemcpy(pk->constants, pl->constants, pl->num_constants * sizeof(Fr), hipMemcpyHostToDevice));
+  }
+  if (!pk->perm_columns.empty()) {
+    // permutation::keygen::Assembly::build_pk (permutation/keygen.rs:151-208)
+    const size_t PC = pk->perm_columns.size();
+    if (hipMalloc(&pk->omega_powers, n * sizeof(Fr)) != hipSuccess || hipMalloc(&pk->perm_values, PC * n * sizeof(Fr)) != hipSuccess ||
+        hipMalloc(&pk->perm_polys, PC * n * sizeof(Fr)) != hipSuccess || hipMalloc(&pk->perm_cosets, PC * ext * sizeof(Fr)) != hipSuccess)
+      return pk_abort(pk, c->fail(CQ_ERR_HIP, "hipMalloc(permutation key)"));
+    if ((rc = fr_powers(c, pk->domain->omega, (uint32_t)n, pk->omega_powers)) != CQ_OK) return pk_abort(pk, rc);
+    std::vector<uint32_t> ident;
+    const uint32_t* mapping = pl->perm_mapping;
+    if (!mapping) {
+      ident.resize(PC * n * 2);
+      for (size_t col = 0; col < PC; col++)
+        for (size_t r = 0; r < n; r++) {
+          ident[(col * n + r) * 2] = (uint32_t)col;
+          ident[(col * n + r) * 2 + 1] = (uint32_t)r;
+        }
+      mapping = ident.data();
+    } else {
+      for (size_t cell = 0; cell < PC * n; cell++)
+        if (mapping[2 * cell] >= PC || mapping[2 * cell + 1] >= n) return pk_abort(pk, c->fail(CQ_ERR_ARG, "pk: permutation mapping out of range"));
+    }
+    std::vector<Fr> dp(PC);
+    const Fr delta = fr_from_raw(FR_DELTA_RAW);
+    Fr cur = Fr::one();
+    for (size_t col = 0; col < PC; col++) {
+      dp[col] = cur;
+      cur = cur * delta;
+    }
+    void* stage;
+    if ((rc = c->ensure_scratch(2, PC * n * 2 * sizeof(uint32_t) + PC * sizeof(Fr), &stage)) != CQ_OK) return pk_abort(pk, rc);
+    Fr* dp_dev = (Fr*)stage;
+    uint32_t* map_dev = (uint32_t*)(dp_dev + PC);
+    CQ_HIP(c, hipMemcpy(dp_dev, dp.data(), PC * sizeof(Fr), hipMemcpyHostToDevice));
+    CQ_HIP(c, hipMemcpy(map_dev, mapping, PC * n * 2 * sizeof(uint32_t), hipMemcpyHostToDevice));
+    if ((rc = perm_sigma(c, map_dev, (uint32_t)PC, (uint32_t)n, pk->omega_powers, dp_dev, pk->perm_values)) != CQ_OK) return pk_abort(pk, rc);
+    if ((rc = domain_lagrange_to_coeff(pk->domain, pk->perm_values, pk->perm_polys, (uint32_t)PC, n, n)) != CQ_OK) return pk_abort(pk, rc);
+    if ((rc = domain_coeff_to_extended(pk->domain, pk->perm_polys, pk->perm_cosets, (uint32_t)PC, n, ext)) != CQ_OK) return pk_abort(pk, rc);
+  }
   // b0_g1_bound: n-1 points (best_multiexp asserts equal lengths, arithmetic.rs:133)
-  if (b0_on_device) {
-    pk->b0_g1_bound = (G1Affine*)b0_g1_bound;
-  } else {
-    if (hipMalloc(&pk->b0_g1_bound, (n - 1) * sizeof(G1Affine)) != hipSuccess) return c->fail(CQ_ERR_HIP, "hipMalloc(b0 bound)");
-    pk->own_b0 = true;
-    CQ_HIP(c, hipMemcpyAsync(pk->b0_g1_bound, b0_g1_bound, (n - 1) * sizeof(G1Affine), hipMemcpyHostToDevice, c->stream));
+  if (b0_g1_bound) {
+    if (b0_on_device) {
+      pk->b0_g1_bound = (G1Affine*)b0_g1_bound;
+    } else {
+      if (hipMalloc(&pk->b0_g1_bound, (n - 1) * sizeof(G1Affine)) != hipSuccess) return pk_abort(pk, c->fail(CQ_ERR_HIP, "hipMalloc(b0 bound)"));
+      pk->own_b0 = true;
+      CQ_HIP(c, hipMemcpyAsync(pk->b0_g1_bound, b0_g1_bound, (n - 1) * sizeof(G1Affine), hipMemcpyHostToDevice, c->stream));
+    }
   }
   // per lookup: [qs_0 | qs_1 | ...] so that q_a is one MSM
   for (auto& lk : pk->lookups) {
     G1Affine* cat = nullptr;
     const size_t N = cfg->N;
-    if (hipMalloc(&cat, lk.tables.size() * N * sizeof(G1Affine)) != hipSuccess) return c->fail(CQ_ERR_HIP, "hipMalloc(qs)");
+    if (hipMalloc(&cat, lk.tables.size() * N * sizeof(G1Affine)) != hipSuccess) return pk_abort(pk, c->fail(CQ_ERR_HIP, "hipMalloc(qs)"));
+    pk->qs_concat.push_back(cat);
     for (size_t j = 0; j < lk.tables.size(); j++)
       CQ_HIP(c, hipMemcpyAsync(cat + j * N, lk.tables[j]->qs, N * sizeof(G1Affine), hipMemcpyDeviceToDevice, c->stream));
-    pk->qs_concat.push_back(cat);
-    if (c->msm_precompute && (rc = msm_register_tables(c, cat, lk.tables.size() * N)) != CQ_OK) return rc;
+    if (c->msm_precompute && (rc = msm_register_tables(c, cat, lk.tables.size() * N)) != CQ_OK) return pk_abort(pk, rc);
   }
-  if (c->msm_precompute && (rc = msm_register_tables(c, pk->b0_g1_bound, n - 1)) != CQ_OK) return rc;
+  if (pk->b0_g1_bound && c->msm_precompute && (rc = msm_register_tables(c, pk->b0_g1_bound, n - 1)) != CQ_OK) return pk_abort(pk, rc);
   CQ_HIP(c, hipStreamSynchronize(c->stream));
   *out = pk;
   return CQ_OK;
@@ -280,7 +385,11 @@ void cq_pk_destroy(cq_pk* pk) {
   hipStreamSynchronize(pk->ctx->stream);
   if (pk->domain) domain_destroy(pk->domain);
   if (pk->l_active_row) hipFree(pk->l_active_row);
-  msm_unregister_tables(pk->ctx, pk->b0_g1_bound);
+  for (void* p : {(void*)pk->fixed_values, (void*)pk->fixed_polys, (void*)pk->fixed_cosets, (void*)pk->l0, (void*)pk->l_last,
+                  (void*)pk->gate_prog, (void*)pk->constants, (void*)pk->perm_values, (void*)pk->perm_polys, (void*)pk->perm_cosets,
+                  (void*)pk->omega_powers})
+    if (p) hipFree(p);
+  if (pk->b0_g1_bound) msm_unregister_tables(pk->ctx, pk->b0_g1_bound);
   if (pk->own_b0 && pk->b0_g1_bound) hipFree(pk->b0_g1_bound);
   for (auto p : pk->qs_concat) {
     msm_unregister_tables(pk->ctx, p);
@@ -293,19 +402,31 @@ uint32_t cq_pk_usable_rows(const cq_pk* pk) { return pk ? pk->u : 0; }
 
 size_t cq_pk_proof_size(const cq_pk* pk) {
   if (!pk) return 0;
-  const size_t L = pk->lookups.size();
-  const size_t points = pk->num_advice + 2 * L + 5 * L + 1 + pk->domain->quotient_poly_degree + 1;
-  const size_t scalars = pk->advice_queries.size() + 1 + 3 * L;
+  const size_t L = pk->lookups.size(), S = pk->perm_sets();
+  // one opening witness per distinct evaluation point (gwc/prover.rs:42-91)
+  std::vector<int32_t> rots{0};
+  auto seen = [&](int32_t r) {
+    if (std::find(rots.begin(), rots.end(), r) == rots.end()) rots.push_back(r);
+  };
+  for (auto& q : pk->advice_queries) seen(q.second);
+  for (auto& q : pk->fixed_queries) seen(q.second);
+  if (S) seen(1);
+  if (S > 1) seen(-(int32_t)(pk->bf + 1));
+  const size_t points = pk->num_advice + 2 * L + S + 5 * L + 1 + pk->domain->quotient_poly_degree + rots.size();
+  const size_t scalars = pk->advice_queries.size() + pk->fixed_queries.size() + 1 + pk->perm_columns.size() + (S ? 3 * S - 1 : 0) + 3 * L;
   return 32 * (points + scalars);
 }
 
-int cq_create_proof(cq_pk* pk, const uint64_t* const* advice_dev, cq_rng_next_u64 rng, void* rng_state, uint8_t* proof,
-                    size_t proof_cap, size_t* proof_len) {
+static int create_proof_any(cq_pk* pk, const uint64_t* const* advice_dev, const uint64_t* const* instances,
+                            const size_t* instance_lens, cq_rng_next_u64 rng, void* rng_state, uint8_t* proof,
+                            size_t proof_cap, size_t* proof_len) {
   if (!pk || (!advice_dev && pk->num_advice) || !rng || !proof || !proof_len) return CQ_ERR_ARG;
   cq_ctx* c = pk->ctx;
+  // "InvalidInstances" (prover.rs:73-82)
+  if (pk->num_instance && (!instances || !instance_lens)) return c->fail(CQ_ERR_ARG, "create_proof: instance columns missing");
   CQ_HIP(c, hipSetDevice(c->device));
   std::vector<uint8_t> out;
-  int rc = create_proof_dev(pk, advice_dev, rng, rng_state, out);
+  int rc = create_proof_dev(pk, advice_dev, instances, instance_lens, rng, rng_state, out);
   if (rc != CQ_OK) return rc;
   if (out.size() > proof_cap) return c->fail(CQ_ERR_ARG, "proof buffer too small");
   memcpy(proof, out.data(), out.size());
@@ -313,8 +434,14 @@ int cq_create_proof(cq_pk* pk, const uint64_t* const* advice_dev, cq_rng_next_u6
   return CQ_OK;
 }
 
-int cq_create_proof_host(cq_pk* pk, const uint64_t* const* advice, cq_rng_next_u64 rng, void* rng_state, uint8_t* proof,
-                         size_t proof_cap, size_t* proof_len) {
+int cq_create_proof(cq_pk* pk, const uint64_t* const* advice_dev, cq_rng_next_u64 rng, void* rng_state, uint8_t* proof,
+                    size_t proof_cap, size_t* proof_len) {
+  return create_proof_any(pk, advice_dev, nullptr, nullptr, rng, rng_state, proof, proof_cap, proof_len);
+}
+
+static int create_proof_host_any(cq_pk* pk, const uint64_t* const* advice, const uint64_t* const* instances,
+                                 const size_t* instance_lens, cq_rng_next_u64 rng, void* rng_state, uint8_t* proof,
+                                 size_t proof_cap, size_t* proof_len) {
   if (!pk || (!advice && pk->num_advice)) return CQ_ERR_ARG;
   cq_ctx* c = pk->ctx;
   CQ_HIP(c, hipSetDevice(c->device));
@@ -328,7 +455,41 @@ int cq_create_proof_host(cq_pk* pk, const uint64_t* const* advice, cq_rng_next_u
     CQ_HIP(c, hipMemcpyAsync(d, advice[a], (size_t)pk->u * sizeof(Fr), hipMemcpyHostToDevice, c->stream));
     ptrs[a] = (const uint64_t*)d;
   }
-  return cq_create_proof(pk, ptrs.data(), rng, rng_state, proof, proof_cap, proof_len);
+  return create_proof_any(pk, ptrs.data(), instances, instance_lens, rng, rng_state, proof, proof_cap, proof_len);
+}
+
+int cq_create_proof_host(cq_pk* pk, const uint64_t* const* advice, cq_rng_next_u64 rng, void* rng_state, uint8_t* proof,
+                         size_t proof_cap, size_t* proof_len) {
+  return create_proof_host_any(pk, advice, nullptr, nullptr, rng, rng_state, proof, proof_cap, proof_len);
+}
+
+int cq_create_proof_instances(cq_pk* pk, const uint64_t* const* advice, int advice_on_device, const uint64_t* const* instances,
+                              const size_t* instance_lens, cq_rng_next_u64 rng, void* rng_state, uint8_t* proof,
+                              size_t proof_cap, size_t* proof_len) {
+  return advice_on_device ? create_proof_any(pk, advice, instances, instance_lens, rng, rng_state, proof, proof_cap, proof_len)
+                          : create_proof_host_any(pk, advice, instances, instance_lens, rng, rng_state, proof, proof_cap, proof_len);
+}
+
+// fixed_commitments (keygen.rs:247-250) and permutation::VerifyingKey::commitments (permutation/keygen.rs:115-149)
+int cq_pk_vk_commitments(cq_pk* pk, uint64_t* fixed_commitments, uint64_t* permutation_commitments) {
+  if (!pk) return CQ_ERR_ARG;
+  cq_ctx* c = pk->ctx;
+  CQ_HIP(c, hipSetDevice(c->device));
+  const size_t n = (size_t)1 << pk->k;
+  for (int which = 0; which < 2; which++) {
+    const size_t cnt = which ? pk->perm_columns.size() : pk->num_fixed;
+    uint64_t* dst = which ? permutation_commitments : fixed_commitments;
+    const Fr* src = which ? pk->perm_values : pk->fixed_values;
+    if (!cnt) continue;
+    if (!dst) return c->fail(CQ_ERR_ARG, "vk commitments: null output");
+    for (size_t i = 0; i < cnt; i++) {
+      uint64_t jac[12];
+      int rc = cq_commit_lagrange_dev(pk->params, (const uint64_t*)(src + i * n), n, jac);
+      if (rc != CQ_OK) return rc;
+      if ((rc = cq_g1_to_affine(jac, dst + 8 * i)) != CQ_OK) return rc;
+    }
+  }
+  return CQ_OK;
 }
 
 // ---- SHA witness fill --------------------------------------------------------------------------------
@@ -437,3 +598,40 @@ uint64_t cq_buffer_rng_next_u64(void* st) {
 }
 
 }  // extern "C"
+
+// ---- permutation::keygen::Assembly (permutation/keygen.rs:14-113), host bookkeeping ---------------------------
+void cq_permutation_assembly_init(uint32_t columns, uint32_t n, uint32_t* mapping, uint32_t* aux, uint32_t* sizes) {
+  // every cell starts as its own 1-cycle: mapping == aux == identity (:22-41)
+  for (uint32_t col = 0; col < columns; col++)
+    for (uint32_t r = 0; r < n; r++) {
+      const size_t cell = (size_t)col * n + r;
+      mapping[2 * cell] = aux[2 * cell] = col;
+      mapping[2 * cell + 1] = aux[2 * cell + 1] = r;
+      sizes[cell] = 1;
+    }
+}
+
+int cq_permutation_assembly_copy(uint32_t columns, uint32_t n, uint32_t* mapping, uint32_t* aux, uint32_t* sizes,
+                                 uint32_t left_column, uint32_t left_row, uint32_t right_column, uint32_t right_row) {
+  if (!mapping || !aux || !sizes) return CQ_ERR_ARG;
+  if (left_column >= columns || right_column >= columns) return CQ_ERR_ARG;  // Error::ColumnNotInPermutation
+  if (left_row >= n || right_row >= n) return CQ_ERR_ARG;                    // Error::BoundsFailure (:62-66)
+  auto cell = [&](uint32_t col, uint32_t row) { return (size_t)col * n + row; };
+  size_t left = cell(left_column, left_row), right = cell(right_column, right_row);
+  size_t left_cycle = cell(aux[2 * left], aux[2 * left + 1]);
+  size_t right_cycle = cell(aux[2 * right], aux[2 * right + 1]);
+  if (left_cycle == right_cycle) return CQ_OK;  // already in the same cycle (:75-77)
+  if (sizes[left_cycle] < sizes[right_cycle]) std::swap(left_cycle, right_cycle);
+  // merge the right cycle into the left one (:83-93)
+  sizes[left_cycle] += sizes[right_cycle];
+  const uint32_t lc_col = (uint32_t)(left_cycle / n), lc_row = (uint32_t)(left_cycle % n);
+  size_t i = right_cycle;
+  do {
+    aux[2 * i] = lc_col;
+    aux[2 * i + 1] = lc_row;
+    i = cell(mapping[2 * i], mapping[2 * i + 1]);
+  } while (i != right_cycle);
+  std::swap(mapping[2 * left], mapping[2 * right]);  // :95-97
+  std::swap(mapping[2 * left + 1], mapping[2 * right + 1]);
+  return CQ_OK;
+}

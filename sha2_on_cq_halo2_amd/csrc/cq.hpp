@@ -84,11 +84,32 @@ struct cq_pk {
   cq_domain* domain = nullptr;
   uint32_t k, num_advice, bf, u;
   std::vector<cq_lookup_desc> lookups;
-  std::vector<std::pair<uint32_t, uint32_t>> advice_queries;  // (column, rotation=0), first-seen order
+  std::vector<std::pair<uint32_t, int32_t>> advice_queries;  // (column, rotation), registration order
   cq_table_config* table_cfg;
   cq::G1Affine* b0_g1_bound = nullptr;  // n-1 points
   bool own_b0 = false;
   cq::Fr* l_active_row = nullptr;       // extended coset
+  // ---- general PLONK part (empty for a CQ-only circuit) ----
+  uint32_t num_fixed = 0, num_instance = 0, cs_degree = 3;
+  std::vector<std::pair<uint32_t, int32_t>> fixed_queries;
+  cq::Fr* fixed_values = nullptr;   // num_fixed x n   (pk.fixed_values, keygen.rs:320-326)
+  cq::Fr* fixed_polys = nullptr;    // num_fixed x n   (:328-331)
+  cq::Fr* fixed_cosets = nullptr;   // num_fixed x ext (:333-336)
+  cq::Fr* l0 = nullptr;             // ext (:340-345)
+  cq::Fr* l_last = nullptr;         // ext (:357-363)
+  uint32_t num_gate_polys = 0;
+  uint32_t* gate_prog = nullptr;    // device: [len, words...] per polynomial
+  cq::Fr* constants = nullptr;      // device
+  std::vector<std::pair<uint32_t, uint32_t>> perm_columns;  // (CQ_COL_*, index) = cs.permutation.columns
+  cq::Fr* perm_values = nullptr;    // columns x n   (permutation::ProvingKey::permutations)
+  cq::Fr* perm_polys = nullptr;     // columns x n   (::polys)
+  cq::Fr* perm_cosets = nullptr;    // columns x ext (::cosets)
+  cq::Fr* omega_powers = nullptr;   // omega^i, i < n
+  bool general() const { return num_gate_polys || !perm_columns.empty(); }
+  size_t perm_sets() const {
+    const size_t chunk = cs_degree - 2;
+    return (perm_columns.size() + chunk - 1) / chunk;
+  }
   cq::Fr vk_repr;
   std::vector<cq::G1Affine*> qs_concat;  // per lookup: [qs_0 | qs_1 | ...] (width*N points)
   // MSM sharding across ranks (one process per GPU): every rank commits its slice of each point range,

@@ -370,6 +370,10 @@ static constexpr uint64_t FR_ROOT_OF_UNITY_RAW[4] = {0xd34f1ed960c37c9cull, 0x32
 static constexpr uint64_t FR_ZETA_RAW[4] = {0xb8ca0b2d36636f23ull, 0xcc37a73fec2bc5e9ull,
                                             0x048b6e193fd84104ull, 0x30644e72e131a029ull};
 
+// DELTA = 7^(2^28): generator of the t-order multiplicative subgroup (fr.rs:112-118)
+static constexpr uint64_t FR_DELTA_RAW[4] = {0x870e56bbe533e9a2ull, 0x5b5f898e5e963f25ull,
+                                             0x64ec26aad4c86e71ull, 0x09226b6e22c6f0caull};
+
 inline Fr fr_from_raw(const uint64_t* raw) {
   return Fr::from_limbs64(raw) * Fr::r2();
 }

@@ -148,12 +148,12 @@ __global__ __launch_bounds__(256) void cq_b_denominators_kernel(const Fr* __rest
 
 // ---- quotient numerator, CQ terms only, then / (X^n - 1)  (evaluation.rs:533-548, domain.rs:319-338) ----
 // h = Horner_y over lookups of (b * (f * l_active + beta) - 1), times t_evaluations[i mod t_len]
-__global__ __launch_bounds__(256) void cq_quotient_kernel(CqQuotientArgs args, uint32_t ext, Fr* __restrict__ h) {
+__global__ __launch_bounds__(256) void cq_quotient_kernel(CqQuotientArgs args, uint32_t ext, Fr* h) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= ext) return;
   const Fr la = ld(args.l_active + i);
   const Fr one = Fr::one();
-  Fr acc = Fr::zero();
+  Fr acc = args.h_in ? ld(args.h_in + i) : Fr::zero();
   for (uint32_t l = 0; l < args.count; l++) {
     const Fr b = ld(args.b[l] + i), f = ld(args.f[l] + i);
     acc = acc * args.y + (b * (f * la + args.beta) - one);

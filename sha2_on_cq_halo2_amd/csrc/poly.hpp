@@ -37,6 +37,7 @@ struct CqQuotientArgs {
   const Fr* b[CQ_MAX_LOOKUPS];
   const Fr* f[CQ_MAX_LOOKUPS];
   uint32_t count;
+  const Fr* h_in;  // terms folded so far (gates, permutation), or nullptr
   const Fr* l_active;
   const Fr* t_evals;
   uint32_t t_len;

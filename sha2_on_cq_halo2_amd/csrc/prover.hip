@@ -1,17 +1,18 @@
-// Host orchestrator: `create_proof` for CQ-only circuits (halo2_proofs/src/plonk/prover.rs:51-779),
-// with the sub-arguments of plonk/static_lookup/prover.rs, plonk/vanishing/prover.rs,
-// plonk/evaluation.rs:533-548 and poly/kzg/multiopen/gwc/prover.rs.  Everything O(n) runs on the GPU
+// Host orchestrator: `create_proof` (halo2_proofs/src/plonk/prover.rs:51-779) with the sub-arguments
+// of plonk/static_lookup/prover.rs, plonk/permutation/prover.rs, plonk/vanishing/prover.rs,
+// plonk/evaluation.rs:285-551 and poly/kzg/multiopen/gwc/prover.rs.  Everything O(n) runs on the GPU
 // (polynomials never leave HBM); the host keeps the Fiat-Shamir transcript (transcript.rs:170-241),
 // draws the blinding scalars from the caller's RNG in the reference's order, folds MSM window sums
 // and normalises the handful of commitment points.  Call order, RNG order and transcript order are
 // the contract: the proof bytes equal the reference's for
 // the same (pk, witness, RNG stream).
 //
-// Scope: constraint systems with advice columns and static lookups whose inputs are
-// `advice[col] @ Rotation::cur()` -- the shape of the reference's one CQ test (tests/my_test.rs).
-// Gates, fixed/instance columns, permutations and legacy lookups are "next" rows.
-// One deliberate omission: evaluation.rs:317-325 also transforms every advice polynomial to the
-// extended coset although no CQ-only term reads them; that dead work is not reproduced.
+// Scope: one circuit with advice / fixed / instance columns, custom gates (postfix programs, plonk.hip),
+// the permutation argument and static lookups whose inputs are `advice[col] @ Rotation::cur()` (the shape
+// of the reference's one CQ test, tests/my_test.rs).  Not built: legacy (plookup-style) lookups,
+// multi-phase challenges, SHPLONK.  One deliberate omission: evaluation.rs:317-335 transforms
+// every advice / instance polynomial to the extended coset even when no term reads them (a CQ-only
+// circuit); that dead work is skipped.
 #include <algorithm>
 #include <cstring>
 #include <vector>
@@ -19,6 +20,7 @@
 #include "cq.hpp"
 #include "ctx.hpp"
 #include "msm.hpp"
+#include "plonk.hpp"
 #include "prover.hpp"
 
 using namespace cq;
@@ -189,34 +191,138 @@ int commit_batch(const cq_pk* pk, const std::vector<const Fr*>& scalars, const s
 
 namespace cq {
 
-size_t prover_arena_elems(const cq_pk* pk) {
-  const size_t n = (size_t)1 << pk->k, ext = pk->domain->ext();
-  const size_t L = pk->lookups.size(), A = pk->num_advice, N = pk->table_cfg->N;
-  size_t wsum = 0;
-  for (auto& lk : pk->lookups) wsum += lk.cols.size();
-  size_t e = 0;
-  e += A * n;          // advice (lagrange -> coeff in place)
-  e += 3 * L * n;      // f_lagrange, f_coeff, b
-  e += n;              // random poly
-  e += 2 * L * ext;    // cosets
-  e += ext;            // h on the extended coset
-  e += ext;            // h coefficients (n*(j-1) = 2n)
-  e += 2 * n;          // gwc batch poly + witness
-  e += N + (L * N + 8) + L * N * 2 + wsum * N;  // t, den, a, m_fr, a_scaled
-  e += 2 * n;          // rng staging (64 B per element = 2 Fr)
-  e += L * N / 8 + 64; // m_counts (u32) + error word
-  return e + 1024;
+namespace {
+
+// Proof-lifetime device buffers, carved from one arena (scratch slot 6).  With base == nullptr the same
+// code only counts elements.
+struct Arena {
+  Fr* base;
+  size_t used = 0;
+  Fr* take(size_t elems) {
+    Fr* p = base ? base + used : nullptr;
+    used += elems;
+    return p;
+  }
+};
+struct Buffers {
+  Fr *adv, *inst_lag, *inst_coeff, *f_lag, *f_coeff, *bpoly, *random_poly, *z, *mv, *cosets, *adv_cosets, *inst_cosets,
+      *z_cosets, *h_ext, *h_coeff, *gwc_batch, *gwc_wit, *t_comp, *den, *a_val, *m_fr, *a_scaled;
+  uint64_t* rng_dev;
+  uint32_t *m_counts, *err_dev;
+};
+
+std::vector<int32_t> opening_rotations(const cq_pk* pk) {
+  std::vector<int32_t> rots{0};
+  auto seen = [&](int32_t r) {
+    if (std::find(rots.begin(), rots.end(), r) == rots.end()) rots.push_back(r);
+  };
+  for (auto& q : pk->advice_queries) seen(q.second);
+  for (auto& q : pk->fixed_queries) seen(q.second);
+  if (pk->perm_sets()) seen(1);
+  if (pk->perm_sets() > 1) seen(-(int32_t)(pk->bf + 1));
+  return rots;
 }
 
-int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, cq_rng_next_u64 rng_next, void* rng_state,
+void carve(const cq_pk* pk, Arena& ar, Buffers& b) {
+  const size_t n = (size_t)1 << pk->k, ext = pk->domain->ext();
+  const size_t L = pk->lookups.size(), A = pk->num_advice, I = pk->num_instance, S = pk->perm_sets();
+  const size_t N = pk->table_cfg ? pk->table_cfg->N : 0;
+  const bool general = pk->general();
+  size_t wsum = 0;
+  for (auto& lk : pk->lookups) wsum += lk.cols.size();
+  const size_t npts = opening_rotations(pk).size();
+  b.adv = ar.take(A * n);            // advice (lagrange -> coeff in place)
+  b.inst_lag = ar.take(I * n);
+  b.inst_coeff = ar.take(I * n);
+  b.f_lag = ar.take(L * n);
+  b.f_coeff = ar.take(L * n);
+  b.bpoly = ar.take(L * n);
+  b.random_poly = ar.take(n);
+  b.z = ar.take(S * n);              // permutation products (lagrange -> coeff in place)
+  b.mv = ar.take(S * n);
+  b.cosets = ar.take(2 * L * ext);   // b, f on the extended coset
+  b.adv_cosets = ar.take(general ? A * ext : 0);
+  b.inst_cosets = ar.take(general ? I * ext : 0);
+  b.z_cosets = ar.take(S * ext);
+  b.h_ext = ar.take(ext);
+  b.h_coeff = ar.take(ext);          // n * (degree - 1) coefficients
+  b.gwc_batch = ar.take(npts * n);
+  b.gwc_wit = ar.take(npts * n);
+  b.t_comp = ar.take(N);
+  b.den = ar.take(L * N + 8);
+  b.a_val = ar.take(L * N);
+  b.m_fr = ar.take(L * N);
+  b.a_scaled = ar.take(wsum * N);
+  b.rng_dev = (uint64_t*)ar.take(2 * n);  // 64 B per element = 2 Fr
+  b.m_counts = (uint32_t*)ar.take(L * N / 8 + 64);
+  b.err_dev = b.m_counts ? b.m_counts + L * N : nullptr;
+}
+
+// sum_i coeff_i * p_i - sub_const, any number of terms (LINCOMB_MAX per launch; later launches fold the
+// partial result back in as one more term)
+struct Term {
+  const Fr* p;
+  uint32_t len;
+  Fr coeff;
+};
+int lincomb_many(cq_ctx* c, const std::vector<Term>& terms, const Fr& sub_const, uint32_t n, Fr* out) {
+  size_t done = 0;
+  bool first = true;
+  do {
+    LincombArgs la;
+    la.count = 0;
+    la.sub_const = Fr::zero();
+    if (!first) {
+      la.p[0] = out;
+      la.len[0] = n;
+      la.coeff[0] = Fr::one();
+      la.count = 1;
+    }
+    while (done < terms.size() && la.count < LINCOMB_MAX) {
+      la.p[la.count] = terms[done].p;
+      la.len[la.count] = terms[done].len;
+      la.coeff[la.count] = terms[done].coeff;
+      la.count++;
+      done++;
+    }
+    if (done == terms.size()) la.sub_const = sub_const;
+    int rc = poly_lincomb(c, la, n, out);
+    if (rc != CQ_OK) return rc;
+    first = false;
+  } while (done < terms.size());
+  return CQ_OK;
+}
+
+int eval_many(cq_ctx* c, const std::vector<const Fr*>& ps, const std::vector<uint32_t>& ls, const Fr& z, Fr* out) {
+  for (size_t off = 0; off < ps.size(); off += EVAL_MAX_BATCH) {
+    const uint32_t cnt = (uint32_t)std::min((size_t)EVAL_MAX_BATCH, ps.size() - off);
+    int rc = poly_eval_batch(c, ps.data() + off, ls.data() + off, cnt, z, out + off);
+    if (rc != CQ_OK) return rc;
+  }
+  return CQ_OK;
+}
+
+}  // namespace
+
+size_t prover_arena_elems(const cq_pk* pk) {
+  Arena ar{nullptr};
+  Buffers b;
+  carve(pk, ar, b);
+  return ar.used + 1024;
+}
+
+int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, const uint64_t* const* instances,
+                     const size_t* instance_lens, cq_rng_next_u64 rng_next, void* rng_state,
                      std::vector<uint8_t>& proof_out) {
   cq_ctx* c = pk->ctx;
   cq_domain* dom = pk->domain;
   const uint32_t k = pk->k;
   const size_t n = (size_t)1 << k, ext = dom->ext();
   const uint32_t bf = pk->bf, u = pk->u;
-  const size_t L = pk->lookups.size(), A = pk->num_advice;
-  const size_t N = pk->table_cfg->N;
+  const size_t L = pk->lookups.size(), A = pk->num_advice, I = pk->num_instance;
+  const size_t N = pk->table_cfg ? pk->table_cfg->N : 0;
+  const size_t S = pk->perm_sets(), PC = pk->perm_columns.size(), chunk_len = pk->cs_degree - 2;
+  const bool general = pk->general();
   hipStream_t s = c->stream;
   Rng rng{rng_next, rng_state};
   Transcript tr;
@@ -224,39 +330,35 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, cq_rng_next_u
   // ---- carve the arena --------------------------------------------------------------------------
   void* arena_v;
   CQ_TRY(c->ensure_scratch(6, prover_arena_elems(pk) * sizeof(Fr), &arena_v));
-  Fr* cur = (Fr*)arena_v;
-  auto take = [&](size_t elems) {
-    Fr* p = cur;
-    cur += elems;
-    return p;
-  };
-  Fr* adv = take(A * n);
-  Fr* f_lag = take(L * n);
-  Fr* f_coeff = take(L * n);
-  Fr* bpoly = take(L * n);
-  Fr* random_poly = take(n);
-  Fr* cosets = take(2 * L * ext);
-  Fr* h_ext = take(ext);
-  Fr* h_coeff = take(ext);
-  Fr* gwc_batch = take(n);
-  Fr* gwc_wit = take(n);
-  Fr* t_comp = take(N);
-  Fr* den = take(L * N + 8);
-  Fr* a_val = take(L * N);
-  Fr* m_fr = take(L * N);
-  size_t wsum = 0;
-  for (auto& lk : pk->lookups) wsum += lk.cols.size();
-  Fr* a_scaled = take(wsum * N);
-  uint64_t* rng_dev = (uint64_t*)take(2 * n);
-  uint32_t* m_counts = (uint32_t*)take(L * N / 8 + 64);
-  uint32_t* err_dev = m_counts + L * N;
+  Arena ar{(Fr*)arena_v};
+  Buffers B;
+  carve(pk, ar, B);
+  Fr *adv = B.adv, *f_lag = B.f_lag, *f_coeff = B.f_coeff, *bpoly = B.bpoly, *random_poly = B.random_poly, *cosets = B.cosets,
+     *h_ext = B.h_ext, *h_coeff = B.h_coeff, *t_comp = B.t_comp, *den = B.den, *a_val = B.a_val, *m_fr = B.m_fr,
+     *a_scaled = B.a_scaled;
+  uint64_t* rng_dev = B.rng_dev;
+  uint32_t *m_counts = B.m_counts, *err_dev = B.err_dev;
 
   // prover.rs:85 -- vk.hash_into(transcript)
   tr.common_scalar(pk->vk_repr);
 
+  // ---- instance columns (prover.rs:100-131), absorbed as scalars in phase 0 (:305-312) ---------------
+  if (I) {
+    CQ_HIP(c, hipMemsetAsync(B.inst_lag, 0, I * n * sizeof(Fr), s));
+    for (size_t i = 0; i < I; i++) {
+      if (instance_lens[i] > u) return c->fail(CQ_ERR_ARG, "Error::InstanceTooLarge");  // :108-110
+      if (instance_lens[i])
+        CQ_HIP(c, hipMemcpyAsync(B.inst_lag + i * n, instances[i], instance_lens[i] * sizeof(Fr), hipMemcpyHostToDevice, s));
+    }
+    CQ_TRY(domain_lagrange_to_coeff(dom, B.inst_lag, B.inst_coeff, (uint32_t)I, n, n));
+    for (size_t i = 0; i < I; i++)
+      for (size_t r = 0; r < instance_lens[i]; r++) tr.common_scalar(Fr::from_limbs64(instances[i] + 4 * r));
+  }
+
   // ---- advice: copy in, blind rows u..n (prover.rs:346-350), one unused blind per column (:352-355) ----
   for (size_t a = 0; a < A; a++)
     CQ_HIP(c, hipMemcpyAsync(adv + a * n, advice_dev[a], (size_t)u * sizeof(Fr), hipMemcpyDeviceToDevice, s));
+  std::vector<Fr> z_tails(S * bf);
   {
     std::vector<Fr> tails(A * (n - u));
     for (size_t a = 0; a < A; a++)
@@ -275,10 +377,15 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, cq_rng_next_u
     for (size_t a = 0; a < A; a++) sc[a] = adv + a * n;
     Commit adv_cm;
     if (A) CQ_TRY(adv_cm.begin(pk, sc, bs, ln));
-    // The next draws from the RNG are the vanishing argument's n coefficients + 1 blind
+    // The next draws from the RNG are, per permutation set, `bf` blinding rows of z and one blind
+    // (permutation/prover.rs:169-175), then the vanishing argument's n coefficients + 1 blind
     // (vanishing/prover.rs:51-55): the CQ rounds in between draw nothing, so taking them now keeps the
     // stream order, overlaps the host-side draws with the advice MSMs, and lets the random
     // polynomial's commitment ride along with round 2's launch.
+    for (size_t st = 0; st < S; st++) {
+      for (uint32_t r = 0; r < bf; r++) z_tails[st * bf + r] = rng.fr();
+      (void)rng.fr();  // permutation_product_blind
+    }
     uint64_t* w = (uint64_t*)pin;
     for (size_t i = 0; i < n; i++) rng.words(w + 8 * i);
     (void)rng.fr();  // random_blind
@@ -297,7 +404,7 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, cq_rng_next_u
   const Fr theta = tr.squeeze();  // :472
 
   // ---- CQ round 1 (static_lookup/prover.rs:51-183) ------------------------------------------------
-  CQ_HIP(c, hipMemsetAsync(m_counts, 0, (L * N + 16) * sizeof(uint32_t), s));
+  if (L) CQ_HIP(c, hipMemsetAsync(m_counts, 0, (L * N + 16) * sizeof(uint32_t), s));
   for (size_t l = 0; l < L; l++) {
     const cq_lookup_desc& lk = pk->lookups[l];
     const uint32_t w = (uint32_t)lk.cols.size();
@@ -324,14 +431,12 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, cq_rng_next_u
     CQ_TRY(cq_round1(c, ra, u, m_counts + l * N, err_dev));
     CQ_TRY(cq_m_to_fr(c, m_counts + l * N, (uint32_t)N, m_fr + l * N));
   }
-  {
+  if (L) {
     uint32_t herr = 0;
     CQ_HIP(c, hipMemcpyAsync(&herr, err_dev, 4, hipMemcpyDeviceToHost, s));
     CQ_HIP(c, hipStreamSynchronize(s));
     if (herr == 1) return c->fail(CQ_ERR_LOOKUP, "witness value not in table");
     if (herr == 2) return c->fail(CQ_ERR_LOOKUP, "Vector lookup must be on the same table row");
-  }
-  if (L) {
     // f_cm (:165) and m_cm (:167-172, as a dense MSM over the table SRS): one launch
     std::vector<const Fr*> sc;
     std::vector<const G1Affine*> bs;
@@ -346,8 +451,54 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, cq_rng_next_u
     }
   }
   const Fr beta = tr.squeeze();   // prover.rs:529
-  (void)tr.squeeze();             // gamma (:532), unused without permutations / legacy lookups
+  const Fr gamma = tr.squeeze();  // :532
   const Fr beta_inv = beta.inv();
+
+  // ---- permutation::Argument::commit (permutation/prover.rs:47-198): Lagrange values of every z ----------
+  auto column_values = [&](const std::pair<uint32_t, uint32_t>& col) -> const Fr* {
+    return col.first == CQ_COL_ADVICE ? adv + (size_t)col.second * n
+         : col.first == CQ_COL_FIXED  ? pk->fixed_values + (size_t)col.second * n
+                                      : B.inst_lag + (size_t)col.second * n;
+  };
+  if (S) {
+    const Fr delta = fr_from_raw(FR_DELTA_RAW);
+    std::vector<PermProductArgs> pa(S);
+    Fr deltaomega = Fr::one();  // delta^(column position), :86-87,146
+    for (size_t st = 0; st < S; st++) {
+      PermProductArgs& a = pa[st];
+      a.count = (uint32_t)std::min(chunk_len, PC - st * chunk_len);
+      a.beta = beta;
+      a.gamma = gamma;
+      a.omega_powers = pk->omega_powers;
+      for (uint32_t j = 0; j < a.count; j++) {
+        const size_t ci = st * chunk_len + j;
+        a.col[j] = column_values(pk->perm_columns[ci]);
+        a.sigma[j] = pk->perm_values + ci * n;
+        a.delta_beta[j] = deltaomega * beta;
+        deltaomega = deltaomega * delta;
+      }
+      CQ_TRY(perm_denominators(c, a, (uint32_t)n, B.mv + st * n));  // :106-121
+    }
+    CQ_TRY(poly_batch_invert(c, B.mv, (uint32_t)(S * n)));  // :124
+    for (size_t st = 0; st < S; st++) CQ_TRY(perm_numerators(c, pa[st], (uint32_t)n, B.mv + st * n));  // :128-147
+    // z[0] = last_z, z[row] = z[row-1] * mv[row-1] (:160-166): a multiplicative scan per set, then the
+    // chain last_z = z[n - (bf+1)] of the previous set (:173) as one scalar per set
+    CQ_TRY(prefix_product(c, B.mv, B.z, (uint32_t)n, (uint32_t)S));
+    std::vector<Fr> at_u(S);
+    for (size_t st = 0; st < S; st++)
+      CQ_HIP(c, hipMemcpyAsync(&at_u[st], B.z + st * n + u, sizeof(Fr), hipMemcpyDeviceToHost, s));
+    CQ_HIP(c, hipStreamSynchronize(s));
+    PermScaleArgs sa;
+    Fr last_z = Fr::one();
+    for (size_t st = 0; st < S; st++) {
+      sa.mult[st] = last_z;
+      last_z = last_z * at_u[st];
+    }
+    CQ_TRY(perm_scale(c, B.z, (uint32_t)n, u + 1, (uint32_t)S, sa));
+    // blinding rows (:169-171)
+    for (size_t st = 0; st < S; st++)
+      CQ_HIP(c, hipMemcpyAsync(B.z + st * n + (n - bf), z_tails.data() + st * bf, bf * sizeof(Fr), hipMemcpyHostToDevice, s));
+  }
 
   // ---- CQ round 2 (static_lookup/prover.rs:187-342) -------------------------------------------------
   std::vector<Fr> a_at_zero(L);
@@ -361,14 +512,11 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, cq_rng_next_u
       LincombArgs la;
       la.count = w;
       la.sub_const = Fr::zero();
-      CqThetaPowers tp;
-      tp.width = w;
       Fr p = Fr::one();
       for (int j = (int)w - 1; j >= 0; j--) {
         la.p[j] = lk.tables[j]->values;
         la.len[j] = (uint32_t)N;
         la.coeff[j] = p;
-        tp.pow[j] = p;
         p = p * theta;
       }
       CQ_TRY(poly_lincomb(c, la, (uint32_t)N, t_comp));
@@ -398,13 +546,15 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, cq_rng_next_u
       CQ_TRY(domain_lagrange_to_coeff(dom, bpoly, bpoly, (uint32_t)L, n, n));
       CQ_TRY(domain_lagrange_to_coeff(dom, f_lag, f_coeff, (uint32_t)L, n, n));  // :326-334
     }
-    // commitments: a, a0 (dense over the table SRS), q_a (over [qs_0|qs_1|...]), p, b0 (n-1 terms of b[1..])
-    // and the vanishing argument's random polynomial (vanishing/prover.rs:58) in one batch of launches
+    // commitments, one batch of launches: the permutation products (permutation/prover.rs:177, written first),
+    // then a, a0 (dense over the table SRS), q_a (over [qs_0|qs_1|...]), p, b0 (n-1 terms of b[1..]) and the
+    // vanishing argument's random polynomial (vanishing/prover.rs:58)
     std::vector<G1Affine> r2;
     {
       std::vector<const Fr*> sc;
       std::vector<const G1Affine*> bs;
       std::vector<size_t> ln;
+      for (size_t st = 0; st < S; st++) { sc.push_back(B.z + st * n); bs.push_back(pk->params->g_lagrange); ln.push_back(n); }
       woff = 0;
       for (size_t l = 0; l < L; l++) {
         const uint32_t w = (uint32_t)pk->lookups[l].cols.size();
@@ -418,12 +568,16 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, cq_rng_next_u
       sc.push_back(random_poly); bs.push_back(pk->params->g); ln.push_back(n);
       CQ_TRY(commit_batch_v(pk, sc, bs, ln, r2));
     }
+    for (size_t st = 0; st < S; st++)
+      if (!tr.write_point(r2[st])) return c->fail(CQ_ERR_TRANSCRIPT, "permutation product commitment is the identity");
+    // z -> coefficients (permutation/prover.rs:179), in place
+    if (S) CQ_TRY(domain_lagrange_to_coeff(dom, B.z, B.z, (uint32_t)S, n, n));
     for (size_t l = 0; l < L; l++) {
       // write order :306-313: a, q_a, a0, b0, p
       for (size_t q = 0; q < 5; q++)
-        if (!tr.write_point(r2[5 * l + q])) return c->fail(CQ_ERR_TRANSCRIPT, "a CQ round-2 commitment is the identity");
+        if (!tr.write_point(r2[S + 5 * l + q])) return c->fail(CQ_ERR_TRANSCRIPT, "a CQ round-2 commitment is the identity");
     }
-    random_cm = r2[5 * L];
+    random_cm = r2[S + 5 * L];
     // a(0) = (n*b(0) - (bf+1)/beta) / N   (:318-324)
     if (L) {
       std::vector<Fr> b0(L);
@@ -443,18 +597,70 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, cq_rng_next_u
   // advice polys: lagrange_to_coeff (:587-603), in place
   if (A) CQ_TRY(domain_lagrange_to_coeff(dom, adv, adv, (uint32_t)A, n, n));
 
-  // ---- evaluate_h, CQ terms (evaluation.rs:533-548) + divide by the vanishing polynomial -----------
+  // ---- evaluate_h (evaluation.rs:285-551) + divide by the vanishing polynomial ------------------------
   {
+    if (general) {
+      // advice / instance cosets (:317-335), permutation product cosets (permutation/prover.rs:182)
+      if (A) CQ_TRY(domain_coeff_to_extended(dom, adv, B.adv_cosets, (uint32_t)A, n, ext));
+      if (I) CQ_TRY(domain_coeff_to_extended(dom, B.inst_coeff, B.inst_cosets, (uint32_t)I, n, ext));
+      if (S) CQ_TRY(domain_coeff_to_extended(dom, B.z, B.z_cosets, (uint32_t)S, n, ext));
+      const uint32_t rot_scale = 1u << (dom->extended_k - dom->k);
+      if (pk->num_gate_polys) {  // custom gates (:348-365)
+        GateEvalArgs ga;
+        ga.prog = pk->gate_prog;
+        ga.num_polys = pk->num_gate_polys;
+        ga.constants = pk->constants;
+        ga.advice = B.adv_cosets;
+        ga.fixed = pk->fixed_cosets;
+        ga.instance = B.inst_cosets;
+        ga.stride = ext;
+        ga.size = (uint32_t)ext;
+        ga.rot_scale = rot_scale;
+        ga.y = y;
+        CQ_TRY(gate_eval(c, ga, h_ext));
+      } else {
+        CQ_HIP(c, hipMemsetAsync(h_ext, 0, ext * sizeof(Fr), s));
+      }
+      if (S) {  // permutation constraints (:367-459)
+        PermHArgs ph;
+        ph.z = B.z_cosets;
+        ph.sigma = pk->perm_cosets;
+        for (size_t ci = 0; ci < PC; ci++) {
+          const auto& col = pk->perm_columns[ci];
+          ph.col[ci] = col.first == CQ_COL_ADVICE ? B.adv_cosets + (size_t)col.second * ext
+                     : col.first == CQ_COL_FIXED  ? pk->fixed_cosets + (size_t)col.second * ext
+                                                  : B.inst_cosets + (size_t)col.second * ext;
+        }
+        ph.sets = (uint32_t)S;
+        ph.chunk_len = (uint32_t)chunk_len;
+        ph.ncols = (uint32_t)PC;
+        ph.l0 = pk->l0;
+        ph.l_last = pk->l_last;
+        ph.l_active = pk->l_active_row;
+        ph.beta = beta;
+        ph.gamma = gamma;
+        ph.y = y;
+        ph.delta_start = beta * dom->g_coset;  // beta * ZETA (:375)
+        ph.extended_omega = dom->extended_omega;
+        ph.delta = fr_from_raw(FR_DELTA_RAW);
+        ph.ext = (uint32_t)ext;
+        ph.rot_scale = rot_scale;
+        ph.last_rot = bf + 1;
+        CQ_TRY(perm_h_terms(c, ph, h_ext));
+      }
+    }
     if (L) {
       CQ_TRY(domain_coeff_to_extended(dom, bpoly, cosets, (uint32_t)L, n, ext));
       CQ_TRY(domain_coeff_to_extended(dom, f_coeff, cosets + L * ext, (uint32_t)L, n, ext));
     }
+    // CQ terms (:533-548), then the division by X^n - 1 (vanishing/prover.rs:84, domain.rs:319-338)
     CqQuotientArgs qa;
     qa.count = (uint32_t)L;
     for (size_t l = 0; l < L; l++) {
       qa.b[l] = cosets + l * ext;
       qa.f[l] = cosets + (L + l) * ext;
     }
+    qa.h_in = general ? h_ext : nullptr;
     qa.l_active = pk->l_active_row;
     qa.t_evals = dom->t_evaluations_dev;
     qa.t_len = (uint32_t)dom->t_evaluations.size();
@@ -478,88 +684,108 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, cq_rng_next_u
   const Fr x = tr.squeeze();  // prover.rs:629
   const Fr xn = x.pow_u64(n);
 
-  // ---- evaluations (prover.rs:654-719): every polynomial is opened at x, one batched launch ---------
-  const size_t pieces_n = pieces;
-  std::vector<Fr> advice_evals(pk->advice_queries.size()), b0_evals(L), f_evals(L), h_evals(pieces_n);
-  Fr random_eval;
-  {
+  // ---- evaluations (prover.rs:654-719) and opening queries (:721-773) ------------------------------------
+  // Every polynomial opened by the proof, in the order ProverGWC receives the queries; `written` marks the
+  // evaluations the transcript carries (h is opened but its value is derived, vanishing/prover.rs:131-153).
+  struct Query {
+    const Fr* p;
+    uint32_t len;
+    int32_t rot;
+    int h_piece;  // -1, or the index of an h piece (folded into one query with coefficient xn^i)
+    Fr eval;
+  };
+  std::vector<Query> qs;
+  auto add_query = [&](const Fr* p, size_t len, int32_t rot) {
+    qs.push_back({p, (uint32_t)len, rot, -1, Fr::zero()});
+    return qs.size() - 1;
+  };
+  const int32_t rot_last = -(int32_t)(bf + 1);
+  std::vector<size_t> q_advice, q_fixed, q_sigma, q_z, q_z_next, q_z_last(S, (size_t)-1), q_b0, q_f, q_h;
+  for (auto& q : pk->advice_queries) q_advice.push_back(add_query(adv + (size_t)q.first * n, n, q.second));
+  for (size_t st = 0; st < S; st++) {  // permutation::Evaluated::open (permutation/prover.rs:294-344)
+    q_z.push_back(add_query(B.z + st * n, n, 0));
+    q_z_next.push_back(add_query(B.z + st * n, n, 1));
+  }
+  for (size_t st = S > 0 ? S - 1 : 0; st-- > 0;) q_z_last[st] = add_query(B.z + st * n, n, rot_last);
+  for (size_t l = 0; l < L; l++) {  // static_lookup::Evaluated::open
+    q_b0.push_back(add_query(bpoly + l * n + 1, n - 1, 0));  // b0 = (b - b(0))/X
+    q_f.push_back(add_query(f_coeff + l * n, n, 0));
+  }
+  for (auto& q : pk->fixed_queries) q_fixed.push_back(add_query(pk->fixed_polys + (size_t)q.first * n, n, q.second));
+  for (size_t ci = 0; ci < PC; ci++) q_sigma.push_back(add_query(pk->perm_polys + ci * n, n, 0));  // ProvingKey::open (:215-225)
+  for (size_t i = 0; i < pieces; i++) {
+    q_h.push_back(add_query(h_coeff + i * n, n, 0));
+    qs.back().h_piece = (int)i;
+  }
+  const size_t q_random = add_query(random_poly, n, 0);
+  // distinct points in first-seen order (gwc.rs:36-61); rotate_omega (domain.rs:414-424)
+  std::vector<int32_t> rots;
+  for (auto& q : qs)
+    if (std::find(rots.begin(), rots.end(), q.rot) == rots.end()) rots.push_back(q.rot);
+  auto point_of = [&](int32_t rot) { return rot >= 0 ? x * dom->omega.pow_u64((uint64_t)rot) : x * dom->omega_inv.pow_u64((uint64_t)(-(int64_t)rot)); };
+  for (int32_t rot : rots) {
     std::vector<const Fr*> ps;
     std::vector<uint32_t> ls;
-    for (auto& q : pk->advice_queries) { ps.push_back(adv + (size_t)q.first * n); ls.push_back((uint32_t)n); }
-    ps.push_back(random_poly); ls.push_back((uint32_t)n);
-    for (size_t l = 0; l < L; l++) {
-      ps.push_back(bpoly + l * n + 1); ls.push_back((uint32_t)(n - 1));  // b0 = (b - b(0))/X
-      ps.push_back(f_coeff + l * n); ls.push_back((uint32_t)n);
-    }
-    for (size_t i = 0; i < pieces_n; i++) { ps.push_back(h_coeff + i * n); ls.push_back((uint32_t)n); }
+    std::vector<size_t> idx;
+    for (size_t i = 0; i < qs.size(); i++)
+      if (qs[i].rot == rot) {
+        ps.push_back(qs[i].p);
+        ls.push_back(qs[i].len);
+        idx.push_back(i);
+      }
     std::vector<Fr> ev(ps.size());
-    for (size_t off = 0; off < ps.size(); off += EVAL_MAX_BATCH) {
-      const uint32_t cnt = (uint32_t)std::min((size_t)EVAL_MAX_BATCH, ps.size() - off);
-      CQ_TRY(poly_eval_batch(c, ps.data() + off, ls.data() + off, cnt, x, ev.data() + off));
-    }
-    size_t e = 0;
-    for (size_t q = 0; q < advice_evals.size(); q++) advice_evals[q] = ev[e++];
-    random_eval = ev[e++];
-    for (size_t l = 0; l < L; l++) { b0_evals[l] = ev[e++]; f_evals[l] = ev[e++]; }
-    for (size_t i = 0; i < pieces_n; i++) h_evals[i] = ev[e++];
+    CQ_TRY(eval_many(c, ps, ls, point_of(rot), ev.data()));
+    for (size_t j = 0; j < idx.size(); j++) qs[idx[j]].eval = ev[j];
   }
-  for (auto& v : advice_evals) tr.write_scalar(v);
-  tr.write_scalar(random_eval);  // vanishing/prover.rs:145-146
+  for (size_t i : q_advice) tr.write_scalar(qs[i].eval);  // :654-672
+  for (size_t i : q_fixed) tr.write_scalar(qs[i].eval);   // :674-687
+  tr.write_scalar(qs[q_random].eval);                     // vanishing/prover.rs:145-146
+  for (size_t i : q_sigma) tr.write_scalar(qs[i].eval);   // permutation/prover.rs:227-239
+  for (size_t st = 0; st < S; st++) {                     // :243-290
+    tr.write_scalar(qs[q_z[st]].eval);
+    tr.write_scalar(qs[q_z_next[st]].eval);
+    if (st + 1 < S) tr.write_scalar(qs[q_z_last[st]].eval);
+  }
   for (size_t l = 0; l < L; l++) {  // static_lookup/prover.rs:360-370
-    tr.write_scalar(b0_evals[l]);
-    tr.write_scalar(f_evals[l]);
+    tr.write_scalar(qs[q_b0[l]].eval);
+    tr.write_scalar(qs[q_f[l]].eval);
     tr.write_scalar(a_at_zero[l]);
   }
 
-  // ---- multiopen, GWC (gwc/prover.rs:42-91): every query is at x => one point group ---------------------
+  // ---- multiopen, GWC (gwc/prover.rs:42-91): one witness polynomial per distinct point ---------------------
   {
     const Fr v = tr.squeeze();
-    // h(X) = sum_i xn^i h_i (vanishing/prover.rs:131-135); get_eval's value follows from the piece evals
+    // h(X) = sum_i xn^i h_i (vanishing/prover.rs:131-135); its value follows from the piece evaluations
     Fr h_eval = Fr::zero();
-    for (size_t i = pieces; i-- > 0;) h_eval = h_eval * xn + h_evals[i];
-    LincombArgs la;
-    la.count = 0;
-    Fr pv = Fr::one();
-    Fr eval_batch = Fr::zero();
-    auto push = [&](const Fr* p, uint32_t len, const Fr& coeff) {
-      la.p[la.count] = p;
-      la.len[la.count] = len;
-      la.coeff[la.count] = coeff;
-      la.count++;
-    };
-    if (pk->advice_queries.size() + 2 * L + pieces + 1 > LINCOMB_MAX) return c->fail(CQ_ERR_ARG, "too many opening queries");
-    for (size_t q = 0; q < pk->advice_queries.size(); q++) {
-      push(adv + (size_t)pk->advice_queries[q].first * n, (uint32_t)n, pv);
-      eval_batch = eval_batch + advice_evals[q] * pv;
-      pv = pv * v;
-    }
-    for (size_t l = 0; l < L; l++) {
-      push(bpoly + l * n + 1, (uint32_t)(n - 1), pv);
-      eval_batch = eval_batch + b0_evals[l] * pv;
-      pv = pv * v;
-      push(f_coeff + l * n, (uint32_t)n, pv);
-      eval_batch = eval_batch + f_evals[l] * pv;
-      pv = pv * v;
-    }
-    {
-      Fr xp = Fr::one();
-      for (size_t i = 0; i < pieces; i++) {
-        push(h_coeff + i * n, (uint32_t)n, pv * xp);
-        xp = xp * xn;
+    for (size_t i = pieces; i-- > 0;) h_eval = h_eval * xn + qs[q_h[i]].eval;
+    std::vector<const Fr*> sc;
+    for (size_t g = 0; g < rots.size(); g++) {
+      std::vector<Term> terms;
+      Fr pv = Fr::one(), eval_batch = Fr::zero(), xp = Fr::one();
+      for (auto& q : qs) {
+        if (q.rot != rots[g]) continue;
+        if (q.h_piece >= 0) {  // the pieces of h share one power of v
+          terms.push_back({q.p, q.len, pv * xp});
+          xp = xp * xn;
+          if ((size_t)q.h_piece + 1 < pieces) continue;
+          eval_batch = eval_batch + h_eval * pv;
+        } else {
+          terms.push_back({q.p, q.len, pv});
+          eval_batch = eval_batch + q.eval * pv;
+        }
+        pv = pv * v;
       }
-      eval_batch = eval_batch + h_eval * pv;
-      pv = pv * v;
+      Fr* batch = B.gwc_batch + g * n;
+      Fr* wit = B.gwc_wit + g * n;
+      CQ_TRY(lincomb_many(c, terms, eval_batch, (uint32_t)n, batch));  // poly_batch - eval_batch (gwc/prover.rs:62-78)
+      CQ_TRY(poly_kate_division(c, batch, (uint32_t)n, point_of(rots[g]), wit));  // :80
+      sc.push_back(wit);
     }
-    push(random_poly, (uint32_t)n, pv);
-    eval_batch = eval_batch + random_eval * pv;
-    la.sub_const = eval_batch;
-    CQ_TRY(poly_lincomb(c, la, (uint32_t)n, gwc_batch));
-    CQ_TRY(poly_kate_division(c, gwc_batch, (uint32_t)n, x, gwc_wit));
-    std::vector<const Fr*> sc{gwc_wit};
-    std::vector<const G1Affine*> bs{pk->params->g};
+    std::vector<const G1Affine*> bs(sc.size(), pk->params->g);
     std::vector<G1Affine> o;
-    CQ_TRY(commit_batch(pk, sc, bs, n - 1, o));
-    if (!tr.write_point(o[0])) return c->fail(CQ_ERR_TRANSCRIPT, "opening witness commitment is the identity");
+    CQ_TRY(commit_batch(pk, sc, bs, n - 1, o));  // :85
+    for (auto& w : o)
+      if (!tr.write_point(w)) return c->fail(CQ_ERR_TRANSCRIPT, "opening witness commitment is the identity");
   }
   proof_out.swap(tr.proof);
   return CQ_OK;

@@ -91,3 +91,42 @@ def oracle_env(k, s_seed=0x6371, **kw):
     pk = CP.keygen_pk(fx["circuit"], tabs, tsrs, b0, 424242, fixed=fx["fixed"], perm_mapping=fx["mapping"])
     fx.update(s=s, params=params, pk=pk, tsrs=tsrs, tabs=tabs, srs_g1_len=2 * n)
     return fx
+
+
+def to_backend_cs(circuit, gtables):
+    """The same constraint system through the backend's `ConstraintSystem` mirror (queries pinned to the
+    oracle circuit's registration order)."""
+    from sha2_on_cq_halo2_amd import plonk as GP
+
+    cs = GP.ConstraintSystem()
+    cols = {A: [cs.advice_column() for _ in range(circuit.num_advice)],
+            F: [cs.fixed_column() for _ in range(circuit.num_fixed)],
+            I: [cs.instance_column() for _ in range(circuit.num_instance)]}
+
+    def conv(e):
+        t = e[0]
+        if t == "const":
+            return GP.Expression.constant(e[1])
+        if t in (A, F, I):
+            return cs.query_any(cols[t][e[1]], e[2])
+        if t == "neg":
+            return -conv(e[1])
+        if t == "add":
+            return conv(e[1]) + conv(e[2])
+        if t == "mul":
+            return conv(e[1]) * conv(e[2])
+        if t == "scale":
+            return conv(e[1]) * int(e[2])
+        raise ValueError(t)
+
+    for kind, idx in circuit.perm_columns:
+        cs.enable_equality(cols[kind][idx])
+    for gi, g in enumerate(circuit.gates):
+        cs.create_gate(f"g{gi}", [conv(g)])
+    for li, lk in enumerate(circuit.lookups):
+        cs.lookup_static(f"l{li}", [(cols[A][c], gtables[t]) for c, t in lk])
+    assert cs.advice_queries == circuit.advice_queries()
+    assert cs.fixed_queries == circuit.fixed_queries()
+    assert cs.instance_queries == circuit.instance_queries()
+    assert cs.degree() == circuit.degree() and cs.blinding_factors() == circuit.blinding_factors()
+    return cs
