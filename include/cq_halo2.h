@@ -238,6 +238,12 @@ typedef struct {
   const uint32_t* perm_column_kinds;   /* CQ_COL_* */
   const uint32_t* perm_column_indices;
   const uint32_t* perm_mapping;
+  /* Static lookup inputs as expressions (`Argument::input: Vec<Expression<F>>`, static_lookup.rs:171-178):
+   * one postfix program per (lookup, table column) pair in the order of cq_circuit.lookup_columns, sharing
+   * `constants`; evaluated over the Lagrange basis as `evaluate(expr, n, 1, ..)` does
+   * (static_lookup/prover.rs:91-107).  NULL = every input is advice[lookup_columns[i]] @ Rotation::cur(). */
+  const uint32_t* lookup_input_program_lens;
+  const uint32_t* lookup_input_programs;
 } cq_plonk;
 
 /* Shape of the constraint system (stands in for ConstraintSystem, plonk/circuit.rs):

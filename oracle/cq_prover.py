@@ -74,8 +74,9 @@ class Blake2bWrite:
 @dataclass
 class CqCircuit:
     """Shape descriptor standing in for `ConstraintSystem` (plonk/circuit.rs).  `lookups[l]` =
-    list of (advice column, table id): one input expression `advice[col]@Rotation::cur()` per table
-    column, as `lookup_static` registers them (plonk/circuit.rs:1579-1602).
+    list of (input, table id), one per table column, as `lookup_static` registers them
+    (plonk/circuit.rs:1579-1602); an input is an advice column index (`advice[col]@Rotation::cur()`)
+    or any oracle/plonk.py expression.
 
     General-PLONK part (all empty for a CQ-only circuit): `gates` = the gate polynomials in
     `cs.gates` order (oracle/plonk.py expressions; selectors already folded into fixed columns as
@@ -104,8 +105,7 @@ class CqCircuit:
             expr_queries(g, q)
         for lk in self.lookups:
             for col, _ in lk:
-                if (ADVICE, col, 0) not in q:
-                    q.append((ADVICE, col, 0))
+                expr_queries(_lookup_input(col), q)
         return {kind: [(c, r) for (t, c, r) in q if t == kind] for kind in (ADVICE, FIXED, INSTANCE)}
 
     def advice_queries(self):
@@ -132,7 +132,15 @@ class CqCircuit:
         d = 3
         for g in self.gates:
             d = max(d, expr_degree(g))
+        for lk in self.lookups:  # static_lookup.rs:181-190: max(3, 2 + input degree)
+            for col, _ in lk:
+                d = max(d, 2 + expr_degree(_lookup_input(col)))
         return d
+
+
+def _lookup_input(col):
+    """A static lookup input: an advice column index (`advice[col] @ Rotation::cur()`) or any expression."""
+    return (ADVICE, col, 0) if isinstance(col, int) else col
 
 
 @dataclass
@@ -255,7 +263,12 @@ def create_proof(params, pk: ProvingKey, advice_usable, rng, msm=None, instances
     for li, lk in enumerate(cs.lookups):
         tables = [pk.tables[tid] for _, tid in lk]
         assert all(t.size == tables[0].size for t in tables)
-        exprs = [advice[col] for col, _ in lk]
+        cols_now = {ADVICE: advice, FIXED: pk.fixed_values, INSTANCE: instance_values}
+        exprs = []
+        for col, _ in lk:  # `evaluate(expression, n, 1, ...)` (:91-107, evaluation.rs:776-818)
+            e = _lookup_input(col)
+            exprs.append([expr_eval(e, lambda kind, c, rot, row=row: cols_now[kind][c][rotation_idx(row, rot, 1, n)])
+                          for row in range(n)])
         f = [0] * n
         for e in exprs:  # :108-116
             f = [(a * theta + b) % P for a, b in zip(f, e)]

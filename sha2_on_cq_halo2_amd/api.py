@@ -461,6 +461,8 @@ class _CqPlonk(C.Structure):
         ("perm_column_kinds", C.POINTER(C.c_uint32)),
         ("perm_column_indices", C.POINTER(C.c_uint32)),
         ("perm_mapping", C.POINTER(C.c_uint32)),
+        ("lookup_input_program_lens", C.POINTER(C.c_uint32)),
+        ("lookup_input_programs", C.POINTER(C.c_uint32)),
     ]
 
 
@@ -509,6 +511,13 @@ def _lower_plonk(cs, fixed, mapping, keep: list) -> _CqPlonk:
         lens.append(len(prog))
         words += prog
     pl.num_gate_polys, pl.gate_program_lens, pl.gate_programs = len(lens), u32(lens), u32(words)
+    if cs.static_lookup_inputs is not None:  # expression-valued lookup inputs
+        llens, lwords = [], []
+        for e in cs.static_lookup_inputs:
+            prog = e.compile(constants)
+            llens.append(len(prog))
+            lwords += prog
+        pl.lookup_input_program_lens, pl.lookup_input_programs = u32(llens), u32(lwords)
     cst = np.zeros((max(len(constants), 1), 4), dtype=np.uint64)
     for i, v in enumerate(constants):
         cst[i] = fr_to_mont(v)

@@ -202,13 +202,15 @@ int cq_pk_create(cq_ctx* c, cq_params* params, const cq_circuit* cs, cq_table_co
     for (uint32_t j = 0; j < w; j++) {
       const uint32_t col = cs->lookup_columns[off + j];
       cq_static_table* t = cs->lookup_tables[off + j];
-      if (col >= cs->num_advice || !t) return pk_abort(pk, c->fail(CQ_ERR_ARG, "pk: bad lookup column / table"));
+      const bool is_expr = pl && pl->lookup_input_program_lens;
+      if ((!is_expr && col >= cs->num_advice) || !t) return pk_abort(pk, c->fail(CQ_ERR_ARG, "pk: bad lookup column / table"));
       // "Tables should all be of the same size" (static_lookup/prover.rs:81-83)
       if (t->N != cfg->N) return pk_abort(pk, c->fail(CQ_ERR_ARG, "pk: table size differs from the table config"));
       d.cols.push_back(col);
+      d.prog.push_back(-1);
       d.tables.push_back(t);
       // query_advice_index (plonk/circuit.rs:1619-1633)
-      if (!(pl && pl->num_advice_queries) &&
+      if (!(pl && pl->num_advice_queries) && !is_expr &&
           std::find(pk->advice_queries.begin(), pk->advice_queries.end(), std::make_pair(col, (int32_t)0)) == pk->advice_queries.end())
         pk->advice_queries.push_back({col, 0});
     }
@@ -303,9 +305,31 @@ int cq_pk_create(cq_ctx* c, cq_params* params, const cq_circuit* cs, cq_table_co
     pk->num_gate_polys = pl->num_gate_polys;
     if (hipMalloc(&pk->gate_prog, blob.size() * sizeof(uint32_t)) != hipSuccess) return pk_abort(pk, c->fail(CQ_ERR_HIP, "hipMalloc(gate program)"));
     CQ_HIP(c, hipMemcpy(pk->gate_prog, blob.data(), blob.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-    if (hipMalloc(&pk->constants, std::max<size_t>(pl->num_constants, 1) * sizeof(Fr)) != hipSuccess)
-      return pk_abort(pk, c->fail(CQ_ERR_HIP, "hipMalloc(gate constants)"));
-    if (pl->num_constants) CQ_HIP(c, hipMemcpy(pk->constants, pl->constants, pl->num_constants * sizeof(Fr), hipMemcpyHostToDevice));
+  }
+  if (pl && pl->num_constants) {
+    if (hipMalloc(&pk->constants, pl->num_constants * sizeof(Fr)) != hipSuccess) return pk_abort(pk, c->fail(CQ_ERR_HIP, "hipMalloc(gate constants)"));
+    CQ_HIP(c, hipMemcpy(pk->constants, pl->constants, pl->num_constants * sizeof(Fr), hipMemcpyHostToDevice));
+  }
+  if (pl && pl->lookup_input_program_lens && off) {
+    // static lookup inputs given as expressions: one single-polynomial program each
+    if (!pl->lookup_input_programs) return pk_abort(pk, c->fail(CQ_ERR_ARG, "pk: null pointer in cq_plonk"));
+    const char* why = nullptr;
+    size_t words = 0;
+    if (!gate_program_check(pl->lookup_input_program_lens, pl->lookup_input_programs, (uint32_t)off, pl->num_constants,
+                            cs->num_advice, pl->num_fixed, pl->num_instance, &why, &words))
+      return pk_abort(pk, c->fail(CQ_ERR_ARG, why));
+    std::vector<uint32_t> blob;
+    size_t o = 0, idx = 0;
+    for (auto& lk : pk->lookups)
+      for (size_t j = 0; j < lk.cols.size(); j++, idx++) {
+        lk.prog[j] = (int64_t)blob.size();
+        blob.push_back(pl->lookup_input_program_lens[idx]);
+        blob.insert(blob.end(), pl->lookup_input_programs + o, pl->lookup_input_programs + o + pl->lookup_input_program_lens[idx]);
+        o += pl->lookup_input_program_lens[idx];
+      }
+    pk->lookup_exprs = true;
+    if (hipMalloc(&pk->lookup_prog, blob.size() * sizeof(uint32_t)) != hipSuccess) return pk_abort(pk, c->fail(CQ_ERR_HIP, "hipMalloc(lookup programs)"));
+    CQ_HIP(c, hipMemcpy(pk->lookup_prog, blob.data(), blob.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
   }
   if (!pk->perm_columns.empty()) {
     // permutation::keygen::Assembly::build_pk (permutation/keygen.rs:151-208)
@@ -386,7 +410,7 @@ void cq_pk_destroy(cq_pk* pk) {
   if (pk->domain) domain_destroy(pk->domain);
   if (pk->l_active_row) hipFree(pk->l_active_row);
   for (void* p : {(void*)pk->fixed_values, (void*)pk->fixed_polys, (void*)pk->fixed_cosets, (void*)pk->l0, (void*)pk->l_last,
-                  (void*)pk->gate_prog, (void*)pk->constants, (void*)pk->perm_values, (void*)pk->perm_polys, (void*)pk->perm_cosets,
+                  (void*)pk->gate_prog, (void*)pk->constants, (void*)pk->lookup_prog, (void*)pk->perm_values, (void*)pk->perm_polys, (void*)pk->perm_cosets,
                   (void*)pk->omega_powers})
     if (p) hipFree(p);
   if (pk->b0_g1_bound) msm_unregister_tables(pk->ctx, pk->b0_g1_bound);

@@ -74,6 +74,7 @@ struct cq_static_table {
 
 struct cq_lookup_desc {
   std::vector<uint32_t> cols;             // advice column per table column (input = advice[col] @ Rotation::cur())
+  std::vector<int64_t> prog;              // or: word offset of the input's program in cq_pk::lookup_prog (-1 = plain column)
   std::vector<cq_static_table*> tables;
 };
 
@@ -100,6 +101,8 @@ struct cq_pk {
   uint32_t num_gate_polys = 0;
   uint32_t* gate_prog = nullptr;    // device: [len, words...] per polynomial
   cq::Fr* constants = nullptr;      // device
+  uint32_t* lookup_prog = nullptr;  // device: [1-poly program] per expression-valued lookup input
+  bool lookup_exprs = false;
   std::vector<std::pair<uint32_t, uint32_t>> perm_columns;  // (CQ_COL_*, index) = cs.permutation.columns
   cq::Fr* perm_values = nullptr;    // columns x n   (permutation::ProvingKey::permutations)
   cq::Fr* perm_polys = nullptr;     // columns x n   (::polys)

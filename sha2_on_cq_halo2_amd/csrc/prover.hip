@@ -206,7 +206,7 @@ struct Arena {
 };
 struct Buffers {
   Fr *adv, *inst_lag, *inst_coeff, *f_lag, *f_coeff, *bpoly, *random_poly, *z, *mv, *cosets, *adv_cosets, *inst_cosets,
-      *z_cosets, *h_ext, *h_coeff, *gwc_batch, *gwc_wit, *t_comp, *den, *a_val, *m_fr, *a_scaled;
+      *z_cosets, *lk_inputs, *h_ext, *h_coeff, *gwc_batch, *gwc_wit, *t_comp, *den, *a_val, *m_fr, *a_scaled;
   uint64_t* rng_dev;
   uint32_t *m_counts, *err_dev;
 };
@@ -244,6 +244,7 @@ void carve(const cq_pk* pk, Arena& ar, Buffers& b) {
   b.adv_cosets = ar.take(general ? A * ext : 0);
   b.inst_cosets = ar.take(general ? I * ext : 0);
   b.z_cosets = ar.take(S * ext);
+  b.lk_inputs = ar.take(pk->lookup_exprs ? wsum * n : 0);  // evaluated input expressions of the static lookups
   b.h_ext = ar.take(ext);
   b.h_coeff = ar.take(ext);          // n * (degree - 1) coefficients
   b.gwc_batch = ar.take(npts * n);
@@ -405,16 +406,39 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, const uint64_
 
   // ---- CQ round 1 (static_lookup/prover.rs:51-183) ------------------------------------------------
   if (L) CQ_HIP(c, hipMemsetAsync(m_counts, 0, (L * N + 16) * sizeof(uint32_t), s));
+  size_t input_slot = 0;
   for (size_t l = 0; l < L; l++) {
     const cq_lookup_desc& lk = pk->lookups[l];
     const uint32_t w = (uint32_t)lk.cols.size();
+    // input expressions on the Lagrange basis: `evaluate(expr, n, 1, fixed, advice, instance)` (:91-107)
+    const Fr* input[CQ_MAX_WIDTH];
+    for (uint32_t j = 0; j < w; j++, input_slot++) {
+      if (lk.prog[j] < 0) {
+        input[j] = adv + (size_t)lk.cols[j] * n;
+        continue;
+      }
+      GateEvalArgs ga;
+      ga.prog = pk->lookup_prog + lk.prog[j];
+      ga.num_polys = 1;
+      ga.constants = pk->constants;
+      ga.advice = adv;
+      ga.fixed = pk->fixed_values;
+      ga.instance = B.inst_lag;
+      ga.stride = n;
+      ga.size = (uint32_t)n;
+      ga.rot_scale = 1;
+      ga.y = Fr::zero();
+      Fr* dst = B.lk_inputs + input_slot * n;
+      CQ_TRY(gate_eval(c, ga, dst));
+      input[j] = dst;
+    }
     // f = sum_j theta^(w-1-j) * e_j   (:108-116, Horner with the first expression first)
     LincombArgs la;
     la.count = w;
     la.sub_const = Fr::zero();
     Fr p = Fr::one();
     for (int j = (int)w - 1; j >= 0; j--) {
-      la.p[j] = adv + (size_t)lk.cols[j] * n;
+      la.p[j] = input[j];
       la.len[j] = (uint32_t)n;
       la.coeff[j] = p;
       p = p * theta;
@@ -423,7 +447,7 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, const uint64_
     CqRound1Args ra;
     ra.width = w;
     for (uint32_t j = 0; j < w; j++) {
-      ra.cols[j] = adv + (size_t)lk.cols[j] * n;
+      ra.cols[j] = input[j];
       ra.values[j] = lk.tables[j]->values;
       ra.slots[j] = lk.tables[j]->slots;
       ra.nslots[j] = lk.tables[j]->nslots;

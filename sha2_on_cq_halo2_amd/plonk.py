@@ -135,6 +135,7 @@ class ConstraintSystem:
         self.gates = []            # flat list of gate polynomials (Gate::polynomials, cs.gates order)
         self.permutation_columns = []
         self.static_lookups = []   # [[(advice column index, table)]]
+        self._lookup_exprs = []    # the input expression of every (lookup, table column) pair, flattened
 
     # -- columns (circuit.rs:1903-1960)
     def advice_column(self) -> Column:
@@ -174,19 +175,31 @@ class ConstraintSystem:
         self.gates.extend(polys)
 
     def lookup_static(self, name: str, table_map):
-        """circuit.rs:1579-1602: [(advice column queried at Rotation::cur(), StaticTable)]."""
+        """circuit.rs:1579-1602: [(input Expression (or a Column, queried at Rotation::cur()), StaticTable)]."""
         row = []
-        for column, table in table_map:
-            assert column.kind == COL_ADVICE, "static lookup inputs are advice columns on this backend"
-            self.query_any(column, 0)
-            row.append((column.index, table))
+        for expr, table in table_map:
+            if isinstance(expr, Column):
+                expr = self.query_any(expr, 0)
+            plain = expr.op == "query" and expr.a.kind == COL_ADVICE and expr.b == 0
+            row.append((expr.a.index if plain else 0, table))
+            self._lookup_exprs.append(expr)
         self.static_lookups.append(row)
+
+    @property
+    def static_lookup_inputs(self):
+        """None when every input is `advice[col] @ Rotation::cur()` (the CQ-only fast path), else all inputs
+        as expressions."""
+        if all(e.op == "query" and e.a.kind == COL_ADVICE and e.b == 0 for e in self._lookup_exprs):
+            return None
+        return self._lookup_exprs
 
     def degree(self) -> int:
         """circuit.rs:1979-2018: permutation argument 3, static lookups 3 (static_lookup.rs:181-190), gates."""
         d = 3
         for g in self.gates:
             d = max(d, g.degree())
+        for e in self._lookup_exprs:
+            d = max(d, 2 + e.degree())
         return d
 
     def blinding_factors(self) -> int:

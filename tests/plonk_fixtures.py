@@ -16,7 +16,7 @@ A, F, I = PL.ADVICE, PL.FIXED, PL.INSTANCE
 TABLE = [0, 1, 6, 8, 10, 12, 14, 16, 18, 20, 22, 24, 26, 28, 30, 32]
 
 
-def chain_circuit(k, degree5=False, with_lookup=False, seed=1):
+def chain_circuit(k, degree5=False, with_lookup=False, lookup_expr=False, seed=1):
     """Returns dict(circuit, fixed, advice, instances, mapping, tables)."""
     n = 1 << k
     q_add, q_mul, q_next, q_prev, q_fix, kc = range(6)
@@ -33,8 +33,13 @@ def chain_circuit(k, degree5=False, with_lookup=False, seed=1):
         q_pow = num_fixed
         num_fixed += 1
         gates.append(PL.mul(PL.fix(q_pow), PL.sub(PL.mul(PL.mul(a, a), PL.mul(a, a)), c)))
+    with_lookup = with_lookup or lookup_expr
     num_advice = 4 if with_lookup else 3
     lookups = [[(3, "t")]] if with_lookup else []
+    if lookup_expr:  # input = selector * (advice - advice@prev + 6): degree 2 -> static lookup degree 4 (static_lookup.rs:181-190)
+        q_lk = num_fixed
+        num_fixed += 1
+        lookups = [[(PL.mul(PL.fix(q_lk), PL.add(PL.sub(PL.adv(3), PL.adv(3, -1)), PL.const(6))), "t")]]
     perm_columns = [(A, 0), (A, 1), (A, 2), (I, 0), (F, kc)]
     circuit = CP.CqCircuit(k, num_advice, lookups, num_fixed, 1, gates, perm_columns)
     bf = circuit.blinding_factors()
@@ -71,7 +76,18 @@ def chain_circuit(k, degree5=False, with_lookup=False, seed=1):
     asm.copy((I, 0), 0, (A, 0), 0)
     asm.copy((I, 0), 1, (A, 2), R - 1)
     asm.copy((A, 2), 3, (A, 2), 3)  # self copy: no-op (keygen.rs:75-77)
-    if with_lookup:
+    if lookup_expr:
+        # d[r] - d[r-1] + 6 in the table on selected rows; unselected rows (and row 0, whose `prev` is a blinding row)
+        # look up 0 * anything = 0, which the table holds
+        cur = 1000
+        for r in range(u):
+            if r and r % 3:
+                fixed[q_lk][r] = 1
+                cur = (cur + TABLE[(r * 5 + 1) % len(TABLE)] - 6) % P
+            else:
+                cur = (cur * 31 + r) % P
+            adv[3][r] = cur
+    elif with_lookup:
         for r in range(u):
             adv[3][r] = TABLE[(r * 7 + 3) % len(TABLE)]
     return dict(circuit=circuit, fixed=fixed, advice=adv, instances=instances, mapping=asm.mapping,
@@ -124,7 +140,7 @@ def to_backend_cs(circuit, gtables):
     for gi, g in enumerate(circuit.gates):
         cs.create_gate(f"g{gi}", [conv(g)])
     for li, lk in enumerate(circuit.lookups):
-        cs.lookup_static(f"l{li}", [(cols[A][c], gtables[t]) for c, t in lk])
+        cs.lookup_static(f"l{li}", [(cs.query_any(cols[A][c], 0) if isinstance(c, int) else conv(c), gtables[t]) for c, t in lk])
     assert cs.advice_queries == circuit.advice_queries()
     assert cs.fixed_queries == circuit.fixed_queries()
     assert cs.instance_queries == circuit.instance_queries()

@@ -47,12 +47,13 @@ def test_assembly_cycles():
         asm.copy(cols[0], 4, cols[1], 0)
 
 
-@pytest.mark.parametrize("kw", [dict(), dict(degree5=True), dict(with_lookup=True)], ids=["deg3", "deg5", "lookup"])
+@pytest.mark.parametrize("kw", [dict(), dict(degree5=True), dict(with_lookup=True), dict(lookup_expr=True)],
+                         ids=["deg3", "deg5", "lookup", "lookup-expr"])
 def test_plonk_proof_verifies(kw):
     fx = oracle_env(5, **kw)
     cs = fx["circuit"]
-    assert cs.degree() == (5 if kw.get("degree5") else 3)
-    assert cs.blinding_factors() == 5  # a is queried at cur and next (circuit.rs:2022-2047)
+    assert cs.degree() == (5 if kw.get("degree5") else 4 if kw.get("lookup_expr") else 3)
+    assert cs.blinding_factors() == 5  # at most two distinct queries per advice column (circuit.rs:2022-2047)
     tr = CP.create_proof(fx["params"], fx["pk"], fx["advice"], B.Xoshiro256ss(7), instances=fx["instances"])
     chunk = cs.degree() - 2
     sets = -(-len(cs.perm_columns) // chunk)

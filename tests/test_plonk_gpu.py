@@ -36,7 +36,8 @@ def _advice_cols(fx, n):
     return [B.to_mont_limbs(list(c) + [0] * (n - len(c))) for c in fx["advice"]]
 
 
-@pytest.mark.parametrize("kw", [dict(), dict(degree5=True), dict(with_lookup=True)], ids=["deg3", "deg5", "lookup"])
+@pytest.mark.parametrize("kw", [dict(), dict(degree5=True), dict(with_lookup=True), dict(lookup_expr=True)],
+                         ids=["deg3", "deg5", "lookup", "lookup-expr"])
 def test_plonk_proof_bytes_match_oracle(ctx, kw):
     k = 5
     n = 1 << k
@@ -65,7 +66,8 @@ def test_plonk_instance_too_large_and_missing(ctx):
         gpk.create_proof(cols, seed=1)
 
 
-@pytest.mark.parametrize("k,kw", [(11, dict(degree5=True)), (12, dict(with_lookup=True))], ids=["k11-deg5", "k12-lookup"])
+@pytest.mark.parametrize("k,kw", [(11, dict(degree5=True)), (12, dict(with_lookup=True)), (10, dict(lookup_expr=True))],
+                         ids=["k11-deg5", "k12-lookup", "k10-lookup-expr"])
 def test_plonk_large_proof_verifies(ctx, k, kw):
     """Beyond the sizes the Python prover reaches: several scan tiles per product set, batched multi-point
     openings; the proof must satisfy every verifier equation, and a broken copy constraint must not."""
