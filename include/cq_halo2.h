@@ -281,6 +281,13 @@ int cq_pk_create(cq_ctx* ctx, cq_params* params, const cq_circuit* circuit, cq_t
  * all-gathered through `fn` and summed locally (EC addition is not an RCCL reduction op), so every rank
  * derives the same transcript.  Every rank must hold the same witness and RNG stream. */
 int cq_pk_set_sharding(cq_pk* pk, uint32_t rank, uint32_t world, cq_allgather_fn fn, void* user);
+/* Multi-open scheme of cq_create_proof*: `P: Prover` of create_proof (prover.rs:55).
+ * CQ_OPENER_GWC = ProverGWC (poly/kzg/multiopen/gwc/prover.rs:42-91, one witness commitment per distinct
+ * point; the default, as in tests/my_test.rs), CQ_OPENER_SHPLONK = ProverSHPLONK
+ * (poly/kzg/multiopen/shplonk/prover.rs:120-286, two commitments). */
+#define CQ_OPENER_GWC 0
+#define CQ_OPENER_SHPLONK 1
+int cq_pk_set_opener(cq_pk* pk, int opener);
 void cq_pk_destroy(cq_pk* pk);
 uint32_t cq_pk_usable_rows(const cq_pk* pk);
 size_t cq_pk_proof_size(const cq_pk* pk);

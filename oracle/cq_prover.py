@@ -36,6 +36,7 @@ from .bn254 import (
 from .plonk import (ADVICE, FIXED, INSTANCE, build_permutation_pk, expr_degree, expr_eval, expr_queries,
                     permutation_commit, permutation_h_terms, rotation_idx)
 from .poly import EvaluationDomain, best_multiexp, eval_polynomial, kate_division
+from .shplonk import shplonk_prove
 
 P = R_MOD
 
@@ -206,7 +207,7 @@ class ProofTrace:
     polys: dict = field(default_factory=dict)
 
 
-def create_proof(params, pk: ProvingKey, advice_usable, rng, msm=None, instances=()) -> ProofTrace:
+def create_proof(params, pk: ProvingKey, advice_usable, rng, msm=None, instances=(), opener="gwc") -> ProofTrace:
     """plonk/prover.rs:51-779 for a single circuit (ProverGWC: QUERY_INSTANCE = false).
 
     `advice_usable[c]` = the assigned values of advice column c on rows 0..u (shorter
@@ -456,6 +457,13 @@ def create_proof(params, pk: ProvingKey, advice_usable, rng, msm=None, instances
         queries.append((x, sp))
     queries.append((x, h_poly))
     queries.append((x, random_poly))
+    if opener == "shplonk":  # ProverSHPLONK (shplonk/prover.rs:120-286): two commitments whatever the point count
+        polys = {id(poly): poly for _, poly in queries}
+        sq = [(id(poly), pt, eval_polynomial(poly, pt)) for pt, poly in queries]
+        shplonk_prove(tr, n, sq, polys, lambda poly: commit_affine(msm(poly, params.g[: len(poly)])))
+        out.proof = bytes(tr.proof)
+        return out
+    assert opener == "gwc"
     v = tr.squeeze_challenge_scalar()
     out.challenges["v"] = v
     groups = []  # gwc.rs:36-61 first-seen order

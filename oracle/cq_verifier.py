@@ -30,6 +30,7 @@ from .bn254 import (
 from .bn254 import FR_DELTA
 from .plonk import ADVICE, FIXED, expr_eval
 from .poly import EvaluationDomain
+from .shplonk import shplonk_verifier_terms
 
 P = R_MOD
 
@@ -94,8 +95,35 @@ def _eq(J1, J2):
     return jac_to_affine(J1) == jac_to_affine(J2)
 
 
+def _gwc_check(tr, proof, queries, s):
+    """gwc/verifier.rs:48-128, unbatched: per point z, s*W - z*W == sum_j v^j (C_j - e_j G)."""
+    v = tr.squeeze()
+    groups = []
+    for q in queries:
+        for g in groups:
+            if g[0] == q[0]:
+                g[1].append(q)
+                break
+        else:
+            groups.append((q[0], [q]))
+    ws = [tr.read_point() for _ in groups]
+    _u = tr.squeeze()
+    if tr.pos != len(proof):
+        return None
+    ok = True
+    for (z, qs), w in zip(groups, ws):
+        rhs = JAC_ID
+        pv = 1
+        for q in qs:
+            term = jac_add(q[1], _smul(G1_GEN, (-q[2]) % P))
+            rhs = jac_add(rhs, jac_mul(term, pv))
+            pv = pv * v % P
+        ok &= _eq(_smul(w, (s - z) % P), rhs)
+    return ok
+
+
 def verify_proof(proof: bytes, circuit, vk_repr: int, s: int, tables: dict, table_size: int,
-                 srs_g1_len: int, instances=(), fixed_commitments=(), perm_commitments=()) -> bool:
+                 srs_g1_len: int, instances=(), fixed_commitments=(), perm_commitments=(), opener="gwc") -> bool:
     """Returns True iff every verifier equation holds.
 
     tables: id -> list of table values (given order); the committed table polynomial
@@ -207,52 +235,50 @@ def verify_proof(proof: bytes, circuit, vk_repr: int, s: int, tables: dict, tabl
     for c in reversed(h_cms):
         h_commitment = jac_add(jac_mul(h_commitment, xn), to_jac(c))
 
-    # queries in prover.rs:721-773 / verifier.rs order
+    # queries in prover.rs:721-773 / verifier.rs order: (point, commitment, eval, commitment identity)
     queries = []
     for (col, rot), ev in zip(aq, advice_evals):
-        queries.append((dom.rotate_omega(x, rot), to_jac(advice_cm[col]), ev))
+        queries.append((dom.rotate_omega(x, rot), to_jac(advice_cm[col]), ev, ("advice", col)))
     x_next = dom.rotate_omega(x, 1)
     x_last = dom.rotate_omega(x, -(bf + 1))
-    for zc, (ze, zn, _zl) in zip(perm_z_cm, perm_evals):  # permutation/verifier.rs:208-252
-        queries.append((x, to_jac(zc), ze))
-        queries.append((x_next, to_jac(zc), zn))
-    for zc, (_ze, _zn, zl) in reversed(list(zip(perm_z_cm, perm_evals))[:-1]):
-        queries.append((x_last, to_jac(zc), zl))
-    for (f_cm, _m), (a, qa, a0, b0, p_), (b0_eval, f_eval, _az) in zip(lk1, lk2, lk_evals):
-        queries.append((x, to_jac(b0), b0_eval))
-        queries.append((x, to_jac(f_cm), f_eval))
+    zsets = list(enumerate(zip(perm_z_cm, perm_evals)))
+    for si, (zc, (ze, zn, _zl)) in zsets:  # permutation/verifier.rs:208-252
+        queries.append((x, to_jac(zc), ze, ("z", si)))
+        queries.append((x_next, to_jac(zc), zn, ("z", si)))
+    for si, (zc, (_ze, _zn, zl)) in reversed(zsets[:-1]):
+        queries.append((x_last, to_jac(zc), zl, ("z", si)))
+    for li, ((f_cm, _m), (a, qa, a0, b0, p_), (b0_eval, f_eval, _az)) in enumerate(zip(lk1, lk2, lk_evals)):
+        queries.append((x, to_jac(b0), b0_eval, ("b0", li)))
+        queries.append((x, to_jac(f_cm), f_eval, ("f", li)))
     for (col, rot), ev in zip(fq, fixed_evals):  # verifier.rs:447-459
-        queries.append((dom.rotate_omega(x, rot), to_jac(fixed_commitments[col]), ev))
-    for cm_, ev in zip(perm_commitments, perm_common_evals):  # permutation/verifier.rs:255-268
-        queries.append((x, to_jac(cm_), ev))
-    queries.append((x, h_commitment, expected_h_eval))
-    queries.append((x, to_jac(random_cm), random_eval))
+        queries.append((dom.rotate_omega(x, rot), to_jac(fixed_commitments[col]), ev, ("fixed", col)))
+    for ci, (cm_, ev) in enumerate(zip(perm_commitments, perm_common_evals)):  # permutation/verifier.rs:255-268
+        queries.append((x, to_jac(cm_), ev, ("sigma", ci)))
+    queries.append((x, h_commitment, expected_h_eval, ("h",)))
+    queries.append((x, to_jac(random_cm), random_eval, ("random",)))
 
-    v = tr.squeeze()
-    groups = []
-    for q in queries:
-        for g in groups:
-            if g[0] == q[0]:
-                g[1].append(q)
-                break
-        else:
-            groups.append((q[0], [q]))
-    ws = [tr.read_point() for _ in groups]
-    _u = tr.squeeze()
-    if tr.pos != len(proof):
-        return False
     ok = True
-    # GWC: per point z: s*W - z*W == sum_j v^j (C_j - e_j G)   (gwc/verifier.rs:76-125, unbatched)
-    for (z, qs), w in zip(groups, ws):
+    if opener == "shplonk":  # shplonk/verifier.rs:54-148
+        y_ = tr.squeeze()
+        v_ = tr.squeeze()
+        h1 = tr.read_point()
+        u_ = tr.squeeze()
+        h2 = tr.read_point()
+        _batch = tr.squeeze()
+        if tr.pos != len(proof):
+            return False
+        terms, r_outer, z_0 = shplonk_verifier_terms([(q[3], q[0], q[2]) for q in queries], y_, v_, u_)
+        by_key = {q[3]: q[1] for q in queries}
         rhs = JAC_ID
-        pv = 1
-        for (_, C, ev) in qs:
-            term = jac_add(C, _smul(G1_GEN, (-ev) % P))
-            rhs = jac_add(rhs, jac_mul(term, pv))
-            pv = pv * v % P
-        lhs = _smul(w, (s - z) % P)
-        ok &= _eq(lhs, rhs)
-
+        for sc_, key in terms:
+            rhs = jac_add(rhs, jac_mul(by_key[key], sc_))
+        rhs = jac_add(rhs, _smul(G1_GEN, (-r_outer) % P))
+        rhs = jac_add(rhs, _smul(h1, (-z_0) % P))
+        ok &= _eq(_smul(h2, (s - u_) % P), rhs)  # e(h2,[s]) = e(rhs + u*h2,[1])
+    else:
+        ok &= _gwc_check(tr, proof, queries, s)
+        if ok is None:
+            return False
     # CQ pairings (static_lookup/verifier.rs:138-177), each equation separately
     for lk, (f_cm, m_cm), (a, qa, a0, b0, p_), (_b0e, _fe, a_at_zero) in zip(cs.lookups, lk1, lk2, lk_evals):
         # [T(s)] compressed with theta over sorted-value interpolants (:151-158, static_lookup.rs:139-146)

@@ -604,6 +604,11 @@ class ProvingKey(_Handle):
                                                                  proof, self.proof_size, C.byref(plen)))
         return bytes(proof[: plen.value])
 
+    def set_opener(self, name: str):
+        """`P: Prover` of create_proof: "gwc" (ProverGWC, default) or "shplonk" (ProverSHPLONK)."""
+        self.ctx._chk(self.ctx.lib.cq_pk_set_opener(self.h, {"gwc": 0, "shplonk": 1}[name]))
+        self.proof_size = self.ctx.lib.cq_pk_proof_size(self.h)
+
     def vk_commitments(self):
         """(fixed_commitments, permutation commitments) of the matching verifying key: uint64[.,8] affine points
         (keygen.rs:247-250, permutation/keygen.rs:115-149)."""

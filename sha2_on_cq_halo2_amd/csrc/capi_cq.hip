@@ -395,6 +395,12 @@ int cq_pk_create(cq_ctx* c, cq_params* params, const cq_circuit* cs, cq_table_co
   return CQ_OK;
 }
 
+int cq_pk_set_opener(cq_pk* pk, int opener) {
+  if (!pk || (opener != CQ_OPENER_GWC && opener != CQ_OPENER_SHPLONK)) return CQ_ERR_ARG;
+  pk->opener = opener;
+  return CQ_OK;
+}
+
 int cq_pk_set_sharding(cq_pk* pk, uint32_t rank, uint32_t world, cq_allgather_fn fn, void* user) {
   if (!pk || world == 0 || rank >= world || (world > 1 && !fn)) return CQ_ERR_ARG;
   pk->shard_rank = rank;
@@ -436,7 +442,8 @@ size_t cq_pk_proof_size(const cq_pk* pk) {
   for (auto& q : pk->fixed_queries) seen(q.second);
   if (S) seen(1);
   if (S > 1) seen(-(int32_t)(pk->bf + 1));
-  const size_t points = pk->num_advice + 2 * L + S + 5 * L + 1 + pk->domain->quotient_poly_degree + rots.size();
+  const size_t openings = pk->opener == CQ_OPENER_SHPLONK ? 2 : rots.size();
+  const size_t points = pk->num_advice + 2 * L + S + 5 * L + 1 + pk->domain->quotient_poly_degree + openings;
   const size_t scalars = pk->advice_queries.size() + pk->fixed_queries.size() + 1 + pk->perm_columns.size() + (S ? 3 * S - 1 : 0) + 3 * L;
   return 32 * (points + scalars);
 }

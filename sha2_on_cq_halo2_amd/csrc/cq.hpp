@@ -108,6 +108,7 @@ struct cq_pk {
   cq::Fr* perm_polys = nullptr;     // columns x n   (::polys)
   cq::Fr* perm_cosets = nullptr;    // columns x ext (::cosets)
   cq::Fr* omega_powers = nullptr;   // omega^i, i < n
+  int opener = CQ_OPENER_GWC;
   bool general() const { return num_gate_polys || !perm_columns.empty(); }
   size_t perm_sets() const {
     const size_t chunk = cs_degree - 2;

@@ -206,7 +206,7 @@ struct Arena {
 };
 struct Buffers {
   Fr *adv, *inst_lag, *inst_coeff, *f_lag, *f_coeff, *bpoly, *random_poly, *z, *mv, *cosets, *adv_cosets, *inst_cosets,
-      *z_cosets, *lk_inputs, *h_ext, *h_coeff, *gwc_batch, *gwc_wit, *t_comp, *den, *a_val, *m_fr, *a_scaled;
+      *z_cosets, *lk_inputs, *h_ext, *h_coeff, *gwc_batch, *gwc_wit, *shplonk, *t_comp, *den, *a_val, *m_fr, *a_scaled;
   uint64_t* rng_dev;
   uint32_t *m_counts, *err_dev;
 };
@@ -247,8 +247,10 @@ void carve(const cq_pk* pk, Arena& ar, Buffers& b) {
   b.lk_inputs = ar.take(pk->lookup_exprs ? wsum * n : 0);  // evaluated input expressions of the static lookups
   b.h_ext = ar.take(ext);
   b.h_coeff = ar.take(ext);          // n * (degree - 1) coefficients
-  b.gwc_batch = ar.take(npts * n);
-  b.gwc_wit = ar.take(npts * n);
+  const bool shplonk = pk->opener == CQ_OPENER_SHPLONK;
+  b.gwc_batch = ar.take(shplonk ? 0 : npts * n);
+  b.gwc_wit = ar.take(shplonk ? 0 : npts * n);
+  b.shplonk = ar.take(shplonk ? 5 * n + 64 * 8 : 0);  // h, two division buffers, h_x, l_x, low-degree remainders
   b.t_comp = ar.take(N);
   b.den = ar.take(L * N + 8);
   b.a_val = ar.take(L * N);
@@ -774,6 +776,176 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, const uint64_
     tr.write_scalar(qs[q_b0[l]].eval);
     tr.write_scalar(qs[q_f[l]].eval);
     tr.write_scalar(a_at_zero[l]);
+  }
+
+  // ---- multiopen, SHPLONK (shplonk/prover.rs:120-286): two commitments whatever the number of points ---------
+  if (pk->opener == CQ_OPENER_SHPLONK) {
+    Fr* sh_h = B.shplonk;           // h(X) = sum_i xn^i h_i as one polynomial (vanishing/prover.rs:131-135)
+    Fr* sh_div[2] = {B.shplonk + n, B.shplonk + 2 * n};
+    Fr* sh_hx = B.shplonk + 3 * n;
+    Fr* sh_lx = B.shplonk + 4 * n;
+    Fr* sh_rem = B.shplonk + 5 * n;  // per rotation set: sum_j y^j r_j (at most 8 coefficients)
+    Fr h_eval = Fr::zero();
+    {
+      std::vector<Term> terms;
+      Fr xp = Fr::one();
+      for (size_t i = 0; i < pieces; i++) {
+        terms.push_back({h_coeff + i * n, (uint32_t)n, xp});
+        xp = xp * xn;
+      }
+      CQ_TRY(lincomb_many(c, terms, Fr::zero(), (uint32_t)n, sh_h));
+      for (size_t i = pieces; i-- > 0;) h_eval = h_eval * xn + qs[q_h[i]].eval;
+    }
+    const Fr y_ = tr.squeeze();  // :136
+    // construct_intermediate_sets (shplonk.rs:56-133): commitments by polynomial identity, grouped by point set
+    struct Com { const Fr* p; uint32_t len; std::vector<int32_t> rots; std::vector<Fr> evals; };
+    std::vector<Com> coms;
+    for (auto& q : qs) {
+      const Fr* key = q.h_piece >= 0 ? sh_h : q.p;
+      if (q.h_piece > 0) continue;
+      const Fr ev = q.h_piece == 0 ? h_eval : q.eval;
+      auto it = std::find_if(coms.begin(), coms.end(), [&](const Com& cm) { return cm.p == key; });
+      if (it == coms.end()) {
+        coms.push_back({key, q.h_piece == 0 ? (uint32_t)n : q.len, {q.rot}, {ev}});
+      } else if (std::find(it->rots.begin(), it->rots.end(), q.rot) == it->rots.end()) {
+        it->rots.push_back(q.rot);
+        it->evals.push_back(ev);
+      }
+    }
+    struct RotSet { std::vector<int32_t> rots; std::vector<size_t> members; };
+    std::vector<RotSet> sets;
+    auto same_set = [](const std::vector<int32_t>& a, const std::vector<int32_t>& b) {
+      return a.size() == b.size() && std::all_of(a.begin(), a.end(), [&](int32_t r) { return std::find(b.begin(), b.end(), r) != b.end(); });
+    };
+    for (size_t ci = 0; ci < coms.size(); ci++) {
+      auto it = std::find_if(sets.begin(), sets.end(), [&](const RotSet& rs) { return same_set(rs.rots, coms[ci].rots); });
+      if (it == sets.end()) sets.push_back({coms[ci].rots, {ci}});
+      else it->members.push_back(ci);
+    }
+    if (sets.size() > 64) return c->fail(CQ_ERR_ARG, "too many rotation sets");
+    const Fr v_ = tr.squeeze();  // :196
+    // lagrange_interpolate (arithmetic.rs:425-478) of a commitment's evaluations over its set's points
+    auto interpolate = [&](const std::vector<Fr>& pts, const std::vector<Fr>& evals) {
+      const size_t m = pts.size();
+      if (m == 1) return std::vector<Fr>{evals[0]};
+      std::vector<Fr> fin(m, Fr::zero());
+      for (size_t j = 0; j < m; j++) {
+        std::vector<Fr> tmp{Fr::one()};
+        for (size_t kk = 0; kk < m; kk++) {
+          if (kk == j) continue;
+          const Fr denom = (pts[j] - pts[kk]).inv();
+          std::vector<Fr> nxt(tmp.size() + 1, Fr::zero());
+          for (size_t i = 0; i <= tmp.size(); i++) {
+            const Fr a_ = i < tmp.size() ? tmp[i] : Fr::zero();
+            const Fr b_ = i > 0 ? tmp[i - 1] : Fr::zero();
+            nxt[i] = a_ * (Fr::zero() - denom * pts[kk]) + b_ * denom;
+          }
+          tmp.swap(nxt);
+        }
+        for (size_t i = 0; i < m; i++) fin[i] = fin[i] + tmp[i] * evals[j];
+      }
+      return fin;
+    };
+    auto eval_small = [](const std::vector<Fr>& poly, const Fr& at) {
+      Fr acc = Fr::zero();
+      for (size_t i = poly.size(); i-- > 0;) acc = acc * at + poly[i];
+      return acc;
+    };
+    // per set: low-degree equivalents r_j and the y-combined remainder (CommitmentExtension, :36-76)
+    std::vector<std::vector<Fr>> set_points(sets.size());
+    std::vector<std::vector<std::vector<Fr>>> low(sets.size());
+    std::vector<Fr> rem_host(sets.size() * 8, Fr::zero());
+    for (size_t si = 0; si < sets.size(); si++) {
+      for (int32_t r : sets[si].rots) set_points[si].push_back(point_of(r));
+      if (set_points[si].size() > 8) return c->fail(CQ_ERR_ARG, "rotation set too large");
+      Fr py = Fr::one();
+      for (size_t ci : sets[si].members) {
+        // the commitment's evaluations, aligned with the set's point order
+        std::vector<Fr> evals;
+        for (int32_t r : sets[si].rots) {
+          const size_t pos = std::find(coms[ci].rots.begin(), coms[ci].rots.end(), r) - coms[ci].rots.begin();
+          evals.push_back(coms[ci].evals[pos]);
+        }
+        low[si].push_back(interpolate(set_points[si], evals));
+        for (size_t i = 0; i < low[si].back().size(); i++) rem_host[si * 8 + i] = rem_host[si * 8 + i] + py * low[si].back()[i];
+        py = py * y_;
+      }
+    }
+    CQ_HIP(c, hipMemcpyAsync(sh_rem, rem_host.data(), rem_host.size() * sizeof(Fr), hipMemcpyHostToDevice, s));
+    // h_x = sum_i v^i * (sum_j y^j (p_j - r_j)) / prod_{pt in set_i} (X - pt)   (quotient_contribution, :138-168)
+    Fr pv = Fr::one();
+    for (size_t si = 0; si < sets.size(); si++) {
+      std::vector<Term> terms;
+      Fr py = Fr::one();
+      for (size_t ci : sets[si].members) {
+        terms.push_back({coms[ci].p, coms[ci].len, py});
+        py = py * y_;
+      }
+      terms.push_back({sh_rem + si * 8, (uint32_t)set_points[si].size(), Fr::zero() - Fr::one()});
+      CQ_TRY(lincomb_many(c, terms, Fr::zero(), (uint32_t)n, sh_div[0]));
+      uint32_t len = (uint32_t)n;
+      int cur = 0;
+      for (const Fr& pt : set_points[si]) {  // div_by_vanishing (:28-34)
+        CQ_TRY(poly_kate_division(c, sh_div[cur], len, pt, sh_div[cur ^ 1]));
+        cur ^= 1;
+        len--;
+      }
+      std::vector<Term> acc;
+      if (si) acc.push_back({sh_hx, (uint32_t)n, Fr::one()});
+      acc.push_back({sh_div[cur], len, pv});
+      CQ_TRY(lincomb_many(c, acc, Fr::zero(), (uint32_t)n, sh_hx));
+      pv = pv * v_;
+    }
+    {
+      std::vector<const Fr*> sc{sh_hx};
+      std::vector<const G1Affine*> bs{pk->params->g};
+      std::vector<G1Affine> o;
+      CQ_TRY(commit_batch(pk, sc, bs, n, o));  // :204
+      if (!tr.write_point(o[0])) return c->fail(CQ_ERR_TRANSCRIPT, "shplonk quotient commitment is the identity");
+    }
+    const Fr u_ = tr.squeeze();  // :206
+    // l_x = sum_i v^i z_i sum_j y^j (p_j - r_j(u)) - Z_T(u) h_x, then / (X - u) and / z_0   (:208-283); the
+    // scaling by 1/z_0 is folded into the coefficients (the division is linear)
+    std::vector<Fr> all_points;
+    for (int32_t r : rots) all_points.push_back(point_of(r));  // super_point_set: every distinct point
+    auto vanish = [&](const std::vector<Fr>& roots) {
+      Fr acc = Fr::one();
+      for (auto& r : roots) acc = (u_ - r) * acc;
+      return acc;
+    };
+    std::vector<Fr> z_diff(sets.size());
+    for (size_t si = 0; si < sets.size(); si++) {
+      std::vector<Fr> diffs;
+      for (size_t pi = 0; pi < rots.size(); pi++)
+        if (std::find(sets[si].rots.begin(), sets[si].rots.end(), rots[pi]) == sets[si].rots.end()) diffs.push_back(all_points[pi]);
+      z_diff[si] = vanish(diffs);
+    }
+    const Fr z0_inv = z_diff[0].inv();
+    const Fr zt_eval = vanish(all_points);
+    std::vector<Term> terms;
+    Fr sub = Fr::zero();
+    pv = Fr::one();
+    for (size_t si = 0; si < sets.size(); si++) {
+      const Fr scale = pv * z_diff[si] * z0_inv;
+      Fr py = Fr::one();
+      for (size_t j = 0; j < sets[si].members.size(); j++) {
+        const Com& cm = coms[sets[si].members[j]];
+        terms.push_back({cm.p, cm.len, scale * py});
+        sub = sub + scale * py * eval_small(low[si][j], u_);
+        py = py * y_;
+      }
+      pv = pv * v_;
+    }
+    terms.push_back({sh_hx, (uint32_t)n, Fr::zero() - zt_eval * z0_inv});
+    CQ_TRY(lincomb_many(c, terms, sub, (uint32_t)n, sh_lx));
+    CQ_TRY(poly_kate_division(c, sh_lx, (uint32_t)n, u_, sh_div[0]));  // :257
+    std::vector<const Fr*> sc{sh_div[0]};
+    std::vector<const G1Affine*> bs{pk->params->g};
+    std::vector<G1Affine> o;
+    CQ_TRY(commit_batch(pk, sc, bs, n - 1, o));  // :270
+    if (!tr.write_point(o[0])) return c->fail(CQ_ERR_TRANSCRIPT, "shplonk opening commitment is the identity");
+    proof_out.swap(tr.proof);
+    return CQ_OK;
   }
 
   // ---- multiopen, GWC (gwc/prover.rs:42-91): one witness polynomial per distinct point ---------------------

@@ -94,10 +94,59 @@ def chain_circuit(k, degree5=False, with_lookup=False, lookup_expr=False, seed=1
                 tables={"t": TABLE} if with_lookup else {})
 
 
-def oracle_env(k, s_seed=0x6371, **kw):
+def plonk_api_circuit(k=5):
+    """`MyCircuit` of halo2_proofs/tests/plonk_api.rs:270-400 (StandardPlonk: "Combined add-mult" and
+    "Public input" gates, 12 equality-enabled columns, 10 multiply/add pairs with two copies each, public
+    input 2, a = 2834758237 * ZETA :401-405) WITHOUT its legacy `meta.lookup` (:316-319; that argument is not
+    built here).  Column allocation order as in `configure` (:281-298); rows as SimpleFloorPlanner lays the
+    one-row regions out in call order."""
+    n = 1 << k
+    e, a, b, c, d = range(5)
+    sf, sm, sa, sb, sc, sp = range(6)
+    A_, F_, I_ = A, F, I
+    # queries in registration order: enable_equality(a,b,c); gates; enable_equality(sf,e,d,p,sm,sa,sb,sc,sp)
+    gate1 = PL.add(
+        PL.sub(PL.add(PL.add(PL.mul(PL.adv(a), PL.fix(sa)), PL.mul(PL.adv(b), PL.fix(sb))),
+                      PL.mul(PL.mul(PL.adv(a), PL.adv(b)), PL.fix(sm))),
+               PL.mul(PL.adv(c), PL.fix(sc))),
+        PL.mul(PL.fix(sf), PL.mul(PL.adv(d, 1), PL.adv(e, -1))))
+    gate2 = PL.mul(PL.fix(sp), PL.sub(PL.adv(a), PL.inst(0)))
+    perm_columns = [(A_, a), (A_, b), (A_, c), (F_, sf), (A_, e), (A_, d), (I_, 0), (F_, sm), (F_, sa), (F_, sb), (F_, sc), (F_, sp)]
+    queries = {
+        A_: [(a, 0), (b, 0), (c, 0), (d, 1), (e, -1), (e, 0), (d, 0)],
+        F_: [(sf, 0), (sa, 0), (sb, 0), (sc, 0), (sm, 0), (sp, 0)],
+        I_: [(0, 0)],
+    }
+    circuit = CP.CqCircuit(k, 5, [], 6, 1, [gate1, gate2], perm_columns, queries)
+    u = n - (circuit.blinding_factors() + 1)
+    fixed = [[0] * n for _ in range(6)]
+    adv = [[0] * u for _ in range(5)]
+    asm = PL.Assembly(n, perm_columns)
+    av = 2834758237 * B.FR_ZETA % P
+    adv[a][0] = 2  # public_input: a = 1 + 1, sp = 1
+    fixed[sp][0] = 1
+    row = 1
+    for _ in range(10):
+        a2 = av * av % P
+        # raw_multiply (:95-153)
+        adv[a][row], adv[d][row], adv[b][row], adv[e][row], adv[c][row] = av, pow(av, 4, P), av, pow(av, 4, P), a2
+        fixed[sc][row], fixed[sm][row] = 1, 1
+        # raw_add (:154-212)
+        r2 = row + 1
+        adv[a][r2], adv[d][r2], adv[b][r2], adv[e][r2], adv[c][r2] = av, pow(av, 4, P), a2, pow(a2, 4, P), (a2 + av) % P
+        fixed[sa][r2], fixed[sb][r2], fixed[sc][r2] = 1, 1, 1
+        for _twice in range(2):  # `copy` constrains the pair twice (:213-226)
+            asm.copy((A_, a), row, (A_, a), r2)
+        for _twice in range(2):
+            asm.copy((A_, b), r2, (A_, c), row)
+        row += 2
+    return dict(circuit=circuit, fixed=fixed, advice=adv, instances=[[2]], mapping=asm.mapping, tables={})
+
+
+def oracle_env(k, s_seed=0x6371, builder=None, **kw):
     """Oracle-side params / pk for `chain_circuit` (SRS layout of tests/my_test.rs:179-205: table SRS over the
     table-sized domain, b0_g1_bound = [s^(n+1+i)]_1, srs_g1_len = 2n)."""
-    fx = chain_circuit(k, **kw)
+    fx = (builder or chain_circuit)(k, **kw)
     s = B.fr_random(B.Xoshiro256ss(s_seed))
     params = kzg.ParamsKZG(k, s)
     n = 1 << k
@@ -141,6 +190,8 @@ def to_backend_cs(circuit, gtables):
         cs.create_gate(f"g{gi}", [conv(g)])
     for li, lk in enumerate(circuit.lookups):
         cs.lookup_static(f"l{li}", [(cs.query_any(cols[A][c], 0) if isinstance(c, int) else conv(c), gtables[t]) for c, t in lk])
+    if circuit.queries is not None:  # registration order pinned by the fixture (e.g. the plonk_api.rs `configure`)
+        cs.advice_queries, cs.fixed_queries, cs.instance_queries = (list(circuit.queries[kk]) for kk in (A, F, I))
     assert cs.advice_queries == circuit.advice_queries()
     assert cs.fixed_queries == circuit.fixed_queries()
     assert cs.instance_queries == circuit.instance_queries()

@@ -10,7 +10,7 @@ from oracle import cq_prover as CP
 from oracle import cq_verifier as CV
 from oracle import plonk as PL
 
-from tests.plonk_fixtures import TABLE, oracle_env
+from tests.plonk_fixtures import TABLE, oracle_env, plonk_api_circuit
 
 P = B.R_MOD
 
@@ -22,11 +22,11 @@ def _vk(fx):
     return fixed_cm, perm_cm
 
 
-def _verify(fx, proof, instances=None):
+def _verify(fx, proof, instances=None, opener="gwc"):
     fixed_cm, perm_cm = _vk(fx)
     return CV.verify_proof(proof, fx["circuit"], 424242, fx["s"], fx["tables"], len(TABLE), fx["srs_g1_len"],
                            instances=fx["instances"] if instances is None else instances,
-                           fixed_commitments=fixed_cm, perm_commitments=perm_cm)
+                           fixed_commitments=fixed_cm, perm_commitments=perm_cm, opener=opener)
 
 
 def test_assembly_cycles():
@@ -90,3 +90,53 @@ def test_plonk_unsatisfied_witness_is_rejected():
     assert fixed_rows_next == 1
     tr = CP.create_proof(fx["params"], fx["pk"], adv, B.Xoshiro256ss(7), instances=fx["instances"])
     assert not _verify(fx, tr.proof)
+
+
+def test_plonk_api_shape_verifies():
+    """The reference's general end-to-end circuit (halo2_proofs/tests/plonk_api.rs `MyCircuit`, minus its legacy
+    lookup): 12 permutation columns at degree 3 -> 12 product sets chained through z_i(w^last X), queries at
+    next / cur / prev, public input 2.  As in the reference test, acceptance is the assertion."""
+    fx = oracle_env(5, builder=plonk_api_circuit)
+    cs = fx["circuit"]
+    assert cs.degree() == 3 and cs.blinding_factors() == 5
+    tr = CP.create_proof(fx["params"], fx["pk"], fx["advice"], B.Xoshiro256ss(3), instances=fx["instances"])
+    assert _verify(fx, tr.proof)
+    assert not _verify(fx, tr.proof, [[3]])  # wrong public input (plonk_api.rs:495-520 expects a failure too)
+
+
+def test_lagrange_interpolate_and_intermediate_sets():
+    """arithmetic.rs:425-478 / shplonk.rs:56-133 on a hand-made query list (the reference's proptest checks the
+    same grouping property: commitments with equal point sets share a rotation set)."""
+    from oracle import shplonk as SH
+    from oracle.poly import eval_polynomial
+
+    rng = B.Xoshiro256ss(5)
+    pts = [B.fr_random(rng) for _ in range(4)]
+    evs = [B.fr_random(rng) for _ in range(4)]
+    poly = SH.lagrange_interpolate(pts, evs)
+    assert len(poly) == 4 and all(eval_polynomial(poly, p) == e for p, e in zip(pts, evs))
+    assert SH.lagrange_interpolate(pts[:1], evs[:1]) == [evs[0]]
+    q = [("a", 1, 10), ("b", 1, 11), ("a", 2, 12), ("c", 2, 13), ("c", 1, 14), ("d", 3, 15)]
+    sets, sup = SH.construct_intermediate_sets(q)
+    assert sup == [1, 2, 3]
+    assert sets == [([1, 2], [("a", [10, 12]), ("c", [14, 13])]), ([1], [("b", [11])]), ([3], [("d", [15])])]
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(with_lookup=True)], ids=["deg3", "lookup"])
+def test_shplonk_proof_verifies(kw):
+    """ProverSHPLONK / VerifierSHPLONK (poly/kzg/multiopen/shplonk) on the same circuits: 2 commitments replace
+    the per-point witnesses, and the restated verifier equation accepts; tampering is rejected."""
+    fx = oracle_env(5, **kw)
+    gwc = CP.create_proof(fx["params"], fx["pk"], fx["advice"], B.Xoshiro256ss(7), instances=fx["instances"])
+    tr = CP.create_proof(fx["params"], fx["pk"], fx["advice"], B.Xoshiro256ss(7), instances=fx["instances"], opener="shplonk")
+    assert len(tr.proof) == len(gwc.proof) - 32 * 2  # 4 GWC witnesses (x, wx, w^-1 x, w^-(bf+1) x) -> 2 points
+    assert tr.proof[:-64] == gwc.proof[:-128]  # everything before the multi-open is shared
+    assert _verify(fx, tr.proof, opener="shplonk")
+    assert not _verify(fx, gwc.proof, opener="shplonk")
+    for pos in (len(tr.proof) - 100, len(tr.proof) - 20, 40):
+        bad = bytearray(tr.proof)
+        bad[pos] ^= 1
+        try:
+            assert not _verify(fx, bytes(bad), opener="shplonk")
+        except ValueError:
+            pass

@@ -8,7 +8,7 @@ import pytest
 from oracle import bn254 as B
 from oracle import cq_prover as CP
 from oracle import cq_verifier as CV
-from tests.plonk_fixtures import TABLE, chain_circuit, oracle_env, to_backend_cs
+from tests.plonk_fixtures import TABLE, chain_circuit, oracle_env, plonk_api_circuit, to_backend_cs
 
 pytestmark = pytest.mark.gpu
 P = B.R_MOD
@@ -53,6 +53,32 @@ def test_plonk_proof_bytes_match_oracle(ctx, kw):
     assert proof == tr.proof
 
 
+def test_plonk_api_shape_proof_bytes(ctx):
+    """halo2_proofs/tests/plonk_api.rs `MyCircuit` without its legacy lookup: 12 chained product sets."""
+    k = 5
+    fx = oracle_env(k, builder=plonk_api_circuit)
+    gpk, _ = _backend_pk(ctx, fx, k, fx["s"])
+    tr = CP.create_proof(fx["params"], fx["pk"], fx["advice"], B.Xoshiro256ss(3), instances=fx["instances"])
+    proof = gpk.create_proof(_advice_cols(fx, 1 << k), seed=3, instances=[B.to_mont_limbs(i) for i in fx["instances"]])
+    assert proof == tr.proof and len(proof) == gpk.proof_size
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(degree5=True), dict(with_lookup=True)], ids=["deg3", "deg5", "lookup"])
+def test_shplonk_proof_bytes_match_oracle(ctx, kw):
+    """ProverSHPLONK (poly/kzg/multiopen/shplonk/prover.rs:120-286) instead of ProverGWC."""
+    k = 5
+    fx = oracle_env(k, **kw)
+    gpk, _ = _backend_pk(ctx, fx, k, fx["s"], b0=fx["pk"].b0_g1_bound)
+    gpk.set_opener("shplonk")
+    tr = CP.create_proof(fx["params"], fx["pk"], fx["advice"], B.Xoshiro256ss(21), instances=fx["instances"], opener="shplonk")
+    proof = gpk.create_proof(_advice_cols(fx, 1 << k), seed=21, instances=[B.to_mont_limbs(i) for i in fx["instances"]])
+    assert len(proof) == gpk.proof_size == len(tr.proof)
+    assert proof == tr.proof
+    gpk.set_opener("gwc")
+    tr = CP.create_proof(fx["params"], fx["pk"], fx["advice"], B.Xoshiro256ss(21), instances=fx["instances"])
+    assert gpk.create_proof(_advice_cols(fx, 1 << k), seed=21, instances=[B.to_mont_limbs(i) for i in fx["instances"]]) == tr.proof
+
+
 def test_plonk_instance_too_large_and_missing(ctx):
     from sha2_on_cq_halo2_amd import CqError
 
@@ -81,11 +107,14 @@ def test_plonk_large_proof_verifies(ctx, k, kw):
     cols = _advice_cols(fx, n)
     proof = gpk.create_proof(cols, seed=5, instances=inst)
 
-    def verify(pr):
+    def verify(pr, opener="gwc"):
         return CV.verify_proof(pr, fx["circuit"], 424242, s, fx["tables"], len(TABLE), n, instances=fx["instances"],
-                               fixed_commitments=to_pts(fcm), perm_commitments=to_pts(pcm))
+                               fixed_commitments=to_pts(fcm), perm_commitments=to_pts(pcm), opener=opener)
 
     assert verify(proof)
+    gpk.set_opener("shplonk")
+    assert verify(gpk.create_proof(cols, seed=5, instances=inst), "shplonk")
+    gpk.set_opener("gwc")
     # break one copy constraint while keeping every gate satisfied: b[0] is tied to a fixed cell only by the permutation
     adv = [list(c) for c in fx["advice"]]
     adv[1][0] = (adv[1][0] + 5) % P
