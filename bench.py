@@ -39,6 +39,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--k", type=int, default=18)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-plonk-variant", action="store_true")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -115,7 +116,7 @@ def main():
         "higher_is_better": True,
         "scaling": "strong" if shard else "weak",
         "vs_baseline": None,
-        "dtype": "u256-montgomery (8x u32 limbs)",
+        "dtype": "u256-montgomery",
         "data": "synthetic (SHA-256 trace of bytes i mod 251; KZG/table SRS from a seeded toxic waste, built on the GPU)",
         "config": {
             "workload": f"k={k} {wl.blocks}-block SHA-256-shaped CQ circuit: {2 * wl.pairs} advice columns, {wl.pairs} width-2 static "
@@ -161,12 +162,37 @@ def main():
             "launches": int(ntt_calls),
             "melem_per_s": ntt_elems / (ntt_ms / 1e3) / 1e6 if ntt_ms > 0 else 0.0,
         }
+        if world == 1 and not args.no_plonk_variant:
+            out["plonk_variant"] = plonk_variant(ctx, wl, max(2, min(args.steps, 5)))
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(ctx)
         print(json.dumps(out), flush=True)
     ctx.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def plonk_variant(ctx, wl, steps):
+    """Secondary figure (not `value`): the same SHA-shaped circuit with a custom gate (rotation), a selector
+    column and copy constraints around the lookups -- the general-PLONK path (gate interpreter, permutation
+    grand product by scan, multi-point openings), with both multi-open schemes."""
+    import torch
+
+    from sha2_on_cq_halo2_amd.sha_circuit import ShaPlonkWorkload
+
+    pw = ShaPlonkWorkload(ctx, wl.k, seed=0x5348413243515F, share=wl)
+    res = {"workload": f"k={wl.k}: {2 * wl.pairs + 2} advice + 1 fixed columns, 2 gates (one with Rotation::next), "
+                       f"{wl.pairs} static lookups, permutation over 2 columns ({2 ** wl.k - 7} copy constraints)"}
+    for opener in ("gwc", "shplonk"):
+        pw.pk.set_opener(opener)
+        proof = pw.prove(seed=1)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            proof = pw.prove(seed=2 + i)
+        torch.cuda.synchronize()
+        res[opener] = {"ms_per_proof": (time.perf_counter() - t0) / steps * 1e3, "proof_bytes": len(proof)}
+    return res
 
 
 def pmc_traffic(kernel):

@@ -88,23 +88,26 @@ class ShaCqWorkload:
     """Proving key + device-resident witness for the SHA-shaped CQ circuit at 2^k rows."""
 
     def __init__(self, ctx: Context, k: int, pairs: int = 4, blocks: int | None = None, seed: int = 0x5348413243515F,
-                 table_bits: int = TABLE_BITS):
+                 table_bits: int = TABLE_BITS, share: "ShaCqWorkload | None" = None):
         import ctypes as C
 
         self.ctx, self.k, self.pairs = ctx, k, pairs
         n = 1 << k
         self.n = n
         N = 1 << table_bits
-        s = fr_to_mont(seed * 0x9E3779B97F4A7C15 + 12345)
-        self.params = ParamsKZG.setup_from_toxic_waste(ctx, k, s)
-        self.cfg = TableConfig.setup_from_toxic_waste(ctx, N, s)
-        idx = np.arange(N)
-        self.dense = StaticTable.setup_from_toxic_waste(ctx, small_to_mont(idx), s)
-        self.spread = StaticTable.setup_from_toxic_waste(ctx, small_to_mont(spread16(idx)), s)
+        if share is not None:  # same SRS / tables as another workload of the same size (setup is not what is measured)
+            assert share.k == k and share.cfg.size == N
+            self.params, self.cfg, self.dense, self.spread = share.params, share.cfg, share.dense, share.spread
+        else:
+            s = fr_to_mont(seed * 0x9E3779B97F4A7C15 + 12345)
+            self.params = ParamsKZG.setup_from_toxic_waste(ctx, k, s)
+            self.cfg = TableConfig.setup_from_toxic_waste(ctx, N, s)
+            idx = np.arange(N)
+            self.dense = StaticTable.setup_from_toxic_waste(ctx, small_to_mont(idx), s)
+            self.spread = StaticTable.setup_from_toxic_waste(ctx, small_to_mont(spread16(idx)), s)
         lookups = [[(2 * p, self.dense), (2 * p + 1, self.spread)] for p in range(pairs)]
         # b0 bound over the circuit SRS itself: srs_g1_len = n  =>  [s^1 .. s^(n-1)]_1 = g[1..]
-        self.pk = ProvingKey(ctx, self.params, k, 2 * pairs, lookups, self.cfg, self.params.g_dev + 64,
-                             fr_to_mont(0xC0FFEE + k))
+        self.pk = self._make_pk(lookups)
         u = self.pk.usable_rows
         if blocks is None:
             blocks = BLOCKS_FOR_K.get(k, max(1, (u * pairs) // (3 * 8 * 64)))
@@ -117,6 +120,14 @@ class ShaCqWorkload:
         self.words_dev = ctx.to_device(words)
         self.cols = [ctx.alloc(n * 32) for _ in range(2 * pairs)]
         self.fill_witness()
+        self._extra_witness(words)
+
+    def _make_pk(self, lookups):
+        return ProvingKey(self.ctx, self.params, self.k, 2 * self.pairs, lookups, self.cfg, self.params.g_dev + 64,
+                          fr_to_mont(0xC0FFEE + self.k))
+
+    def _extra_witness(self, words):
+        pass
 
     def fill_witness(self):
         """SHA word -> limb witness fill on the GPU (cq_sha_witness_fill_dev)."""
@@ -141,3 +152,54 @@ class ShaCqWorkload:
     def ntt_elems_per_proof(self) -> int:
         L, A, n = self.pairs, 2 * self.pairs, self.n
         return (2 * L + A) * n + 2 * L * 2 * n + 2 * n  # iNTT(b,f), iNTT(advice), coset NTTs, iNTT(ext)
+
+
+class ShaPlonkWorkload(ShaCqWorkload):
+    """The SHA-shaped CQ circuit plus what a real SHA-2 circuit wraps around its lookups: a custom gate with a
+    rotation, a fixed selector, and copy constraints.  Two more advice columns: `w` = limb0 + 2^16 * limb1 of
+    each row (gate `q * (a0 + 2^16 * a2 - w)`), `w2[r] = w[r+1]` (gate `q * (w2 - w@next)` and, for every row, a
+    copy constraint (w2, r) == (w, r+1)); permutation over (w, w2) -> two product sets at degree 3."""
+
+    def _make_pk(self, lookups):
+        from . import plonk as GP
+
+        n, pairs = self.n, self.pairs
+        cs = GP.ConstraintSystem()
+        adv = [cs.advice_column() for _ in range(2 * pairs + 2)]
+        q = cs.fixed_column()
+        w, w2 = adv[2 * pairs], adv[2 * pairs + 1]
+        cs.enable_equality(w)
+        cs.enable_equality(w2)
+        qe = cs.query_fixed(q)
+        cs.create_gate("recompose", [qe * (cs.query_advice(adv[0]) + cs.query_advice(adv[2]) * (1 << 16) - cs.query_advice(w))])
+        cs.create_gate("shift", [qe * (cs.query_advice(w2) - cs.query_advice(w, 1))])
+        for lk in lookups:
+            cs.lookup_static("limb", [(adv[c], t) for c, t in lk])
+        self.cs = cs
+        u = n - (cs.blinding_factors() + 1)
+        self.rows = u - 1  # gate / copy rows: w@next must stay inside the usable rows
+        qcol = np.zeros((n, 4), dtype=np.uint64)
+        qcol[: self.rows] = fr_to_mont(1)
+        # copy constraints (w2, r) == (w, r+1): disjoint 2-cycles, written directly as Assembly.mapping
+        mapping = np.zeros((2, n, 2), dtype=np.uint32)
+        mapping[0, :, 0], mapping[1, :, 0] = 0, 1
+        mapping[:, :, 1] = np.arange(n, dtype=np.uint32)
+        r = np.arange(self.rows, dtype=np.uint32)
+        mapping[1, r, 0], mapping[1, r, 1] = 0, r + 1
+        mapping[0, r + 1, 0], mapping[0, r + 1, 1] = 1, r
+        return ProvingKey(self.ctx, self.params, self.k, 0, [], self.cfg, self.params.g_dev + 64, fr_to_mont(0xC0FFEE + self.k),
+                          cs=cs, fixed=[qcol], permutation=mapping)
+
+    def _extra_witness(self, words):
+        n, pairs, u = self.n, self.pairs, self.pk.usable_rows
+        wv = words.astype(np.uint64)
+        limbs = np.stack([wv >> 20, (wv >> 10) & 0x3FF, wv & 0x3FF], axis=1).reshape(-1)  # (x, y, z) of tables.rs:135-154
+        grid = np.zeros(u * pairs, dtype=np.uint64)
+        grid[: limbs.shape[0]] = limbs
+        grid = grid.reshape(u, pairs)  # limb t -> row t // pairs, pair t % pairs (cq_sha_witness_fill_dev)
+        wcol = grid[:, 0] + (grid[:, 1] << np.uint64(16))
+        wm = np.zeros((n, 4), dtype=np.uint64)
+        wm[:u] = small_to_mont(wcol)
+        w2m = np.zeros((n, 4), dtype=np.uint64)
+        w2m[: u - 1] = wm[1:u]
+        self.cols += [self.ctx.to_device(wm), self.ctx.to_device(w2m)]

@@ -120,3 +120,38 @@ def test_k18_proof_is_accepted_and_deterministic(ctx):
     assert p1 == p2 and p1 != p3
     s = (seed * 0x9E3779B97F4A7C15 + 12345) % B.R_MOD
     assert _verify_workload_proof(wl, p1, s)
+
+
+@pytest.mark.parametrize("k", [10, 14])
+def test_sha_plonk_workload_proof_is_accepted(ctx, k):
+    """SHA-shaped circuit with a custom gate (rotation), a selector and copy constraints around the lookups
+    (`ShaPlonkWorkload`): the proof satisfies the restated verifier; a broken copy does not."""
+    from oracle import plonk as PL
+    from sha2_on_cq_halo2_amd.sha_circuit import ShaPlonkWorkload
+
+    seed = 0x5348413243515F
+    wl = ShaPlonkWorkload(ctx, k, seed=seed)
+    s = (seed * 0x9E3779B97F4A7C15 + 12345) % B.R_MOD
+    N = wl.cfg.size
+    A = 2 * wl.pairs
+    w, w2 = A, A + 1
+    gates = [PL.mul(PL.fix(0), PL.sub(PL.add(PL.adv(0), PL.scale(PL.adv(2), 1 << 16)), PL.adv(w))),
+             PL.mul(PL.fix(0), PL.sub(PL.adv(w2), PL.adv(w, 1)))]
+    circ = CP.CqCircuit(k, A + 2, [[(2 * p, "dense"), (2 * p + 1, "spread")] for p in range(wl.pairs)], 1, 0, gates,
+                        [(PL.ADVICE, w), (PL.ADVICE, w2)])
+    assert circ.advice_queries() == wl.cs.advice_queries and circ.fixed_queries() == wl.cs.fixed_queries
+    tv = {"dense": list(range(N)), "spread": [_spread(i) for i in range(N)]}
+    fcm, pcm = wl.pk.vk_commitments()
+
+    def verify(pr):
+        return CV.verify_proof(pr, circ, 0xC0FFEE + k, s, tv, N, 1 << k, fixed_commitments=B.points_from_mont_limbs(fcm),
+                               perm_commitments=B.points_from_mont_limbs(pcm))
+
+    proof = wl.prove(seed=4)
+    assert len(proof) == wl.pk.proof_size and verify(proof)
+    # w2[7] no longer equals w[8]: the `shift` gate and the copy constraint both fail
+    n = 1 << k
+    col = wl.cols[w2].download((n, 4))
+    col[7] = B.to_mont_limbs([12345])[0]
+    wl.cols[w2].upload(col)
+    assert not verify(wl.prove(seed=4))
