@@ -101,8 +101,10 @@ int cq_g1_to_affine(const uint64_t jac[12], uint64_t out_affine[8]);
  * HBM) for a device-resident base array and registers them with the context; later multiexps over
  * that array (or a prefix of it) then need a single bucket set and no window folding.  cq_params_*
  * does this for g and g_lagrange unless disabled with cq_msm_set_precompute(ctx, 0).  Results are
- * identical either way. */
+ * identical either way.  The tables are a snapshot of the array: call cq_msm_forget_dev before the array is
+ * freed or overwritten (cq_dev_free does it for arrays it frees). */
 int cq_msm_precompute_dev(cq_ctx* ctx, const uint64_t* bases_dev, size_t n);
+int cq_msm_forget_dev(cq_ctx* ctx, const uint64_t* bases_dev);
 int cq_msm_set_precompute(cq_ctx* ctx, int on);
 /* Pippenger window width in bits (2..15), 0 = automatic.  Tuning knob; results do not depend on it. */
 int cq_msm_set_window(cq_ctx* ctx, uint32_t bits);
@@ -341,6 +343,8 @@ uint64_t cq_buffer_rng_next_u64(void* state /* cq_buffer_rng* */);
  * (and forgets those spans). */
 #define CQ_PROF_MSM_ACCUMULATE 1 /* msm_accumulate_kernel: bucket accumulation (mixed additions) */
 #define CQ_PROF_NTT_PASS 2       /* ntt_pass_kernel: one radix-2^deg Stockham pass */
+#define CQ_PROF_MSM_ENTRIES 3    /* no timing: `calls` = (point, non-zero digit) pairs = mixed additions executed by
+                                  * msm_accumulate_kernel since the last read */
 int cq_profile_enable(cq_ctx* ctx, int on);
 int cq_profile_read(cq_ctx* ctx, int id, double* total_ms, uint64_t* calls);
 

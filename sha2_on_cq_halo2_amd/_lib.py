@@ -145,6 +145,7 @@ def _declare(lib):  # noqa: F811
     lib.cq_buffer_rng_next_u64.argtypes = [vp]
     lib.cq_msm_precompute_dev.argtypes = [vp, vp, C.c_size_t]
     lib.cq_msm_set_precompute.argtypes = [vp, C.c_int]
+    lib.cq_msm_forget_dev.argtypes = [vp, vp]
     lib.cq_sha_synthesis_table_dev.argtypes = [vp, C.c_int, C.c_uint32, C.c_uint32, vp]
     lib.cq_sha_decomposition_table_dev.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, vp]
     lib.cq_static_table_new.argtypes = [vp, C.c_size_t, vp, vp, C.POINTER(vp)]

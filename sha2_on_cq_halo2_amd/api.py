@@ -224,6 +224,7 @@ class ParamsKZG:
 
 PROF_MSM_ACCUMULATE = 1
 PROF_NTT_PASS = 2
+PROF_MSM_ENTRIES = 3
 
 
 def _ctx_profile_enable(self, on: bool = True):

@@ -1,5 +1,6 @@
 // C ABI: context, device memory, arithmetic.rs entry points.  See include/cq_halo2.h.
 #include "ctx.hpp"
+#include "msm.hpp"
 #include "poly.hpp"
 #include <cstring>
 
@@ -55,6 +56,7 @@ void cq_ctx_destroy(cq_ctx* c) {
     if (c->scratch[i]) hipFree(c->scratch[i]);
   if (c->pinned) hipHostFree(c->pinned);
   if (c->pinned_msm) hipHostFree(c->pinned_msm);
+  if (c->prof_entries) hipHostFree(c->prof_entries);
   if (c->fb_table) hipFree(c->fb_table);
   for (auto& t : c->msm_tables) hipFree(t.table);
   if (c->own_stream) hipStreamDestroy(c->stream);
@@ -81,6 +83,7 @@ int cq_dev_free(cq_ctx* c, void* dptr) {
   if (!c) return CQ_ERR_ARG;
   if (!dptr) return CQ_OK;
   CQ_HIP(c, hipStreamSynchronize(c->stream));
+  msm_unregister_tables(c, dptr);  // window tables built from this array must not outlive it
   CQ_HIP(c, hipFree(dptr));
   return CQ_OK;
 }
@@ -108,6 +111,10 @@ int cq_dev_memset(cq_ctx* c, void* dptr, int value, size_t bytes) {
 // ---- per-kernel timing (HIP events on the context's stream) ---------------------------------------
 int cq_profile_enable(cq_ctx* c, int on) {
   if (!c) return CQ_ERR_ARG;
+  if (on && !c->prof_entries) {
+    hipError_t e = hipHostMalloc((void**)&c->prof_entries, cq_ctx::PROF_COUNTERS * sizeof(uint32_t), hipHostMallocDefault);
+    if (e != hipSuccess) return c->hip_fail(e, "hipHostMalloc(profile counters)");
+  }
   c->prof_on = on != 0;
   return CQ_OK;
 }
@@ -117,6 +124,13 @@ int cq_profile_read(cq_ctx* c, int id, double* total_ms, uint64_t* calls) {
   CQ_HIP(c, hipStreamSynchronize(c->stream));
   double tot = 0;
   uint64_t n = 0;
+  if (id == CQ_PROF_MSM_ENTRIES) {
+    for (size_t i = 0; i < c->prof_entries_n; i++) n += c->prof_entries[i];
+    c->prof_entries_n = 0;
+    *total_ms = 0;
+    *calls = n;
+    return CQ_OK;
+  }
   std::vector<cq_ctx::ProfSpan> keep;
   for (auto& sp : c->prof_spans) {
     if (sp.id != id) {

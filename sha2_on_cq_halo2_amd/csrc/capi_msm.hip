@@ -177,6 +177,13 @@ int cq_msm_precompute_dev(cq_ctx* c, const uint64_t* bases_dev, size_t n) {
   return msm_register_tables(c, (const G1Affine*)bases_dev, n);
 }
 
+int cq_msm_forget_dev(cq_ctx* c, const uint64_t* bases_dev) {
+  if (!c || !bases_dev) return CQ_ERR_ARG;
+  CQ_HIP(c, hipStreamSynchronize(c->stream));
+  msm_unregister_tables(c, bases_dev);
+  return CQ_OK;
+}
+
 int cq_msm_set_precompute(cq_ctx* c, int on) {
   if (!c) return CQ_ERR_ARG;
   c->msm_precompute = on != 0;

@@ -42,6 +42,10 @@ struct cq_ctx {
   struct ProfSpan { int id; hipEvent_t a, b; };
   bool prof_on = false;
   std::vector<ProfSpan> prof_spans;
+  // (point, digit) entries handed to msm_accumulate_kernel, one pinned counter per launch while profiling
+  static constexpr size_t PROF_COUNTERS = 4096;
+  uint32_t* prof_entries = nullptr;
+  size_t prof_entries_n = 0;
   hipEvent_t prof_begin(int id) {
     if (!prof_on) return nullptr;
     ProfSpan sp;

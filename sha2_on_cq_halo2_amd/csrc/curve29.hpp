@@ -1,0 +1,180 @@
+// BN254 G1 group law on the lazy 9 x 29-bit field (field29.hpp) for the MSM kernels.
+//
+// Same formulas as curve.hpp (XYZZ: madd-2008-s, add-2008-s, dbl-2008-s-1) -- results are the same group
+// elements, so nothing that reaches the transcript changes -- but coordinates stay in limb form in registers
+// and range over [0, K p).  Invariant of every XYZZ29 held in registers, LDS or memory:
+//     x < 8 p,  y < 4 p,  zz, zzz < 2 p,  limbs normalised;  identity <=> all limbs of zz are zero
+// (zz of a finite point is non-zero mod p, so its limbs cannot all vanish; the special cases that produce the
+// identity set it explicitly).  The bound of every intermediate is given as a multiple of p in the comments; a
+// product needs (bound a) * (bound b) <= 128.
+#pragma once
+#include "curve.hpp"
+#include "field29.hpp"
+
+namespace cq {
+
+struct XYZZ29 {
+  Fq29 x, y, zz, zzz;
+  static __device__ __forceinline__ XYZZ29 identity() { return {Fq29::zero(), Fq29::zero(), Fq29::zero(), Fq29::zero()}; }
+  __device__ __forceinline__ bool is_identity() const { return zz.limbs_zero(); }
+};
+
+// affine point in R' form (x, y < 2 p); identity = (0, 0) with all limbs zero
+struct Affine29 {
+  Fq29 x, y;
+  __device__ __forceinline__ bool is_identity() const { return x.limbs_zero() && y.limbs_zero(); }
+};
+
+// ---- memory <-> registers ---------------------------------------------------------------------------------
+static __device__ __forceinline__ void ld8(const void* p, uint32_t* w) {
+  const uint4* q = reinterpret_cast<const uint4*>(p);
+  const uint4 a = q[0], b = q[1];
+  w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w;
+  w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
+}
+static __device__ __forceinline__ void st8(void* p, const uint32_t* w) {
+  uint4* q = reinterpret_cast<uint4*>(p);
+  q[0] = make_uint4(w[0], w[1], w[2], w[3]);
+  q[1] = make_uint4(w[4], w[5], w[6], w[7]);
+}
+// table / SRS point.  `mont256`: the array holds the reference's R = 2^256 values (converted with one product per
+// coordinate); otherwise it is a library-built table already in R' form.
+static __device__ __forceinline__ Affine29 load_affine29(const G1Affine* p, bool mont256) {
+  uint32_t wx[8], wy[8];
+  ld8(&p->x, wx);
+  ld8(&p->y, wy);
+  Affine29 r;
+  r.x = Fq29::unpack(wx);
+  r.y = Fq29::unpack(wy);
+  if (mont256) {
+    Fq29 f;
+    CQ_UNROLL for (int i = 0; i < 9; i++) f.a[i] = CONSTS29<FqP>.from256[i];
+    r.x = Fq29::mul(r.x, f);  // 0 stays 0 (identity)
+    r.y = Fq29::mul(r.y, f);
+  }
+  return r;
+}
+// partial sums / buckets: 4 x (8 x u32) holding R'-form values below 2^256 (x is reduced first: 8 p > 2^256)
+static __device__ __forceinline__ XYZZ29 load_xyzz29(const XYZZ* p) {
+  uint32_t w[8];
+  XYZZ29 r;
+  ld8(&p->x, w);   r.x = Fq29::unpack(w);
+  ld8(&p->y, w);   r.y = Fq29::unpack(w);
+  ld8(&p->zz, w);  r.zz = Fq29::unpack(w);
+  ld8(&p->zzz, w); r.zzz = Fq29::unpack(w);
+  return r;
+}
+static __device__ __forceinline__ void store_xyzz29(XYZZ* p, const XYZZ29& v) {
+  uint32_t w[8];
+  const Fq29 xr = v.x.reduced();  // < 2 p
+  xr.pack(w);    st8(&p->x, w);
+  v.y.pack(w);   st8(&p->y, w);   // 4 p < 2^256
+  v.zz.pack(w);  st8(&p->zz, w);
+  v.zzz.pack(w); st8(&p->zzz, w);
+}
+
+// ---- group law ----------------------------------------------------------------------------------------------
+// 2 * (ax, ay), affine in (x, y < 2 p)
+static __device__ __forceinline__ XYZZ29 xyzz29_dbl_affine(const Affine29& a) {
+  if (a.is_identity()) return XYZZ29::identity();
+  const Fq29 u = a.y + a.y;                    // < 4
+  const Fq29 v = u.sqr();                      // 16 -> < 2
+  const Fq29 w = u * v;                        // 8
+  const Fq29 s = a.x * v;                      // 4
+  const Fq29 x2 = a.x.sqr();                   // 4
+  Fq29 m = x2 + x2 + x2;                       // < 6, limbs < 3 * 2^29
+  m.normalise();
+  const Fq29 x3 = Fq29::sub<4>(m.sqr(), s + s);                   // 36; s + s < 4  ->  x3 < 6
+  const Fq29 y3 = Fq29::sub<2>(m * Fq29::sub<8>(s, x3), w * a.y);  // (s - x3) < 10, 6 * 10 = 60; w * y: 4  ->  y3 < 4
+  return {x3, y3, v, w};
+}
+
+static __device__ __forceinline__ XYZZ29 xyzz29_dbl(const XYZZ29& p) {
+  if (p.is_identity()) return XYZZ29::identity();
+  const Fq29 u = p.y + p.y;                    // < 8, limbs < 2^30
+  const Fq29 v = u.sqr();                      // 64
+  const Fq29 w = u * v;                        // 16
+  const Fq29 s = p.x * v;                      // 16
+  const Fq29 x2 = p.x.sqr();                   // 64
+  Fq29 m = x2 + x2 + x2;                       // < 6
+  m.normalise();
+  const Fq29 x3 = Fq29::sub<4>(m.sqr(), s + s);                   // x3 < 6
+  const Fq29 y3 = Fq29::sub<2>(m * Fq29::sub<8>(s, x3), w * p.y);  // 60; 2 * 4 = 8  ->  y3 < 4
+  return {x3, y3, v * p.zz, w * p.zzz};
+}
+
+// acc += a, complete (identity operands, a == acc, a == -acc)
+static __device__ __forceinline__ void xyzz29_add_affine(XYZZ29& acc, const Affine29& a) {
+  if (a.is_identity()) return;
+  if (acc.is_identity()) {
+    acc = {a.x, a.y, Fq29::one(), Fq29::one()};
+    return;
+  }
+  const Fq29 u2 = a.x * acc.zz;                // 4
+  const Fq29 s2 = a.y * acc.zzz;               // 4
+  const Fq29 p = Fq29::sub<8>(u2, acc.x);      // < 10
+  const Fq29 r = Fq29::sub<4>(s2, acc.y);      // < 6
+  const Fq29 pp = p.sqr();                     // 100
+  if (pp.is_zero_mod_p()) {                    // same x: doubling or cancellation
+    if (r.sqr().is_zero_mod_p()) acc = xyzz29_dbl_affine(a);
+    else acc = XYZZ29::identity();
+    return;
+  }
+  const Fq29 ppp = p * pp;                     // 20
+  const Fq29 q = acc.x * pp;                   // 16
+  const Fq29 x3 = Fq29::sub<6, 31>(r.sqr(), ppp + q + q);               // 36; subtrahend < 6, limbs < 3 * 2^29  ->  x3 < 8
+  const Fq29 y3 = Fq29::sub<2>(r * Fq29::sub<8>(q, x3), acc.y * ppp);   // 6 * 10 = 60; 4 * 2 = 8  ->  y3 < 4
+  acc.x = x3;
+  acc.y = y3;
+  acc.zz = acc.zz * pp;                        // 4
+  acc.zzz = acc.zzz * ppp;                     // 4
+}
+
+// acc += b, complete
+static __device__ __forceinline__ void xyzz29_add(XYZZ29& acc, const XYZZ29& b) {
+  if (b.is_identity()) return;
+  if (acc.is_identity()) {
+    acc = b;
+    return;
+  }
+  const Fq29 u1 = acc.x * b.zz;                // 16
+  const Fq29 u2 = b.x * acc.zz;                // 16
+  const Fq29 s1 = acc.y * b.zzz;               // 8
+  const Fq29 s2 = b.y * acc.zzz;               // 8
+  const Fq29 p = Fq29::sub<2>(u2, u1);         // < 4
+  const Fq29 r = Fq29::sub<2>(s2, s1);         // < 4
+  const Fq29 pp = p.sqr();                     // 16
+  if (pp.is_zero_mod_p()) {
+    if (r.sqr().is_zero_mod_p()) acc = xyzz29_dbl(acc);
+    else acc = XYZZ29::identity();
+    return;
+  }
+  const Fq29 ppp = p * pp;                     // 8
+  const Fq29 q = u1 * pp;                      // 4
+  const Fq29 x3 = Fq29::sub<6, 31>(r.sqr(), ppp + q + q);              // x3 < 8
+  const Fq29 y3 = Fq29::sub<2>(r * Fq29::sub<8>(q, x3), s1 * ppp);     // 4 * 10 = 40; 4  ->  y3 < 4
+  acc.x = x3;
+  acc.y = y3;
+  acc.zz = acc.zz * b.zz * pp;                 // 4, 4
+  acc.zzz = acc.zzz * b.zzz * ppp;
+}
+
+// Jacobian representative (X ZZ, Y ZZZ, ZZ) in the reference's layout: canonical R = 2^256 Montgomery values
+static __device__ __forceinline__ G1Jac xyzz29_to_jac(const XYZZ29& v) {
+  if (v.is_identity()) return G1Jac::identity();
+  return {(v.x * v.zz).to_mont256(), (v.y * v.zzz).to_mont256(), v.zz.to_mont256()};  // 16, 8
+}
+
+static __device__ __forceinline__ XYZZ29 xyzz29_shfl_down(const XYZZ29& a, int delta) {
+  XYZZ29 r;
+#pragma unroll
+  for (int k = 0; k < 9; k++) {
+    r.x.a[k] = __shfl_down(a.x.a[k], delta, 64);
+    r.y.a[k] = __shfl_down(a.y.a[k], delta, 64);
+    r.zz.a[k] = __shfl_down(a.zz.a[k], delta, 64);
+    r.zzz.a[k] = __shfl_down(a.zzz.a[k], delta, 64);
+  }
+  return r;
+}
+
+}  // namespace cq

@@ -1,0 +1,229 @@
+// Device-only "lazy" field type for the elliptic-curve kernels: the value lives in registers as 9 unsaturated
+// 29-bit limbs in Montgomery form with R' = 2^261 (nine whole digits), not 8 x 32 with R = 2^256.
+//
+// Why: with Fp (field.hpp) every product unpacks two operands to 29-bit limbs, repacks the result and ends
+// with a conditional subtraction -- about as many instructions as the 162 multiplies themselves.  Keeping
+// operands in limb form between operations, and letting values range over [0, K p) instead of [0, p),
+// removes all of that: a product is 81 + 81 v_mad_u64_u32, 9 digit multiplies and the carry shifts.
+//
+// Contract (K-bounds are tracked in comments at every call site in curve29.hpp):
+//   * "normalised": limbs 0..7 < 2^29 (the top limb holds whatever is left).  mul() needs limb products to fit
+//     64-bit columns: limbs of one operand < 2^30 and of the other < 2^30 (9 * 2^60 + 9 * 2^58 + carries < 2^64).
+//   * mul(a, b) with a < Ka p, b < Kb p, Ka * Kb <= 128: result normalised and < 2 p   (R' = 2^261 > 128 p).
+//   * add() is limb-wise (no carries); sub<K>(a, b) = a + (K p - b) with K p in a borrow-proof limb form, then
+//     normalised; requires b < K p with normalised-or-sum limbs (< 2^30).
+// Memory formats stay what they were: R = 2^256 Montgomery values (the reference's bytes) are converted with one
+// product on load (from_mont256) / store (to_mont256); library-internal arrays (window tables, partial sums)
+// hold the R' form packed into 8 x u32 (values < 2^256 there).
+#pragma once
+#include "field.hpp"
+
+namespace cq {
+
+// ---- compile-time limb constants ----------------------------------------------------------------------------
+struct Consts29 {
+  uint32_t one[9];      // R' mod p      (the field's 1)
+  uint32_t to256[9];    // 2^256 mod p   : mul(x, to256) turns x R' into x R
+  uint32_t from256[9];  // 2^266 mod p   : mul(y, from256) turns y = x R into x R'
+};
+struct Limbs29 {
+  uint32_t l[9];
+};
+
+// 2^e mod p by repeated doubling on 9 x 29-bit limbs
+template <class P>
+constexpr void pow2_mod_p29(int e, uint32_t* out) {
+  constexpr uint32_t M29 = 0x1fffffffu;
+  uint32_t v[9] = {1, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int s = 0; s < e; s++) {
+    uint32_t carry = 0;
+    for (int i = 0; i < 9; i++) {
+      const uint32_t t = (v[i] << 1) | carry;
+      carry = t >> 29;
+      v[i] = t & M29;
+    }
+    bool ge = true;  // v < 2p: subtract p once if v >= p
+    for (int i = 8; i >= 0; i--) {
+      if (v[i] != Fp<P>::p29(i)) {
+        ge = v[i] > Fp<P>::p29(i);
+        break;
+      }
+    }
+    if (ge) {
+      uint32_t borrow = 0;
+      for (int i = 0; i < 9; i++) {
+        const uint32_t sub_ = Fp<P>::p29(i) + borrow;
+        if (v[i] >= sub_) {
+          v[i] -= sub_;
+          borrow = 0;
+        } else {
+          v[i] = v[i] + (1u << 29) - sub_;
+          borrow = 1;
+        }
+      }
+    }
+  }
+  for (int i = 0; i < 9; i++) out[i] = v[i];
+}
+template <class P>
+constexpr Consts29 make_consts29() {
+  Consts29 c{};
+  pow2_mod_p29<P>(261, c.one);
+  pow2_mod_p29<P>(256, c.to256);
+  pow2_mod_p29<P>(266, c.from256);
+  return c;
+}
+template <class P>
+inline constexpr Consts29 CONSTS29 = make_consts29<P>();
+
+// K*p in "borrow-proof" limb form: every limb below the top one carries an extra 2^PAD that the next limb pays for
+// (2^PAD * 2^(29 j) = 2^(PAD-29) * 2^(29 (j+1))), so  limb_j - b_j  cannot go negative for b_j < 2^PAD.  The limbs
+// still sum to K p.
+template <class P, uint32_t K, uint32_t PAD>
+constexpr Limbs29 make_kp29() {
+  Limbs29 r{};
+  uint64_t carry = 0;
+  for (int i = 0; i < 9; i++) {
+    const uint64_t t = (uint64_t)Fp<P>::p29(i) * K + carry;
+    r.l[i] = i < 8 ? (uint32_t)(t & 0x1fffffffu) : (uint32_t)t;
+    carry = t >> 29;
+  }
+  for (int i = 0; i < 8; i++) {
+    r.l[i] += 1u << PAD;
+    r.l[i + 1] -= 1u << (PAD - 29);
+  }
+  return r;
+}
+template <class P, uint32_t K, uint32_t PAD>
+inline constexpr Limbs29 KP29 = make_kp29<P, K, PAD>();
+
+template <class P>
+struct Fp29 {
+  uint32_t a[9];
+
+  static constexpr uint32_t M29 = 0x1fffffffu;
+  static constexpr uint32_t pl(int j) { return Fp<P>::p29(j); }
+  // -p^-1 mod 2^29
+  static constexpr uint32_t NINV = P::INV & M29;
+
+  static __device__ __forceinline__ Fp29 zero() {
+    Fp29 r;
+    CQ_UNROLL for (int i = 0; i < 9; i++) r.a[i] = 0;
+    return r;
+  }
+  __device__ __forceinline__ bool limbs_zero() const {
+    uint32_t o = 0;
+    CQ_UNROLL for (int i = 0; i < 9; i++) o |= a[i];
+    return o == 0;
+  }
+  // value == 0 (mod p) for a normalised value < 2 p: the limbs are all zero or spell p
+  __device__ __forceinline__ bool is_zero_mod_p() const {
+    uint32_t o = 0, q = 0;
+    CQ_UNROLL for (int i = 0; i < 9; i++) {
+      o |= a[i];
+      q |= a[i] ^ pl(i);
+    }
+    return o == 0 || q == 0;
+  }
+
+  // carry propagation: limbs 0..7 back below 2^29
+  __device__ __forceinline__ void normalise() {
+    CQ_UNROLL for (int i = 0; i < 8; i++) {
+      a[i + 1] += a[i] >> 29;
+      a[i] &= M29;
+    }
+  }
+
+  // Montgomery product, divisor 2^261
+  static __device__ __forceinline__ Fp29 mul(const Fp29& x, const Fp29& y) {
+    uint64_t c[18];
+    CQ_UNROLL for (int k = 0; k < 18; k++) c[k] = 0;
+    CQ_UNROLL for (int i = 0; i < 9; i++) {
+      CQ_UNROLL for (int j = 0; j < 9; j++) c[i + j] += (uint64_t)x.a[i] * y.a[j];
+    }
+    CQ_UNROLL for (int i = 0; i < 9; i++) {
+      const uint32_t m = ((uint32_t)c[i] * NINV) & M29;
+      CQ_UNROLL for (int j = 0; j < 9; j++) c[i + j] += (uint64_t)m * pl(j);
+      c[i + 1] += c[i] >> 29;
+    }
+    Fp29 r;
+    CQ_UNROLL for (int k = 0; k < 8; k++) {
+      r.a[k] = (uint32_t)c[9 + k] & M29;
+      c[10 + k] += c[9 + k] >> 29;
+    }
+    r.a[8] = (uint32_t)c[17];
+    return r;
+  }
+  __device__ __forceinline__ Fp29 operator*(const Fp29& o) const { return mul(*this, o); }
+  __device__ __forceinline__ Fp29 sqr() const { return mul(*this, *this); }
+
+  // limb-wise sum (no carries): limbs < 2^30 for two normalised operands
+  __device__ __forceinline__ Fp29 operator+(const Fp29& o) const {
+    Fp29 r;
+    CQ_UNROLL for (int i = 0; i < 9; i++) r.a[i] = a[i] + o.a[i];
+    return r;
+  }
+
+  // a - b + K p, normalised.  Needs b < K p, limbs of b < 2^PAD and limbs of a < 2^30 (PAD = 30) / 2^29 (PAD = 31).
+  template <uint32_t K, uint32_t PAD = 30>
+  static __device__ __forceinline__ Fp29 sub(const Fp29& x, const Fp29& y) {
+    Fp29 r;
+    CQ_UNROLL for (int i = 0; i < 9; i++) r.a[i] = x.a[i] + (KP29<P, K, PAD>.l[i] - y.a[i]);
+    r.normalise();
+    return r;
+  }
+  // K p - b, normalised
+  template <uint32_t K>
+  static __device__ __forceinline__ Fp29 neg(const Fp29& y) {
+    Fp29 r;
+    CQ_UNROLL for (int i = 0; i < 9; i++) r.a[i] = KP29<P, K, 30>.l[i] - y.a[i];
+    r.normalise();
+    return r;
+  }
+
+  // ---- packing: value < 2^256 <-> 8 x u32 --------------------------------------------------------------
+  static __device__ __forceinline__ Fp29 unpack(const uint32_t* x) {
+    Fp29 r;
+    Fp<P>::unpack29(x, r.a);
+    return r;
+  }
+  // normalised limbs, value < 2^256
+  __device__ __forceinline__ void pack(uint32_t* o) const {
+    o[0] = a[0] | (a[1] << 29);
+    o[1] = (a[1] >> 3) | (a[2] << 26);
+    o[2] = (a[2] >> 6) | (a[3] << 23);
+    o[3] = (a[3] >> 9) | (a[4] << 20);
+    o[4] = (a[4] >> 12) | (a[5] << 17);
+    o[5] = (a[5] >> 15) | (a[6] << 14);
+    o[6] = (a[6] >> 18) | (a[7] << 11);
+    o[7] = (a[7] >> 21) | (a[8] << 8);
+  }
+
+  static __device__ __forceinline__ Fp29 one() {
+    Fp29 r;
+    CQ_UNROLL for (int i = 0; i < 9; i++) r.a[i] = CONSTS29<P>.one[i];
+    return r;
+  }
+  // R = 2^256 Montgomery value (8 x u32, < p) -> R' limb form, < 2 p
+  static __device__ __forceinline__ Fp29 from_mont256(const Fp<P>& y) {
+    Fp29 u = unpack(y.v.l), f;
+    CQ_UNROLL for (int i = 0; i < 9; i++) f.a[i] = CONSTS29<P>.from256[i];
+    return mul(u, f);
+  }
+  // value < 64 p (normalised limbs) -> canonical R = 2^256 Montgomery value < p
+  __device__ __forceinline__ Fp<P> to_mont256() const {
+    Fp29 t;
+    CQ_UNROLL for (int i = 0; i < 9; i++) t.a[i] = CONSTS29<P>.to256[i];
+    Fp29 r = mul(*this, t);  // < 2 p
+    Fp<P> o;
+    r.pack(o.v.l);
+    Fp<P>::cond_sub_p(o.v.l, 0);
+    return o;
+  }
+  // reduce a normalised value < 64 p to < 2 p (one product with the field's 1)
+  __device__ __forceinline__ Fp29 reduced() const { return mul(*this, one()); }
+};
+
+using Fq29 = Fp29<FqP>;
+
+}  // namespace cq

@@ -28,6 +28,7 @@
 //   6. host      : W window sums per MSM (<= 2 KiB) come back; Horner over windows (c doublings
 //                  each) on the host, O(254) group operations.
 #include "msm.hpp"
+#include "curve29.hpp"
 #include "ctx.hpp"
 
 namespace cq {
@@ -282,28 +283,17 @@ __global__ __launch_bounds__(MSM_ACC_THREADS) void msm_accumulate_kernel(
   const uint32_t r = j - off1[g];
   const uint32_t lo = off0[g] + r * MSM_S1;
   const uint32_t hi = min(off0[g] + cnt[g], lo + MSM_S1);
-  XYZZ acc = XYZZ::identity();
+  XYZZ29 acc = XYZZ29::identity();
   for (uint32_t e = lo; e < hi; e++) {
     const uint32_t ix = sorted[e];
-    // precomputed mode: table[w][i] = 2^(c*w) * base[i]
+    // precomputed mode: table[w][i] = 2^(c*w) * base[i], stored in the kernels' R' limb form; otherwise the
+    // caller's array of R = 2^256 values is converted on the fly
     const size_t at = pre ? (size_t)((ix >> 26) & 31u) * table_stride + (ix & 0x03ffffffu) : (size_t)(ix & 0x7fffffffu);
-    G1Affine p = load_affine(pts + at);
-    if (ix >> 31) p = p.neg();
-    xyzz_add_affine(acc, p);
+    Affine29 p = load_affine29(pts + at, !pre);
+    if ((ix >> 31) && !p.is_identity()) p.y = Fq29::neg<2>(p.y);
+    xyzz29_add_affine(acc, p);
   }
-  if (t1[g] == 1) buckets[g] = acc; else partial[j] = acc;
-}
-
-static __device__ __forceinline__ XYZZ xyzz_shfl_down(const XYZZ& a, int delta) {
-  XYZZ r;
-#pragma unroll
-  for (int k = 0; k < 8; k++) {
-    r.x.v.l[k] = __shfl_down(a.x.v.l[k], delta, 64);
-    r.y.v.l[k] = __shfl_down(a.y.v.l[k], delta, 64);
-    r.zz.v.l[k] = __shfl_down(a.zz.v.l[k], delta, 64);
-    r.zzz.v.l[k] = __shfl_down(a.zzz.v.l[k], delta, 64);
-  }
-  return r;
+  store_xyzz29(t1[g] == 1 ? buckets + g : partial + j, acc);
 }
 
 // level k >= 2, long sub-lists: one WAVE per sub-list of <= MSM_S2 partial sums of level k-1
@@ -321,16 +311,14 @@ __global__ __launch_bounds__(256) void msm_combine_kernel(
   const uint32_t r = j - off_cur[g];
   const uint32_t lo = off_prev[g] + r * MSM_S2;
   const uint32_t hi = min(off_prev[g] + tp, lo + MSM_S2);
-  XYZZ acc = XYZZ::identity();
-  for (uint32_t e = lo + lane; e < hi; e += 64) xyzz_add(acc, prev[e]);
+  XYZZ29 acc = XYZZ29::identity();
+  for (uint32_t e = lo + lane; e < hi; e += 64) xyzz29_add(acc, load_xyzz29(prev + e));
 #pragma unroll 1
   for (int delta = 32; delta >= 1; delta >>= 1) {
-    XYZZ o = xyzz_shfl_down(acc, delta);
-    xyzz_add(acc, o);
+    XYZZ29 o = xyzz29_shfl_down(acc, delta);
+    xyzz29_add(acc, o);
   }
-  if (lane == 0) {
-    if (t_cur[g] == 1) buckets[g] = acc; else partial[j] = acc;
-  }
+  if (lane == 0) store_xyzz29(t_cur[g] == 1 ? buckets + g : partial + j, acc);
 }
 
 // level k >= 2, short sub-lists (<= MSM_SHORT partial sums, always the whole bucket): one LANE each
@@ -343,17 +331,33 @@ __global__ __launch_bounds__(MSM_ACC_THREADS) void msm_combine_short_kernel(
   const uint32_t tp = t_prev[g];
   if (tp > MSM_SHORT) return;
   const uint32_t lo = off_prev[g];
-  XYZZ acc = prev[lo];
-  for (uint32_t e = 1; e < tp; e++) xyzz_add(acc, prev[lo + e]);
-  buckets[g] = acc;  // tp <= MSM_SHORT <= MSM_S2  =>  t_cur[g] == 1
+  XYZZ29 acc = load_xyzz29(prev + lo);
+  for (uint32_t e = 1; e < tp; e++) xyzz29_add(acc, load_xyzz29(prev + lo + e));
+  store_xyzz29(buckets + g, acc);  // tp <= MSM_SHORT <= MSM_S2  =>  t_cur[g] == 1
 }
 
-// ---- precomputed window tables: next[i] = 2^c * prev[i] (affine in, affine out) ---------------------
+// ---- precomputed window tables (one-off setup) -----------------------------------------------------------
+// Tables are library-internal, so they hold the accumulate kernel's own representation: coordinates in
+// Montgomery form with R' = 2^261, packed into 8 x u32 (field29.hpp).  Window 0 = the caller's points converted.
+static __device__ __forceinline__ void store_affine29(G1Affine* dst, const Affine29& p) {
+  uint32_t w[8];
+  p.x.pack(w);
+  st8(&dst->x, w);
+  p.y.pack(w);
+  st8(&dst->y, w);
+}
+__global__ __launch_bounds__(256) void msm_table0_kernel(const G1Affine* __restrict__ bases, G1Affine* __restrict__ table, uint32_t n) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  store_affine29(table + i, load_affine29(bases + i, true));
+}
+// next[i] = 2^c * prev[i] (affine in, affine out): the doublings and the inversion run on the canonical field type
 __global__ __launch_bounds__(256) void msm_pre_kernel(const G1Affine* __restrict__ prev, G1Affine* __restrict__ next, uint32_t n,
                                                       uint32_t c) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const G1Affine p = load_affine(prev + i);
+  const Affine29 p29 = load_affine29(prev + i, false);
+  const G1Affine p = {p29.x.to_mont256(), p29.y.to_mont256()};
   XYZZ a = xyzz_dbl_affine(p);
   for (uint32_t k = 1; k < c; k++) a = xyzz_dbl(a);
   G1Affine r = G1Affine::identity();
@@ -362,17 +366,13 @@ __global__ __launch_bounds__(256) void msm_pre_kernel(const G1Affine* __restrict
     r.x = a.x * (iv * a.zzz);
     r.y = a.y * (iv * a.zz);
   }
-  uint4* q = reinterpret_cast<uint4*>(next + i);
-  q[0] = make_uint4(r.x.v.l[0], r.x.v.l[1], r.x.v.l[2], r.x.v.l[3]);
-  q[1] = make_uint4(r.x.v.l[4], r.x.v.l[5], r.x.v.l[6], r.x.v.l[7]);
-  q[2] = make_uint4(r.y.v.l[0], r.y.v.l[1], r.y.v.l[2], r.y.v.l[3]);
-  q[3] = make_uint4(r.y.v.l[4], r.y.v.l[5], r.y.v.l[6], r.y.v.l[7]);
+  store_affine29(next + i, {Fq29::from_mont256(r.x), Fq29::from_mont256(r.y)});
 }
 
 int msm_precompute_tables(cq_ctx* ctx, const G1Affine* bases, uint32_t n, uint32_t c, G1Affine* table /* W*n */) {
   const uint32_t W = (255 + c - 1) / c;
   hipStream_t s = ctx->stream;
-  if (hipMemcpyAsync(table, bases, (size_t)n * sizeof(G1Affine), hipMemcpyDeviceToDevice, s) != hipSuccess) return -1;
+  msm_table0_kernel<<<(n + 255) / 256, 256, 0, s>>>(bases, table, n);
   for (uint32_t w = 1; w < W; w++)
     msm_pre_kernel<<<(n + 255) / 256, 256, 0, s>>>(table + (size_t)(w - 1) * n, table + (size_t)w * n, n, c);
   return hipGetLastError() == hipSuccess ? 0 : -1;
@@ -381,42 +381,42 @@ int msm_precompute_tables(cq_ctx* ctx, const G1Affine* bases, uint32_t n, uint32
 // ---- 5. reduction: sum_{b=1..M} b * B_b per window ------------------------------------------------
 // Block (grp, mw) folds buckets [grp*Mg, (grp+1)*Mg) of (msm,window) mw into the pair
 //   S = sum B_b,  T = sum_{j=1..Mg} j * B_{grp*Mg + j}.
-static __device__ __forceinline__ void block_weighted_sum(const XYZZ* __restrict__ Bk, uint32_t Mg, XYZZ* sh,
-                                                          XYZZ& S_out, XYZZ& T_out) {
+static __device__ __forceinline__ void block_weighted_sum(const XYZZ* __restrict__ Bk, uint32_t Mg, XYZZ29* sh,
+                                                          XYZZ29& S_out, XYZZ29& T_out) {
   const uint32_t tid = threadIdx.x;
   const uint32_t N = Mg < MSM_RED_THREADS ? Mg : MSM_RED_THREADS;  // active lanes
   const uint32_t L = Mg / N;                                      // buckets per lane (power of two)
-  XYZZ running = XYZZ::identity();  // S_tid
-  XYZZ acc = XYZZ::identity();      // sum_j j * B[tid*L + j - 1]
+  XYZZ29 running = XYZZ29::identity();  // S_tid
+  XYZZ29 acc = XYZZ29::identity();      // sum_j j * B[tid*L + j - 1]
   if (tid < N) {
     for (uint32_t j = L; j >= 1; j--) {
-      xyzz_add(running, Bk[(size_t)tid * L + (j - 1)]);
-      xyzz_add(acc, running);
+      xyzz29_add(running, load_xyzz29(Bk + (size_t)tid * L + (j - 1)));
+      xyzz29_add(acc, running);
     }
   }
   // inclusive suffix scan of S over lanes
-  XYZZ inc = running;
+  XYZZ29 inc = running;
   sh[tid] = inc;
   __syncthreads();
   for (uint32_t off = 1; off < N; off <<= 1) {
-    XYZZ t = (tid + off < N) ? sh[tid + off] : XYZZ::identity();
+    XYZZ29 t = (tid + off < N) ? sh[tid + off] : XYZZ29::identity();
     __syncthreads();
-    xyzz_add(inc, t);
+    xyzz29_add(inc, t);
     sh[tid] = inc;
     __syncthreads();
   }
   S_out = sh[0];  // total
   __syncthreads();
   // sum_t t*S_t = sum_{t>=1} Inc_t ; value = acc + L * Inc (t>=1)
-  XYZZ v = (tid >= 1 && tid < N) ? inc : XYZZ::identity();
-  for (uint32_t l = L; l > 1; l >>= 1) v = xyzz_dbl(v);
-  xyzz_add(v, acc);
+  XYZZ29 v = (tid >= 1 && tid < N) ? inc : XYZZ29::identity();
+  for (uint32_t l = L; l > 1; l >>= 1) v = xyzz29_dbl(v);
+  xyzz29_add(v, acc);
   sh[tid] = v;
   __syncthreads();
   for (uint32_t off = MSM_RED_THREADS / 2; off >= 1; off >>= 1) {
     if (tid < off) {
-      XYZZ t = sh[tid + off];
-      xyzz_add(v, t);
+      XYZZ29 t = sh[tid + off];
+      xyzz29_add(v, t);
       sh[tid] = v;
     }
     __syncthreads();
@@ -427,47 +427,47 @@ static __device__ __forceinline__ void block_weighted_sum(const XYZZ* __restrict
 
 __global__ __launch_bounds__(MSM_RED_THREADS) void msm_group_reduce_kernel(const XYZZ* __restrict__ buckets, uint32_t M,
                                                                            uint32_t Mg, XYZZ* __restrict__ pairs) {
-  __shared__ XYZZ sh[MSM_RED_THREADS];
+  __shared__ XYZZ29 sh[MSM_RED_THREADS];
   const uint32_t grp = blockIdx.x, mw = blockIdx.y, G = gridDim.x;
-  XYZZ S, T;
+  XYZZ29 S, T;
   block_weighted_sum(buckets + (size_t)mw * M + (size_t)grp * Mg, Mg, sh, S, T);
   if (threadIdx.x == 0) {
-    pairs[((size_t)mw * G + grp) * 2] = S;
-    pairs[((size_t)mw * G + grp) * 2 + 1] = T;
+    store_xyzz29(pairs + ((size_t)mw * G + grp) * 2, S);
+    store_xyzz29(pairs + ((size_t)mw * G + grp) * 2 + 1, T);
   }
 }
 
 // window sum = sum_g (T_g + g*Mg*S_g) = sum_g T_g + Mg * sum_g g*S_g
 __global__ __launch_bounds__(MSM_RED_THREADS) void msm_window_final_kernel(const XYZZ* __restrict__ pairs, uint32_t G,
                                                                            uint32_t Mg, G1Jac* __restrict__ window_sums) {
-  __shared__ XYZZ sh[MSM_RED_THREADS];
+  __shared__ XYZZ29 sh[MSM_RED_THREADS];
   const uint32_t mw = blockIdx.x, tid = threadIdx.x;
   const XYZZ* P = pairs + (size_t)mw * G * 2;
   // lanes hold S_g (g = tid); sum_g g*S_g = sum_{g>=1} Inc_g with Inc the inclusive suffix scan
-  XYZZ inc = tid < G ? P[(size_t)tid * 2] : XYZZ::identity();
+  XYZZ29 inc = tid < G ? load_xyzz29(P + (size_t)tid * 2) : XYZZ29::identity();
   sh[tid] = inc;
   __syncthreads();
   for (uint32_t off = 1; off < G; off <<= 1) {
-    XYZZ t = (tid + off < G) ? sh[tid + off] : XYZZ::identity();
+    XYZZ29 t = (tid + off < G) ? sh[tid + off] : XYZZ29::identity();
     __syncthreads();
-    xyzz_add(inc, t);
+    xyzz29_add(inc, t);
     sh[tid] = inc;
     __syncthreads();
   }
-  XYZZ v = (tid >= 1 && tid < G) ? inc : XYZZ::identity();
-  for (uint32_t l = Mg; l > 1; l >>= 1) v = xyzz_dbl(v);
-  if (tid < G) xyzz_add(v, P[(size_t)tid * 2 + 1]);
+  XYZZ29 v = (tid >= 1 && tid < G) ? inc : XYZZ29::identity();
+  for (uint32_t l = Mg; l > 1; l >>= 1) v = xyzz29_dbl(v);
+  if (tid < G) xyzz29_add(v, load_xyzz29(P + (size_t)tid * 2 + 1));
   sh[tid] = v;
   __syncthreads();
   for (uint32_t off = MSM_RED_THREADS / 2; off >= 1; off >>= 1) {
     if (tid < off) {
-      XYZZ t = sh[tid + off];
-      xyzz_add(v, t);
+      XYZZ29 t = sh[tid + off];
+      xyzz29_add(v, t);
       sh[tid] = v;
     }
     __syncthreads();
   }
-  if (tid == 0) window_sums[mw] = v.to_jac();
+  if (tid == 0) window_sums[mw] = xyzz29_to_jac(v);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -565,6 +565,8 @@ int msm_run(cq_ctx* ctx, const Fr* const* scalars_host_ptrs, const G1Affine* con
   msm_scan_apply_kernel<<<L.nblk, 256, 0, s>>>(counts, Bt, L.nseq, blocksums, off, tk);
   const uint32_t* off0 = off;
   msm_scatter_kernel<<<dim3((n + 255) / 256, batch), 256, 0, s>>>(d_scalars, d_lens, n, c, W, pre ? 1u : 0u, ranks, off0, sorted);
+  if (ctx->prof_on && ctx->prof_entries && ctx->prof_entries_n < cq_ctx::PROF_COUNTERS)
+    (void)hipMemcpyAsync(ctx->prof_entries + ctx->prof_entries_n++, off0 + Bt, sizeof(uint32_t), hipMemcpyDeviceToHost, s);
   hipEvent_t pe = ctx->prof_begin(CQ_PROF_MSM_ACCUMULATE);
   msm_accumulate_kernel<<<(uint32_t)((L.tmax[0] + MSM_ACC_THREADS - 1) / MSM_ACC_THREADS), MSM_ACC_THREADS, 0, s>>>(
       d_bases, L.B, pre ? 1u : 0u, d_strides, sorted, counts, off0, tk, off + (size_t)(Bt + 1), Bt, part[0], buckets);
