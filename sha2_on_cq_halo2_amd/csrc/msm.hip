@@ -284,13 +284,40 @@ __global__ __launch_bounds__(MSM_ACC_THREADS) void msm_accumulate_kernel(
   const uint32_t lo = off0[g] + r * MSM_S1;
   const uint32_t hi = min(off0[g] + cnt[g], lo + MSM_S1);
   XYZZ29 acc = XYZZ29::identity();
+  // Software pipeline: the table point of entry e+1 (a dependent, essentially random 64-byte gather) and the
+  // index of entry e+2 are requested before the ~10 products of entry e are computed.
+  // precomputed mode: table[w][i] = 2^(c*w) * base[i], stored in the kernels' R' limb form; otherwise the
+  // caller's array of R = 2^256 values is converted on the fly
+  auto addr_of = [&](uint32_t ix) {
+    return pre ? (size_t)((ix >> 26) & 31u) * table_stride + (ix & 0x03ffffffu) : (size_t)(ix & 0x7fffffffu);
+  };
+  uint32_t ix_cur = lo < hi ? sorted[lo] : 0u;
+  uint32_t ix_next = lo + 1 < hi ? sorted[lo + 1] : 0u;
+  uint32_t wx[8], wy[8];
+  if (lo < hi) {
+    const G1Affine* q = pts + addr_of(ix_cur);
+    ld8(&q->x, wx);
+    ld8(&q->y, wy);
+  }
   for (uint32_t e = lo; e < hi; e++) {
-    const uint32_t ix = sorted[e];
-    // precomputed mode: table[w][i] = 2^(c*w) * base[i], stored in the kernels' R' limb form; otherwise the
-    // caller's array of R = 2^256 values is converted on the fly
-    const size_t at = pre ? (size_t)((ix >> 26) & 31u) * table_stride + (ix & 0x03ffffffu) : (size_t)(ix & 0x7fffffffu);
-    Affine29 p = load_affine29(pts + at, !pre);
-    if ((ix >> 31) && !p.is_identity()) p.y = Fq29::neg<2>(p.y);
+    Affine29 p;
+    p.x = Fq29::unpack(wx);
+    p.y = Fq29::unpack(wy);
+    const uint32_t neg = ix_cur >> 31;
+    ix_cur = ix_next;
+    if (e + 1 < hi) {
+      const G1Affine* q = pts + addr_of(ix_cur);
+      ld8(&q->x, wx);
+      ld8(&q->y, wy);
+    }
+    ix_next = e + 2 < hi ? sorted[e + 2] : 0u;
+    if (!pre) {  // R = 2^256 values of a caller's array
+      Fq29 f;
+      CQ_UNROLL for (int i = 0; i < 9; i++) f.a[i] = CONSTS29<FqP>.from256[i];
+      p.x = Fq29::mul(p.x, f);
+      p.y = Fq29::mul(p.y, f);
+    }
+    if (neg && !p.is_identity()) p.y = Fq29::neg<2>(p.y);
     xyzz29_add_affine(acc, p);
   }
   store_xyzz29(t1[g] == 1 ? buckets + g : partial + j, acc);
