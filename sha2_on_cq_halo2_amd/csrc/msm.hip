@@ -98,24 +98,126 @@ static __device__ __forceinline__ uint32_t signed_digit(const U256& v, uint32_t 
 
 // One lane per scalar: every window's digit bumps the histogram; the value the atomic returns is the
 // entry's rank inside its bucket, kept for the scatter pass (so the sort needs one atomic per entry).
+//
+// The kernel is bound by atomic round trips, so a wave never waits for one before issuing the next: windows are
+// handled DIGIT_GROUP at a time -- all their atomics go out back to back (one instruction per window), and only
+// then are the returned values turned into ranks.  Within a window the lanes that share the key of the first
+// two pending lanes (hot keys: 0/1 columns, sparse top windows) are folded into their leader's atomic, which
+// adds the group size; `meta` remembers leader lane and position inside the group.
+constexpr uint32_t DIGIT_GROUP = 6;
 __global__ __launch_bounds__(256) void msm_digits_kernel(const Fr* const* __restrict__ scalars, const uint64_t* __restrict__ lens,
                                                          uint32_t nmax, uint32_t c, uint32_t nwin, uint32_t pre,
                                                          uint32_t* __restrict__ ranks, uint32_t* __restrict__ counts) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t m = blockIdx.y;
+  const uint32_t lane = threadIdx.x & 63;
   const bool live = i < (uint32_t)lens[m];
   U256 v;
   if (live) v = scalars[m][i].to_canonical();
   else for (int k = 0; k < 8; k++) v.l[k] = 0;
   const uint32_t M = 1u << (c - 1);
   uint32_t carry = 0, neg;
-  for (uint32_t w = 0; w < nwin; w++) {
-    const uint32_t d = signed_digit(v, w, c, carry, neg);
-    const size_t mw = (size_t)m * nwin + w;
-    // precomputed-table mode folds every window into one bucket set per MSM
-    const bool act = live && d != 0;
-    const uint32_t rank = wave_atomic_inc(counts, (uint32_t)((pre ? (size_t)m : mw) * M) + (d - 1), act);
-    if (act) ranks[mw * nmax + i] = rank;
+  for (uint32_t w0 = 0; w0 < nwin; w0 += DIGIT_GROUP) {
+    uint32_t ret[DIGIT_GROUP], meta[DIGIT_GROUP];  // meta: 0xffffffff = inactive, else leader lane << 8 | offset, leader 64 = none
+#pragma unroll
+    for (uint32_t q = 0; q < DIGIT_GROUP; q++) {
+      const uint32_t w = w0 + q;
+      meta[q] = 0xffffffffu;
+      ret[q] = 0;
+      if (w >= nwin) continue;  // wave-uniform
+      const uint32_t d = signed_digit(v, w, c, carry, neg);
+      const size_t mw = (size_t)m * nwin + w;
+      // precomputed-table mode folds every window into one bucket set per MSM
+      const bool act = live && d != 0;
+      const uint32_t key = (uint32_t)((pre ? (size_t)m : mw) * M) + (d - 1);
+      bool pending = act;
+      uint32_t add = 1, lead = 64, below = 0;
+      bool issue = act;
+#pragma unroll
+      for (int round = 0; round < 2; round++) {
+        const unsigned long long pend = __ballot(pending);
+        if (pend) {  // wave-uniform
+          const int leader = __ffsll((long long)pend) - 1;
+          const uint32_t lkey = __shfl(key, leader, 64);
+          const bool mine = pending && key == lkey;
+          const unsigned long long grp = __ballot(mine);
+          if (mine) {
+            lead = (uint32_t)leader;
+            below = __popcll(grp & ((1ull << lane) - 1ull));
+            add = __popcll(grp);
+            issue = (int)lane == leader;
+            pending = false;
+          }
+        }
+      }
+      if (issue) ret[q] = atomicAdd(&counts[key], (lead == lane || lead == 64) ? add : 1u);
+      if (act) meta[q] = (lead << 8) | below;
+    }
+#pragma unroll
+    for (uint32_t q = 0; q < DIGIT_GROUP; q++) {
+      const uint32_t w = w0 + q;
+      if (w >= nwin) continue;
+      const uint32_t lead = (meta[q] >> 8) & 0xff;
+      const uint32_t base = __shfl(ret[q], lead & 63, 64);  // every lane takes part in the shuffle
+      if (meta[q] != 0xffffffffu) {
+        const uint32_t rank = lead < 64 ? base + (meta[q] & 0xff) : ret[q];
+        ranks[((size_t)m * nwin + w) * nmax + i] = rank;
+      }
+    }
+  }
+}
+
+// Precomputed-table mode (one bucket set of M <= 2^14 counters per MSM): the histogram of a chunk of scalars is
+// built in LDS first, so the device-scope atomics -- the throughput limit of the kernel above, every one of them
+// lands on the same few hundred cache lines -- drop from one per (scalar, window) to one per non-empty bucket per
+// block.  Pass 1 counts in LDS; each non-empty bucket then reserves its range with ONE global atomic and the LDS
+// counter becomes that range's cursor; pass 2 hands out the ranks from the cursors.
+constexpr uint32_t DIGITS_LDS_THREADS = 1024;
+constexpr uint32_t DIGITS_LDS_PER_LANE = 8;
+constexpr uint32_t DIGITS_LDS_CHUNK = DIGITS_LDS_THREADS * DIGITS_LDS_PER_LANE;
+constexpr uint32_t DIGITS_LDS_MAX_M = 1u << 14;
+__global__ __launch_bounds__(DIGITS_LDS_THREADS) void msm_digits_lds_kernel(const Fr* const* __restrict__ scalars,
+                                                                            const uint64_t* __restrict__ lens, uint32_t nmax,
+                                                                            uint32_t c, uint32_t nwin, uint32_t* __restrict__ ranks,
+                                                                            uint32_t* __restrict__ counts) {
+  __shared__ uint32_t hist[DIGITS_LDS_MAX_M];
+  const uint32_t m = blockIdx.y, t = threadIdx.x;
+  const uint32_t M = 1u << (c - 1);
+  const uint32_t len = (uint32_t)lens[m];
+  const uint32_t base = blockIdx.x * DIGITS_LDS_CHUNK;
+  if (base >= len) return;  // block-uniform
+  for (uint32_t b = t; b < M; b += DIGITS_LDS_THREADS) hist[b] = 0;
+  U256 v[DIGITS_LDS_PER_LANE];
+#pragma unroll
+  for (uint32_t k = 0; k < DIGITS_LDS_PER_LANE; k++) {
+    const uint32_t i = base + k * DIGITS_LDS_THREADS + t;
+    if (i < len) v[k] = scalars[m][i].to_canonical();
+    else for (int q = 0; q < 8; q++) v[k].l[q] = 0;  // zero scalar: no non-zero digit
+  }
+  __syncthreads();
+#pragma unroll
+  for (uint32_t k = 0; k < DIGITS_LDS_PER_LANE; k++) {
+    uint32_t carry = 0, neg;
+    for (uint32_t w = 0; w < nwin; w++) {
+      const uint32_t d = signed_digit(v[k], w, c, carry, neg);
+      if (d) atomicAdd(&hist[d - 1], 1u);
+    }
+  }
+  __syncthreads();
+  uint32_t* cnt = counts + (size_t)m * M;
+  for (uint32_t b = t; b < M; b += DIGITS_LDS_THREADS) {
+    const uint32_t h = hist[b];
+    if (h) hist[b] = atomicAdd(&cnt[b], h);
+  }
+  __syncthreads();
+#pragma unroll
+  for (uint32_t k = 0; k < DIGITS_LDS_PER_LANE; k++) {
+    const uint32_t i = base + k * DIGITS_LDS_THREADS + t;
+    uint32_t carry = 0, neg;
+    for (uint32_t w = 0; w < nwin; w++) {
+      const uint32_t d = signed_digit(v[k], w, c, carry, neg);
+      if (d) ranks[((size_t)m * nwin + w) * nmax + i] = atomicAdd(&hist[d - 1], 1u);
+    }
   }
 }
 
@@ -586,7 +688,11 @@ int msm_run(cq_ctx* ctx, const Fr* const* scalars_host_ptrs, const G1Affine* con
   const uint64_t* d_lens = (const uint64_t*)((const void**)d_scalars + 3 * batch);
   // counts and buckets (identity = all zero) are adjacent: one memset
   if (hipMemsetAsync(counts, 0, L.zero_end - L.off_counts, s) != hipSuccess) return -1;
-  msm_digits_kernel<<<dim3((n + 255) / 256, batch), 256, 0, s>>>(d_scalars, d_lens, n, c, W, pre ? 1u : 0u, ranks, counts);
+  if (pre && M <= DIGITS_LDS_MAX_M)
+    msm_digits_lds_kernel<<<dim3((n + DIGITS_LDS_CHUNK - 1) / DIGITS_LDS_CHUNK, batch), DIGITS_LDS_THREADS, 0, s>>>(d_scalars, d_lens, n, c, W,
+                                                                                                                  ranks, counts);
+  else
+    msm_digits_kernel<<<dim3((n + 255) / 256, batch), 256, 0, s>>>(d_scalars, d_lens, n, c, W, pre ? 1u : 0u, ranks, counts);
   msm_scan_reduce_kernel<<<L.nblk, 256, 0, s>>>(counts, Bt, L.nseq, blocksums);
   msm_scan_spine_kernel<<<1, 1024, 0, s>>>(blocksums, L.nblk, L.nseq);
   msm_scan_apply_kernel<<<L.nblk, 256, 0, s>>>(counts, Bt, L.nseq, blocksums, off, tk);
