@@ -350,7 +350,8 @@ int cq_profile_read(cq_ctx* ctx, int id, double* total_ms, uint64_t* calls);
 
 /* ---- microbenchmarks (measurement support, not part of the drop-in surface) -------------- */
 /* Runs `iters` dependent Montgomery multiplications per lane over `lanes` lanes and writes one
- * folded element per lane; used to measure the chip's 256-bit modmul rate. which: 0 = Fr, 1 = Fq */
+ * folded element per lane; used to measure the chip's 256-bit modmul rate. which: 0 = Fr, 1 = Fq (the 8 x u32
+ * memory-format type), 2 = Fq in the lazy 9 x 29-bit form the MSM kernels compute in */
 int cq_bench_modmul_dev(cq_ctx* ctx, uint64_t* out_dev, uint32_t lanes, uint32_t iters, int which);
 
 #ifdef __cplusplus
