@@ -57,6 +57,8 @@ void cq_ctx_destroy(cq_ctx* c) {
   if (c->pinned) hipHostFree(c->pinned);
   if (c->pinned_msm) hipHostFree(c->pinned_msm);
   if (c->prof_entries) hipHostFree(c->prof_entries);
+  if (c->copy_done) hipEventDestroy(c->copy_done);
+  if (c->copy_stream) hipStreamDestroy(c->copy_stream);
   if (c->fb_table) hipFree(c->fb_table);
   for (auto& t : c->msm_tables) hipFree(t.table);
   if (c->own_stream) hipStreamDestroy(c->stream);

@@ -100,6 +100,18 @@ struct cq_ctx {
     *out = pinned;
     return CQ_OK;
   }
+  // side stream for host->device uploads that should overlap kernels on `stream` (the DMA engine is otherwise
+  // serialised behind whatever the main stream has queued); `copy_done` orders the main stream after an upload
+  hipStream_t copy_stream = nullptr;
+  hipEvent_t copy_done = nullptr;
+  int ensure_copy_stream() {
+    if (copy_stream) return CQ_OK;
+    hipError_t e = hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking);
+    if (e != hipSuccess) return hip_fail(e, "hipStreamCreate(copy)");
+    e = hipEventCreateWithFlags(&copy_done, hipEventDisableTiming);
+    if (e != hipSuccess) return hip_fail(e, "hipEventCreate(copy)");
+    return CQ_OK;
+  }
   void* pinned_msm = nullptr;  // MSM results (kept apart from `pinned`, which stages RNG words)
   size_t pinned_msm_bytes = 0;
   int ensure_pinned_msm(size_t bytes, void** out) {

@@ -390,6 +390,20 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, const uint64_
   for (size_t a = 0; a < A; a++)
     CQ_HIP(c, hipMemcpyAsync(adv + a * n, advice_dev[a], (size_t)u * sizeof(Fr), hipMemcpyDeviceToDevice, s));
   std::vector<Fr> z_tails(S * bf);
+  uint64_t* rng_pin = nullptr;
+  size_t rng_first = 0;
+  // second half of the vanishing argument's draws + the blind, upload, and the words -> field elements kernel
+  auto finish_random_poly = [&]() -> int {
+    if (rng_first < 8 * n) {
+      rng.fill(rng_pin + rng_first, 8 * n - rng_first);
+      CQ_HIP(c, hipMemcpyAsync(rng_dev + rng_first, rng_pin + rng_first, (8 * n - rng_first) * sizeof(uint64_t), hipMemcpyHostToDevice,
+                               c->copy_stream));
+    }
+    (void)rng.fr();  // random_blind
+    CQ_HIP(c, hipEventRecord(c->copy_done, c->copy_stream));
+    CQ_HIP(c, hipStreamWaitEvent(s, c->copy_done, 0));
+    return poly_from_u512(c, rng_dev, (uint32_t)n, random_poly);
+  };
   {
     std::vector<Fr> tails(A * (n - u));
     for (size_t a = 0; a < A; a++)
@@ -417,10 +431,15 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, const uint64_
       for (uint32_t r = 0; r < bf; r++) z_tails[st * bf + r] = rng.fr();
       (void)rng.fr();  // permutation_product_blind
     }
-    rng.fill((uint64_t*)pin, 8 * n);
-    (void)rng.fr();  // random_blind
-    CQ_HIP(c, hipMemcpyAsync(rng_dev, pin, (size_t)64 * n, hipMemcpyHostToDevice, s));
-    CQ_TRY(poly_from_u512(c, rng_dev, (uint32_t)n, random_poly));
+    // Drawing 8n words on the host (2^21 at k = 18) takes longer than the advice MSMs run, so only the first
+    // half is drawn here; the second half is drawn while the round-1 commitments are computed (no other draw
+    // comes in between).  The uploads ride a side stream so that they overlap the kernels queued on `s`.
+    CQ_TRY(c->ensure_copy_stream());
+    rng_pin = (uint64_t*)pin;
+    rng_first = L ? 4 * n : 8 * n;
+    rng.fill(rng_pin, rng_first);
+    CQ_HIP(c, hipMemcpyAsync(rng_dev, rng_pin, rng_first * sizeof(uint64_t), hipMemcpyHostToDevice, c->copy_stream));
+    if (!L) CQ_TRY(finish_random_poly());
     // batch_normalize (:363-366), write (:370-374)
     if (A) {
       std::vector<G1Affine> pts;
@@ -497,7 +516,10 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, const uint64_
     for (size_t l = 0; l < L; l++) { sc.push_back(f_lag + l * n); bs.push_back(pk->params->g_lagrange); ln.push_back(n); }
     for (size_t l = 0; l < L; l++) { sc.push_back(m_fr + l * N); bs.push_back(pk->table_cfg->g1_lagrange); ln.push_back(N); }
     std::vector<G1Affine> cm;
-    CQ_TRY(commit_batch_v(pk, sc, bs, ln, cm));
+    Commit r1;
+    CQ_TRY(r1.begin(pk, sc, bs, ln));
+    CQ_TRY(finish_random_poly());  // host draws overlap the MSM kernels just queued
+    CQ_TRY(r1.end(cm));
     for (size_t l = 0; l < L; l++) {
       if (!tr.write_point(cm[l])) return c->fail(CQ_ERR_TRANSCRIPT, "f commitment is the identity");
       if (!tr.write_point(cm[L + l])) return c->fail(CQ_ERR_TRANSCRIPT, "m commitment is the identity");
