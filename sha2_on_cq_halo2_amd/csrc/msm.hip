@@ -507,96 +507,77 @@ int msm_precompute_tables(cq_ctx* ctx, const G1Affine* bases, uint32_t n, uint32
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
-// ---- 5. reduction: sum_{b=1..M} b * B_b per window ------------------------------------------------
-// Block (grp, mw) folds buckets [grp*Mg, (grp+1)*Mg) of (msm,window) mw into the pair
-//   S = sum B_b,  T = sum_{j=1..Mg} j * B_{grp*Mg + j}.
-static __device__ __forceinline__ void block_weighted_sum(const XYZZ* __restrict__ Bk, uint32_t Mg, XYZZ29* sh,
-                                                          XYZZ29& S_out, XYZZ29& T_out) {
-  const uint32_t tid = threadIdx.x;
-  const uint32_t N = Mg < MSM_RED_THREADS ? Mg : MSM_RED_THREADS;  // active lanes
-  const uint32_t L = Mg / N;                                      // buckets per lane (power of two)
-  XYZZ29 running = XYZZ29::identity();  // S_tid
-  XYZZ29 acc = XYZZ29::identity();      // sum_j j * B[tid*L + j - 1]
-  if (tid < N) {
-    for (uint32_t j = L; j >= 1; j--) {
-      xyzz29_add(running, load_xyzz29(Bk + (size_t)tid * L + (j - 1)));
-      xyzz29_add(acc, running);
-    }
+// ---- 5. reduction: sum_{b=1..M} b * B_b per bucket set ---------------------------------------------------
+// Every dependent EC addition costs a wave ~5 us whatever the number of busy lanes, so the reduction is shaped
+// for depth, not work.  Buckets are read as a rows x cols matrix (b = cols * hi + lo + 1, cols = min(M, 128)):
+//     sum_b b B_b  =  cols * sum_hi hi R_hi  +  sum_lo (lo + 1) C_lo,     R = row sums, C = column sums.
+// Kernel 1: one WAVE per row / column sum (<= 2 buckets per lane, then a 6-level shuffle tree): rows + cols waves
+// per bucket set, all independent.  Kernel 2: per bucket set two waves, one per weighted sum of <= 128 terms
+// (pair sums, suffix scan by shuffles, one tree), joined through LDS.  ~7 + ~24 dependent operations instead of
+// the ~46 of a lane-serial running sum over 1024-bucket groups.
+static __device__ __forceinline__ XYZZ29 wave_sum(XYZZ29 v) {
+#pragma unroll 1
+  for (int delta = 32; delta >= 1; delta >>= 1) {
+    XYZZ29 o = xyzz29_shfl_down(v, delta);
+    xyzz29_add(v, o);
   }
-  // inclusive suffix scan of S over lanes
-  XYZZ29 inc = running;
-  sh[tid] = inc;
-  __syncthreads();
-  for (uint32_t off = 1; off < N; off <<= 1) {
-    XYZZ29 t = (tid + off < N) ? sh[tid + off] : XYZZ29::identity();
-    __syncthreads();
-    xyzz29_add(inc, t);
-    sh[tid] = inc;
-    __syncthreads();
-  }
-  S_out = sh[0];  // total
-  __syncthreads();
-  // sum_t t*S_t = sum_{t>=1} Inc_t ; value = acc + L * Inc (t>=1)
-  XYZZ29 v = (tid >= 1 && tid < N) ? inc : XYZZ29::identity();
-  for (uint32_t l = L; l > 1; l >>= 1) v = xyzz29_dbl(v);
-  xyzz29_add(v, acc);
-  sh[tid] = v;
-  __syncthreads();
-  for (uint32_t off = MSM_RED_THREADS / 2; off >= 1; off >>= 1) {
-    if (tid < off) {
-      XYZZ29 t = sh[tid + off];
-      xyzz29_add(v, t);
-      sh[tid] = v;
-    }
-    __syncthreads();
-  }
-  T_out = sh[0];
-  __syncthreads();
+  return v;  // lane 0 holds the sum
 }
 
-__global__ __launch_bounds__(MSM_RED_THREADS) void msm_group_reduce_kernel(const XYZZ* __restrict__ buckets, uint32_t M,
-                                                                           uint32_t Mg, XYZZ* __restrict__ pairs) {
-  __shared__ XYZZ29 sh[MSM_RED_THREADS];
-  const uint32_t grp = blockIdx.x, mw = blockIdx.y, G = gridDim.x;
-  XYZZ29 S, T;
-  block_weighted_sum(buckets + (size_t)mw * M + (size_t)grp * Mg, Mg, sh, S, T);
+__global__ __launch_bounds__(64) void msm_rowcol_kernel(const XYZZ* __restrict__ buckets, uint32_t M, uint32_t rows, uint32_t cols,
+                                                        XYZZ* __restrict__ sums /*[sets][rows + cols]*/) {
+  const uint32_t q = blockIdx.x, set = blockIdx.y, lane = threadIdx.x;
+  const XYZZ* Bk = buckets + (size_t)set * M;
+  XYZZ29 acc = XYZZ29::identity();
+  if (q < rows) {  // R_q = sum_lo B[q][lo]
+    for (uint32_t lo = lane; lo < cols; lo += 64) xyzz29_add(acc, load_xyzz29(Bk + (size_t)q * cols + lo));
+  } else {         // C_lo = sum_hi B[hi][lo]
+    const uint32_t lo = q - rows;
+    for (uint32_t hi = lane; hi < rows; hi += 64) xyzz29_add(acc, load_xyzz29(Bk + (size_t)hi * cols + lo));
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) store_xyzz29(sums + (size_t)set * (rows + cols) + q, acc);
+}
+
+// sum_{j < count} (j + first_weight) X_j over one wave, count <= 128; result in lane 0
+static __device__ __forceinline__ XYZZ29 wave_weighted_sum(const XYZZ* __restrict__ X, uint32_t count, uint32_t first_weight) {
+  const uint32_t lane = threadIdx.x & 63;
+  const XYZZ29 a = 2 * lane < count ? load_xyzz29(X + 2 * lane) : XYZZ29::identity();
+  const XYZZ29 b = 2 * lane + 1 < count ? load_xyzz29(X + 2 * lane + 1) : XYZZ29::identity();
+  // sum_j j X_j = sum_l (2l (a_l + b_l) + b_l) = 2 sum_l l S_l + sum_l b_l,   sum_l l S_l = sum_{l >= 1} Suffix_l
+  XYZZ29 suf = a;
+  xyzz29_add(suf, b);  // S_l
+#pragma unroll 1
+  for (int delta = 1; delta < 64; delta <<= 1) {
+    XYZZ29 o = xyzz29_shfl_down(suf, delta);
+    if (lane + delta < 64) xyzz29_add(suf, o);
+  }
+  XYZZ29 v = lane >= 1 ? xyzz29_dbl(suf) : XYZZ29::identity();
+  xyzz29_add(v, b);
+  if (first_weight) {  // + first_weight * sum_j X_j (the total is lane 0's suffix); first_weight is 0 or 1 here
+    if (lane == 0) xyzz29_add(v, suf);
+  }
+  return wave_sum(v);
+}
+
+__global__ __launch_bounds__(128) void msm_weighted_kernel(const XYZZ* __restrict__ sums, uint32_t rows, uint32_t cols,
+                                                           G1Jac* __restrict__ window_sums) {
+  __shared__ XYZZ29 other;
+  const uint32_t set = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const XYZZ* S = sums + (size_t)set * (rows + cols);
+  XYZZ29 v;
+  if (wave == 0) {
+    v = wave_weighted_sum(S, rows, 0);                      // sum_hi hi R_hi
+    for (uint32_t l = cols; l > 1; l >>= 1) v = xyzz29_dbl(v);  // * cols (a power of two)
+  } else {
+    v = wave_weighted_sum(S + rows, cols, 1);               // sum_lo (lo + 1) C_lo
+    if (lane == 0) other = v;
+  }
+  __syncthreads();
   if (threadIdx.x == 0) {
-    store_xyzz29(pairs + ((size_t)mw * G + grp) * 2, S);
-    store_xyzz29(pairs + ((size_t)mw * G + grp) * 2 + 1, T);
+    xyzz29_add(v, other);
+    window_sums[set] = xyzz29_to_jac(v);
   }
-}
-
-// window sum = sum_g (T_g + g*Mg*S_g) = sum_g T_g + Mg * sum_g g*S_g
-__global__ __launch_bounds__(MSM_RED_THREADS) void msm_window_final_kernel(const XYZZ* __restrict__ pairs, uint32_t G,
-                                                                           uint32_t Mg, G1Jac* __restrict__ window_sums) {
-  __shared__ XYZZ29 sh[MSM_RED_THREADS];
-  const uint32_t mw = blockIdx.x, tid = threadIdx.x;
-  const XYZZ* P = pairs + (size_t)mw * G * 2;
-  // lanes hold S_g (g = tid); sum_g g*S_g = sum_{g>=1} Inc_g with Inc the inclusive suffix scan
-  XYZZ29 inc = tid < G ? load_xyzz29(P + (size_t)tid * 2) : XYZZ29::identity();
-  sh[tid] = inc;
-  __syncthreads();
-  for (uint32_t off = 1; off < G; off <<= 1) {
-    XYZZ29 t = (tid + off < G) ? sh[tid + off] : XYZZ29::identity();
-    __syncthreads();
-    xyzz29_add(inc, t);
-    sh[tid] = inc;
-    __syncthreads();
-  }
-  XYZZ29 v = (tid >= 1 && tid < G) ? inc : XYZZ29::identity();
-  for (uint32_t l = Mg; l > 1; l >>= 1) v = xyzz29_dbl(v);
-  if (tid < G) xyzz29_add(v, load_xyzz29(P + (size_t)tid * 2 + 1));
-  sh[tid] = v;
-  __syncthreads();
-  for (uint32_t off = MSM_RED_THREADS / 2; off >= 1; off >>= 1) {
-    if (tid < off) {
-      XYZZ29 t = sh[tid + off];
-      xyzz29_add(v, t);
-      sh[tid] = v;
-    }
-    __syncthreads();
-  }
-  if (tid == 0) window_sums[mw] = xyzz29_to_jac(v);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -625,8 +606,8 @@ MsmLayout::MsmLayout(uint32_t n_, uint32_t c_, uint32_t batch_, bool pre_) : n(n
   }
   nseq = levels + 1;
   nblk = (Bt + 2047) / 2048;
-  Mg = M < MSM_RED_GROUP ? M : MSM_RED_GROUP;
-  G = M / Mg;
+  cols = M < 128 ? M : 128;  // bucket matrix of the reduction (msm_rowcol_kernel)
+  rows = M / cols;
   auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
   const uint64_t E = (uint64_t)batch * W * n;  // upper bound on (point,digit) entries
   size_t o = 0;
@@ -650,7 +631,7 @@ MsmLayout::MsmLayout(uint32_t n_, uint32_t c_, uint32_t batch_, bool pre_) : n(n
   o = up(o + (size_t)tmax[0] * sizeof(XYZZ));
   off_part[1] = o;
   o = up(o + (size_t)(levels > 1 ? tmax[1] : 0) * sizeof(XYZZ));
-  off_pairs = o;   o = up(o + (size_t)batch * Wb * G * 2 * sizeof(XYZZ));
+  off_pairs = o;   o = up(o + (size_t)batch * Wb * (rows + cols) * sizeof(XYZZ));
   total = o;
 }
 
@@ -715,8 +696,8 @@ int msm_run(cq_ctx* ctx, const Fr* const* scalars_host_ptrs, const G1Affine* con
     msm_combine_kernel<<<(uint32_t)((L.tmax[k] + 3) / 4), 256, 0, s>>>(part[(k - 1) & 1], t_prev, off_prev, t_cur, off_cur, Bt,
                                                                        part[k & 1], buckets);
   }
-  msm_group_reduce_kernel<<<dim3(L.G, batch * L.Wb), MSM_RED_THREADS, 0, s>>>(buckets, M, L.Mg, pairs);
-  msm_window_final_kernel<<<batch * L.Wb, MSM_RED_THREADS, 0, s>>>(pairs, L.G, L.Mg, window_sums_dev);
+  msm_rowcol_kernel<<<dim3(L.rows + L.cols, batch * L.Wb), 64, 0, s>>>(buckets, M, L.rows, L.cols, pairs);
+  msm_weighted_kernel<<<batch * L.Wb, 128, 0, s>>>(pairs, L.rows, L.cols, window_sums_dev);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

@@ -29,7 +29,7 @@ struct MsmStrides {
 
 // Workspace carve-up for `batch` MSMs of n terms each with c-bit signed windows.
 struct MsmLayout {
-  uint32_t n, c, batch, W, Wb, M, B, Bt, levels, nseq, nblk, Mg, G;
+  uint32_t n, c, batch, W, Wb, M, B, Bt, levels, nseq, nblk, rows, cols;
   bool pre;
   uint64_t tmax[8];
   size_t off_ptrs, off_ranks, off_counts, off_buckets, zero_end, off_blocksums, off_off, off_tk,
