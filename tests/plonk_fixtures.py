@@ -6,6 +6,8 @@ add/mul chain with next/prev rotations, a scaled-constant gate, an instance colu
 inside the permutation, optionally a degree-5 gate (-> extended domain 4n, 3 columns per permutation
 set) and optionally a static (CQ) lookup next to them.
 """
+import numpy as np
+
 from oracle import bn254 as B
 from oracle import cq_prover as CP
 from oracle import kzg
@@ -143,13 +145,71 @@ def plonk_api_circuit(k=5):
     return dict(circuit=circuit, fixed=fixed, advice=adv, instances=[[2]], mapping=asm.mapping, tables={})
 
 
-def oracle_env(k, s_seed=0x6371, builder=None, **kw):
+class _Params:
+    """ParamsKZG look-alike (k, n, g, g_lagrange) whose points were multiplied out by the C oracle."""
+
+
+def c_scalar_muls(scalars):
+    """[scalar * G]_1 as affine tuples via the C restatement (oracle/cq_oracle.c `cqo_g1_mul`): the Python
+    double-and-add is too slow beyond a few hundred points."""
+    from oracle import cbind as OC
+
+    gen = B.points_to_mont_limbs([B.G1_GEN])[0]
+    sm = B.to_mont_limbs(scalars)
+    jac = np.stack([OC.g1_mul(gen, sm[i]) for i in range(len(scalars))])
+    return B.jac_from_mont_limbs(jac)
+
+
+def fast_params(k, s):
+    """`ParamsKZG::setup_from_toxic_waste` (kzg/commitment.rs:209-276) with the closed-form Lagrange scalars
+    (:241-251), points from the C oracle."""
+    n = 1 << k
+    p = _Params()
+    p.k, p.n = k, n
+    p.g = c_scalar_muls([pow(s, i, P) for i in range(n)])
+    root = kzg._root_for(k)
+    mult = (pow(s, n, P) - 1) * B.inv_mod(n % P, P) % P
+    sc = []
+    rp = 1
+    for _ in range(n):
+        sc.append(mult * rp % P * B.inv_mod((s - rp) % P, P) % P)
+        rp = rp * root % P
+    p.g_lagrange = c_scalar_muls(sc)
+    return p
+
+
+def c_msm(coeffs, bases, _cache={}):
+    """`best_multiexp` through the C restatement, for oracle proofs at sizes the Python Pippenger cannot reach."""
+    from oracle import cbind as OC
+
+    key = (id(bases), len(bases))
+    if key not in _cache:
+        _cache[key] = (bases, B.points_to_mont_limbs(bases))  # keeps `bases` alive so the id stays unique
+    pts = _cache[key][1]
+    out = OC.best_multiexp(B.to_mont_limbs(coeffs), pts[: len(coeffs)])
+    zs = B.from_mont_limbs(out.reshape(1, 12)[:, 8:12], B.Q_MOD)[0]
+    if zs == 0:
+        return B.JAC_ID
+    xs = B.from_mont_limbs(out.reshape(1, 12)[:, 0:4], B.Q_MOD)[0]
+    ys = B.from_mont_limbs(out.reshape(1, 12)[:, 4:8], B.Q_MOD)[0]
+    return (xs, ys, zs)
+
+
+def oracle_env(k, s_seed=0x6371, builder=None, fast=False, **kw):
     """Oracle-side params / pk for `chain_circuit` (SRS layout of tests/my_test.rs:179-205: table SRS over the
-    table-sized domain, b0_g1_bound = [s^(n+1+i)]_1, srs_g1_len = 2n)."""
+    table-sized domain, b0_g1_bound = [s^(n+1+i)]_1, srs_g1_len = 2n).  fast: SRS points from the C oracle."""
     fx = (builder or chain_circuit)(k, **kw)
     s = B.fr_random(B.Xoshiro256ss(s_seed))
-    params = kzg.ParamsKZG(k, s)
     n = 1 << k
+    if fast:
+        params = fast_params(k, s)
+        tsrs = kzg.TableSRS(len(TABLE) - 1, s)
+        tabs = {name: kzg.StaticTableValues(v, tsrs.g1) for name, v in fx["tables"].items()}
+        b0 = c_scalar_muls([pow(s, n + 1 + i, P) for i in range(n - 1)])
+        pk = CP.keygen_pk(fx["circuit"], tabs, tsrs, b0, 424242, fixed=fx["fixed"], perm_mapping=fx["mapping"])
+        fx.update(s=s, params=params, pk=pk, tsrs=tsrs, tabs=tabs, srs_g1_len=2 * n)
+        return fx
+    params = kzg.ParamsKZG(k, s)
     tsrs = kzg.TableSRS(len(TABLE) - 1, s)
     tabs = {name: kzg.StaticTableValues(v, tsrs.g1) for name, v in fx["tables"].items()}
     b0 = kzg._powers_g1(s, 2 * n)[n + 1:]

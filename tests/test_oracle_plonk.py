@@ -140,3 +140,18 @@ def test_shplonk_proof_verifies(kw):
             assert not _verify(fx, bytes(bad), opener="shplonk")
         except ValueError:
             pass
+
+
+def test_c_backed_oracle_env_matches_python():
+    """The C-accelerated helpers used for larger oracle proofs (SRS points by `cqo_g1_mul`, multiexp by
+    `cqo_best_multiexp`) give the same SRS and the same proof bytes as the pure-Python path."""
+    from tests.plonk_fixtures import c_msm, fast_params
+
+    fx = oracle_env(5, with_lookup=True)
+    fp = fast_params(5, fx["s"])
+    assert fp.g == fx["params"].g and fp.g_lagrange == fx["params"].g_lagrange
+    fast = oracle_env(5, fast=True, with_lookup=True)
+    assert fast["pk"].b0_g1_bound == fx["pk"].b0_g1_bound
+    a = CP.create_proof(fx["params"], fx["pk"], fx["advice"], B.Xoshiro256ss(9), instances=fx["instances"])
+    b = CP.create_proof(fast["params"], fast["pk"], fast["advice"], B.Xoshiro256ss(9), msm=c_msm, instances=fast["instances"])
+    assert a.proof == b.proof

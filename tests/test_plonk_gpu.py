@@ -8,7 +8,7 @@ import pytest
 from oracle import bn254 as B
 from oracle import cq_prover as CP
 from oracle import cq_verifier as CV
-from tests.plonk_fixtures import TABLE, chain_circuit, oracle_env, plonk_api_circuit, to_backend_cs
+from tests.plonk_fixtures import TABLE, c_msm, chain_circuit, oracle_env, plonk_api_circuit, to_backend_cs
 
 pytestmark = pytest.mark.gpu
 P = B.R_MOD
@@ -50,6 +50,20 @@ def test_plonk_proof_bytes_match_oracle(ctx, kw):
     tr = CP.create_proof(fx["params"], fx["pk"], fx["advice"], B.Xoshiro256ss(77), instances=fx["instances"])
     proof = gpk.create_proof(_advice_cols(fx, n), seed=77, instances=[B.to_mont_limbs(i) for i in fx["instances"]])
     assert len(proof) == gpk.proof_size == len(tr.proof)
+    assert proof == tr.proof
+
+
+@pytest.mark.parametrize("opener", ["gwc", "shplonk"])
+def test_plonk_proof_bytes_match_oracle_k11(ctx, opener):
+    """Byte parity beyond one scan tile (n = 2048: two tiles per product set, extended domain 8192, 5 permutation
+    columns in two sets, a degree-5 gate and a static lookup together).  The Python prover runs with the C
+    restatement's multiexp and SRS points so that it finishes in seconds."""
+    k = 11
+    fx = oracle_env(k, fast=True, degree5=True, with_lookup=True)
+    gpk, _ = _backend_pk(ctx, fx, k, fx["s"], b0=fx["pk"].b0_g1_bound)
+    gpk.set_opener(opener)
+    tr = CP.create_proof(fx["params"], fx["pk"], fx["advice"], B.Xoshiro256ss(31), msm=c_msm, instances=fx["instances"], opener=opener)
+    proof = gpk.create_proof(_advice_cols(fx, 1 << k), seed=31, instances=[B.to_mont_limbs(i) for i in fx["instances"]])
     assert proof == tr.proof
 
 
