@@ -278,6 +278,22 @@ int cq_permutation_assembly_copy(uint32_t columns, uint32_t n, uint32_t* mapping
  * host; may be NULL when the circuit has no static lookup, as may `cfg`). */
 int cq_pk_create(cq_ctx* ctx, cq_params* params, const cq_circuit* circuit, cq_table_config* cfg,
                  const uint64_t* b0_g1_bound, int b0_on_device, cq_pk** out);
+/* ProvingKey::write / ProvingKey::read, SerdeFormat::RawBytes / RawBytesUnchecked (plonk.rs:349-403).  Layout:
+ *   VerifyingKey::write (:92-113): k:u32 BE | #fixed:u32 BE | fixed commitments (64 B each, raw Montgomery x||y) |
+ *     permutation commitments (64 B each) | per selector 2^k/8 bytes of packed bits (helpers.rs:98-105)
+ *   then l0 | l_last | l_active_row | fixed_values | fixed_polys | fixed_cosets | permutation {permutations, polys,
+ *     cosets} where a polynomial is len:u32 BE + len x 32 B raw limbs (poly.rs:163-170) and a slice of
+ *     polynomials starts with its count:u32 BE (helpers.rs:129-140).
+ * cq_pk_read_raw = cq_pk_create with those polynomials uploaded straight into HBM instead of recomputed (cosets
+ * included: no NTT runs); `circuit` gives the shape (its plonk->fixed / perm_mapping are not read), `num_selectors`
+ * the number of selector bit vectors to skip, `checked` != 0 validates every element (RawBytes).  The Rust reader
+ * leaves static tables / b0_g1_bound empty (:396-401, "FIXME"); here they are passed as for cq_pk_create.
+ * cq_pk_write_raw emits the same stream (`selector_bits` is copied through: the prover does not keep selectors). */
+int cq_pk_read_raw(cq_ctx* ctx, cq_params* params, const cq_circuit* circuit, cq_table_config* cfg,
+                   const uint64_t* b0_g1_bound, int b0_on_device, const uint8_t* buf, size_t len, uint32_t num_selectors,
+                   int checked, cq_pk** out);
+size_t cq_pk_raw_size(const cq_pk* pk, uint32_t num_selectors);
+int cq_pk_write_raw(cq_pk* pk, const uint8_t* selector_bits, uint32_t num_selectors, uint8_t* buf, size_t cap, size_t* written);
 /* Shards every commitment of cq_create_proof across `world` ranks by point range: rank r
  * multiplies the slice shard(len, r, world) of each (scalars, bases) pair, the 96-byte Jacobian partials are
  * all-gathered through `fn` and summed locally (EC addition is not an RCCL reduction op), so every rank

@@ -480,16 +480,18 @@ class _CqCircuit(C.Structure):
     ]
 
 
-def _lower_plonk(cs, fixed, mapping, keep: list) -> _CqPlonk:
-    """`ConstraintSystem` (+ the keygen outputs `fixed_values`, `Assembly.mapping`) -> cq_plonk arrays."""
+def _lower_plonk(cs, fixed, mapping, keep: list, from_raw: bool = False) -> _CqPlonk:
+    """`ConstraintSystem` (+ the keygen outputs `fixed_values`, `Assembly.mapping`) -> cq_plonk arrays.
+    from_raw: the key's polynomials come from a serialized ProvingKey, only the shape is lowered."""
     pl = _CqPlonk()
     n_fixed = cs.num_fixed_columns
     fixed = [_fr(f) for f in (fixed or [])]
-    assert len(fixed) == n_fixed, "one value column per fixed column (pk.fixed_values)"
-    fptrs = (C.c_void_p * max(n_fixed, 1))(*[f.ctypes.data for f in fixed])
-    keep += [fixed, fptrs]
     pl.num_fixed, pl.num_instance = n_fixed, cs.num_instance_columns
-    pl.fixed = C.cast(fptrs, C.POINTER(C.c_void_p))
+    if not from_raw:
+        assert len(fixed) == n_fixed, "one value column per fixed column (pk.fixed_values)"
+        fptrs = (C.c_void_p * max(n_fixed, 1))(*[f.ctypes.data for f in fixed])
+        keep += [fixed, fptrs]
+        pl.fixed = C.cast(fptrs, C.POINTER(C.c_void_p))
     pl.cs_degree, pl.blinding_factors = cs.degree(), cs.blinding_factors()
 
     def u32(vals):
@@ -529,7 +531,7 @@ def _lower_plonk(cs, fixed, mapping, keep: list) -> _CqPlonk:
     pl.perm_column_indices = u32([c.index for c in cs.permutation_columns])
     if mapping is not None:
         m = np.ascontiguousarray(mapping, dtype=np.uint32)
-        assert m.shape == (len(cs.permutation_columns), fixed[0].shape[0] if fixed else m.shape[1], 2)
+        assert m.shape == (len(cs.permutation_columns), m.shape[1], 2)
         keep.append(m)
         pl.perm_mapping = m.ctypes.data_as(C.POINTER(C.c_uint32))
     return pl
@@ -550,7 +552,8 @@ class ProvingKey(_Handle):
     _destroy = "cq_pk_destroy"
 
     def __init__(self, ctx: Context, params: ParamsKZG, k: int, num_advice: int, lookups, table_cfg: TableConfig,
-                 b0_g1_bound, vk_repr: np.ndarray, cs=None, fixed=None, permutation=None):
+                 b0_g1_bound, vk_repr: np.ndarray, cs=None, fixed=None, permutation=None, raw: bytes = None,
+                 num_selectors: int = 0, checked: bool = True):
         self.ctx, self.params, self.k = ctx, params, k
         self.cs = cs
         if cs is not None:
@@ -570,7 +573,7 @@ class ProvingKey(_Handle):
         for i in range(4):
             cs_.vk_repr[i] = int(vr[i])
         if cs is not None:
-            pl = _lower_plonk(cs, fixed, permutation, self._keep)
+            pl = _lower_plonk(cs, fixed, permutation, self._keep, from_raw=raw is not None)
             self._keep.append(pl)
             cs_.plonk = C.pointer(pl)
         h = C.c_void_p()
@@ -583,8 +586,13 @@ class ProvingKey(_Handle):
             assert b0.shape[0] == (1 << k) - 1, "b0_g1_bound must hold n-1 points (arithmetic.rs:133)"
             self._b0 = b0
             b0_ptr, on_dev = b0.ctypes.data, 0
-        ctx._chk(ctx.lib.cq_pk_create(ctx.h, params.h, C.byref(cs_), table_cfg.h if table_cfg is not None else None, b0_ptr, on_dev,
-                                       C.byref(h)))
+        cfg_h = table_cfg.h if table_cfg is not None else None
+        if raw is None:
+            ctx._chk(ctx.lib.cq_pk_create(ctx.h, params.h, C.byref(cs_), cfg_h, b0_ptr, on_dev, C.byref(h)))
+        else:  # `ProvingKey::read(reader, RawBytes | RawBytesUnchecked)` (plonk.rs:379-403)
+            rb = np.frombuffer(raw, dtype=np.uint8)
+            ctx._chk(ctx.lib.cq_pk_read_raw(ctx.h, params.h, C.byref(cs_), cfg_h, b0_ptr, on_dev, rb.ctypes.data, rb.shape[0],
+                                            num_selectors, 1 if checked else 0, C.byref(h)))
         self.h = h
         self.num_advice = num_advice
         self.usable_rows = ctx.lib.cq_pk_usable_rows(h)
@@ -604,6 +612,16 @@ class ProvingKey(_Handle):
             self.ctx._chk(self.ctx.lib.cq_create_proof_instances(self.h, arr, 1 if on_device else 0, iptr, ilen, rng_fn, rng_state,
                                                                  proof, self.proof_size, C.byref(plen)))
         return bytes(proof[: plen.value])
+
+    def to_bytes(self, selector_bits: bytes = b"", num_selectors: int = 0) -> bytes:
+        """`ProvingKey::to_bytes(SerdeFormat::RawBytes)` (plonk.rs:405-410)."""
+        size = self.ctx.lib.cq_pk_raw_size(self.h, num_selectors)
+        buf = np.zeros(size, dtype=np.uint8)
+        sel = np.frombuffer(selector_bits, dtype=np.uint8) if num_selectors else None
+        w = C.c_size_t()
+        self.ctx._chk(self.ctx.lib.cq_pk_write_raw(self.h, sel.ctypes.data if sel is not None else None, num_selectors,
+                                                   buf.ctypes.data, size, C.byref(w)))
+        return buf[: w.value].tobytes()
 
     def set_opener(self, name: str):
         """`P: Prover` of create_proof: "gwc" (ProverGWC, default) or "shplonk" (ProverSHPLONK)."""

@@ -178,8 +178,47 @@ static int pk_abort(cq_pk* pk, int rc) {
   return rc;
 }
 
-int cq_pk_create(cq_ctx* c, cq_params* params, const cq_circuit* cs, cq_table_config* cfg, const uint64_t* b0_g1_bound,
-                 int b0_on_device, cq_pk** out) {
+// Cursor over a ProvingKey::write byte stream (plonk.rs:349-362): big-endian u32 counts, raw 32-byte elements
+namespace {
+struct RawReader {
+  const uint8_t* p = nullptr;
+  size_t left = 0;
+  bool ok = true;
+  uint32_t be32() {
+    if (left < 4) { ok = false; return 0; }
+    const uint32_t v = ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3];
+    p += 4;
+    left -= 4;
+    return v;
+  }
+  const uint8_t* take(size_t bytes) {
+    if (left < bytes) { ok = false; return nullptr; }
+    const uint8_t* q = p;
+    p += bytes;
+    left -= bytes;
+    return q;
+  }
+};
+void put_be32(uint8_t*& o, uint32_t v) {
+  o[0] = (uint8_t)(v >> 24); o[1] = (uint8_t)(v >> 16); o[2] = (uint8_t)(v >> 8); o[3] = (uint8_t)v;
+  o += 4;
+}
+// unit vector at `row` on the extended coset (l0 / l_last, keygen.rs:340-363); tmp: n elements of scratch
+int unit_coset(cq_pk* pk, size_t row, Fr* tmp, Fr* dst) {
+  cq_ctx* c = pk->ctx;
+  const size_t n = (size_t)1 << pk->k, ext = pk->domain->ext();
+  const Fr one = Fr::one();
+  CQ_HIP(c, hipMemsetAsync(tmp, 0, n * sizeof(Fr), c->stream));
+  CQ_HIP(c, hipMemcpyAsync(tmp + row, &one, sizeof(Fr), hipMemcpyHostToDevice, c->stream));
+  CQ_HIP(c, hipStreamSynchronize(c->stream));
+  int rc;
+  if ((rc = domain_lagrange_to_coeff(pk->domain, tmp, tmp, 1, n, n)) != CQ_OK) return rc;
+  return domain_coeff_to_extended(pk->domain, tmp, dst, 1, n, ext);
+}
+}  // namespace
+
+static int pk_create_impl(cq_ctx* c, cq_params* params, const cq_circuit* cs, cq_table_config* cfg, const uint64_t* b0_g1_bound,
+                          int b0_on_device, const uint8_t* raw, size_t raw_len, uint32_t num_selectors, int checked, cq_pk** out) {
   if (!c || !params || !cs || !out) return CQ_ERR_ARG;
   if (cs->num_lookups && (!cfg || !b0_g1_bound)) return c->fail(CQ_ERR_ARG, "pk: static lookups need a table config and b0_g1_bound");
   if (cs->k != params->k) return c->fail(CQ_ERR_ARG, "pk: circuit k differs from params k");
@@ -223,7 +262,7 @@ int cq_pk_create(cq_ctx* c, cq_params* params, const cq_circuit* cs, cq_table_co
     pk->cs_degree = pl->cs_degree ? pl->cs_degree : 3;
     if (pk->cs_degree < 3 || pk->cs_degree - 2 > PERM_MAX_CHUNK) return pk_abort(pk, c->fail(CQ_ERR_ARG, "pk: cs_degree out of range"));
     if (pl->num_perm_columns > PERM_MAX_COLUMNS) return pk_abort(pk, c->fail(CQ_ERR_ARG, "pk: too many permutation columns"));
-    if ((pl->num_fixed && !pl->fixed) || (pl->num_gate_polys && (!pl->gate_program_lens || !pl->gate_programs)) ||
+    if ((pl->num_fixed && !pl->fixed && !raw) || (pl->num_gate_polys && (!pl->gate_program_lens || !pl->gate_programs)) ||
         (pl->num_constants && !pl->constants) || (pl->num_perm_columns && (!pl->perm_column_kinds || !pl->perm_column_indices)))
       return pk_abort(pk, c->fail(CQ_ERR_ARG, "pk: null pointer in cq_plonk"));
     for (uint32_t q = 0; q < pl->num_advice_queries; q++) {
@@ -263,20 +302,56 @@ int cq_pk_create(cq_ctx* c, cq_params* params, const cq_circuit* cs, cq_table_co
   // l_active_row = 1 - (l_last + l_blind) on the extended coset (keygen.rs:344-373); by linearity it is
   // the coset extension of the indicator of the usable rows
   if (hipMalloc(&pk->l_active_row, ext * sizeof(Fr)) != hipSuccess) return pk_abort(pk, c->fail(CQ_ERR_HIP, "hipMalloc(l_active_row)"));
-  if ((rc = poly_fill_usable_rows(c, (Fr*)tmp, (uint32_t)n, pk->u)) != CQ_OK) return pk_abort(pk, rc);
-  if ((rc = domain_lagrange_to_coeff(pk->domain, (Fr*)tmp, (Fr*)tmp, 1, n, n)) != CQ_OK) return pk_abort(pk, rc);
-  if ((rc = domain_coeff_to_extended(pk->domain, (Fr*)tmp, pk->l_active_row, 1, n, ext)) != CQ_OK) return pk_abort(pk, rc);
-  if (pk->general()) {
-    // l0 (keygen.rs:340-345) and l_last (:357-363): unit vectors at rows 0 and n - bf - 1
-    const Fr one = Fr::one();
+  // ---- ProvingKey::read (plonk.rs:379-403): with a serialized key the polynomial data below is uploaded straight
+  // into HBM instead of being recomputed.  The VerifyingKey part (k, fixed / permutation commitments, selector
+  // bits; :92-113) is skipped: the prover only needs its shape, which the circuit description gives.
+  RawReader rd;
+  std::vector<std::pair<Fr*, size_t>> to_check;  // uploaded vectors to validate under SerdeFormat::RawBytes
+  auto read_poly = [&](Fr* dst, size_t expect) -> int {
+    const uint32_t len = rd.be32();
+    const uint8_t* src = rd.take((size_t)len * sizeof(Fr));
+    if (!rd.ok || len != expect) return c->fail(CQ_ERR_ARG, "pk: serialized polynomial has the wrong length");
+    if (dst) {
+      CQ_HIP(c, hipMemcpyAsync(dst, src, (size_t)len * sizeof(Fr), hipMemcpyHostToDevice, c->stream));
+      to_check.push_back({dst, len});
+    }
+    return CQ_OK;
+  };
+  auto read_slice = [&](Fr* dst, size_t count, size_t each) -> int {
+    if (rd.be32() != count || !rd.ok) return c->fail(CQ_ERR_ARG, "pk: serialized key has a different number of polynomials");
+    for (size_t i = 0; i < count; i++) {
+      int r2 = read_poly(dst ? dst + i * each : nullptr, each);
+      if (r2 != CQ_OK) return r2;
+    }
+    return CQ_OK;
+  };
+  if (raw) {
+    rd.p = raw;
+    rd.left = raw_len;
+    const uint32_t rk = rd.be32(), nfix = rd.be32();
+    const size_t nperm = pk->perm_columns.size();
+    rd.take((size_t)nfix * sizeof(G1Affine) + nperm * sizeof(G1Affine) + (size_t)num_selectors * ((n + 7) / 8));
+    if (!rd.ok || rk != pk->k || nfix != pk->num_fixed) return pk_abort(pk, c->fail(CQ_ERR_ARG, "pk: serialized key does not match the circuit"));
+  }
+  if (raw) {
+    // l0, l_last, l_active_row (keygen.rs:338-373) come first; a CQ-only prover reads only the last
     for (int which = 0; which < 2; which++) {
       Fr** dst = which ? &pk->l_last : &pk->l0;
-      if (hipMalloc(dst, ext * sizeof(Fr)) != hipSuccess) return pk_abort(pk, c->fail(CQ_ERR_HIP, "hipMalloc(l0/l_last)"));
-      CQ_HIP(c, hipMemsetAsync(tmp, 0, n * sizeof(Fr), c->stream));
-      CQ_HIP(c, hipMemcpyAsync((Fr*)tmp + (which ? n - pk->bf - 1 : 0), &one, sizeof(Fr), hipMemcpyHostToDevice, c->stream));
-      CQ_HIP(c, hipStreamSynchronize(c->stream));
-      if ((rc = domain_lagrange_to_coeff(pk->domain, (Fr*)tmp, (Fr*)tmp, 1, n, n)) != CQ_OK) return pk_abort(pk, rc);
-      if ((rc = domain_coeff_to_extended(pk->domain, (Fr*)tmp, *dst, 1, n, ext)) != CQ_OK) return pk_abort(pk, rc);
+      if (pk->general() && hipMalloc(dst, ext * sizeof(Fr)) != hipSuccess) return pk_abort(pk, c->fail(CQ_ERR_HIP, "hipMalloc(l0/l_last)"));
+      if ((rc = read_poly(pk->general() ? *dst : nullptr, ext)) != CQ_OK) return pk_abort(pk, rc);
+    }
+    if ((rc = read_poly(pk->l_active_row, ext)) != CQ_OK) return pk_abort(pk, rc);
+  } else {
+    if ((rc = poly_fill_usable_rows(c, (Fr*)tmp, (uint32_t)n, pk->u)) != CQ_OK) return pk_abort(pk, rc);
+    if ((rc = domain_lagrange_to_coeff(pk->domain, (Fr*)tmp, (Fr*)tmp, 1, n, n)) != CQ_OK) return pk_abort(pk, rc);
+    if ((rc = domain_coeff_to_extended(pk->domain, (Fr*)tmp, pk->l_active_row, 1, n, ext)) != CQ_OK) return pk_abort(pk, rc);
+    if (pk->general()) {
+      // l0 (keygen.rs:340-345) and l_last (:357-363): unit vectors at rows 0 and n - bf - 1
+      for (int which = 0; which < 2; which++) {
+        Fr** dst = which ? &pk->l_last : &pk->l0;
+        if (hipMalloc(dst, ext * sizeof(Fr)) != hipSuccess) return pk_abort(pk, c->fail(CQ_ERR_HIP, "hipMalloc(l0/l_last)"));
+        if ((rc = unit_coset(pk, which ? n - pk->bf - 1 : 0, (Fr*)tmp, *dst)) != CQ_OK) return pk_abort(pk, rc);
+      }
     }
   }
   if (pk->num_fixed) {
@@ -284,10 +359,19 @@ int cq_pk_create(cq_ctx* c, cq_params* params, const cq_circuit* cs, cq_table_co
     if (hipMalloc(&pk->fixed_values, F * n * sizeof(Fr)) != hipSuccess || hipMalloc(&pk->fixed_polys, F * n * sizeof(Fr)) != hipSuccess ||
         hipMalloc(&pk->fixed_cosets, F * ext * sizeof(Fr)) != hipSuccess)
       return pk_abort(pk, c->fail(CQ_ERR_HIP, "hipMalloc(fixed columns)"));
-    for (size_t f = 0; f < F; f++)
-      CQ_HIP(c, hipMemcpyAsync(pk->fixed_values + f * n, pl->fixed[f], n * sizeof(Fr), hipMemcpyHostToDevice, c->stream));
-    if ((rc = domain_lagrange_to_coeff(pk->domain, pk->fixed_values, pk->fixed_polys, (uint32_t)F, n, n)) != CQ_OK) return pk_abort(pk, rc);
-    if ((rc = domain_coeff_to_extended(pk->domain, pk->fixed_polys, pk->fixed_cosets, (uint32_t)F, n, ext)) != CQ_OK) return pk_abort(pk, rc);
+    if (raw) {
+      if ((rc = read_slice(pk->fixed_values, F, n)) != CQ_OK || (rc = read_slice(pk->fixed_polys, F, n)) != CQ_OK ||
+          (rc = read_slice(pk->fixed_cosets, F, ext)) != CQ_OK)
+        return pk_abort(pk, rc);
+    } else {
+      for (size_t f = 0; f < F; f++)
+        CQ_HIP(c, hipMemcpyAsync(pk->fixed_values + f * n, pl->fixed[f], n * sizeof(Fr), hipMemcpyHostToDevice, c->stream));
+      if ((rc = domain_lagrange_to_coeff(pk->domain, pk->fixed_values, pk->fixed_polys, (uint32_t)F, n, n)) != CQ_OK) return pk_abort(pk, rc);
+      if ((rc = domain_coeff_to_extended(pk->domain, pk->fixed_polys, pk->fixed_cosets, (uint32_t)F, n, ext)) != CQ_OK) return pk_abort(pk, rc);
+    }
+  } else if (raw) {
+    if ((rc = read_slice(nullptr, 0, n)) != CQ_OK || (rc = read_slice(nullptr, 0, n)) != CQ_OK || (rc = read_slice(nullptr, 0, ext)) != CQ_OK)
+      return pk_abort(pk, rc);
   }
   if (pl && pl->num_gate_polys) {
     const char* why = nullptr;
@@ -338,6 +422,11 @@ int cq_pk_create(cq_ctx* c, cq_params* params, const cq_circuit* cs, cq_table_co
         hipMalloc(&pk->perm_polys, PC * n * sizeof(Fr)) != hipSuccess || hipMalloc(&pk->perm_cosets, PC * ext * sizeof(Fr)) != hipSuccess)
       return pk_abort(pk, c->fail(CQ_ERR_HIP, "hipMalloc(permutation key)"));
     if ((rc = fr_powers(c, pk->domain->omega, (uint32_t)n, pk->omega_powers)) != CQ_OK) return pk_abort(pk, rc);
+    if (raw) {  // permutation::ProvingKey::read (permutation.rs:124-134)
+      if ((rc = read_slice(pk->perm_values, PC, n)) != CQ_OK || (rc = read_slice(pk->perm_polys, PC, n)) != CQ_OK ||
+          (rc = read_slice(pk->perm_cosets, PC, ext)) != CQ_OK)
+        return pk_abort(pk, rc);
+    } else {
     std::vector<uint32_t> ident;
     const uint32_t* mapping = pl->perm_mapping;
     if (!mapping) {
@@ -368,6 +457,22 @@ int cq_pk_create(cq_ctx* c, cq_params* params, const cq_circuit* cs, cq_table_co
     if ((rc = perm_sigma(c, map_dev, (uint32_t)PC, (uint32_t)n, pk->omega_powers, dp_dev, pk->perm_values)) != CQ_OK) return pk_abort(pk, rc);
     if ((rc = domain_lagrange_to_coeff(pk->domain, pk->perm_values, pk->perm_polys, (uint32_t)PC, n, n)) != CQ_OK) return pk_abort(pk, rc);
     if ((rc = domain_coeff_to_extended(pk->domain, pk->perm_polys, pk->perm_cosets, (uint32_t)PC, n, ext)) != CQ_OK) return pk_abort(pk, rc);
+    }
+  } else if (raw) {
+    if ((rc = read_slice(nullptr, 0, n)) != CQ_OK || (rc = read_slice(nullptr, 0, n)) != CQ_OK || (rc = read_slice(nullptr, 0, ext)) != CQ_OK)
+      return pk_abort(pk, rc);
+  }
+  if (raw && rd.left != 0) return pk_abort(pk, c->fail(CQ_ERR_ARG, "pk: trailing bytes after the serialized key"));
+  if (raw && checked) {  // SerdeFormat::RawBytes: every field element below the modulus (helpers.rs:62-79)
+    void* flag;
+    if ((rc = c->ensure_scratch(1, 64, &flag)) != CQ_OK) return pk_abort(pk, rc);
+    CQ_HIP(c, hipMemsetAsync(flag, 0, 4, c->stream));
+    for (auto& v : to_check)
+      if ((rc = fr_validate(c, v.first, v.second, (uint32_t*)flag)) != CQ_OK) return pk_abort(pk, rc);
+    uint32_t bad = 0;
+    CQ_HIP(c, hipMemcpyAsync(&bad, flag, 4, hipMemcpyDeviceToHost, c->stream));
+    CQ_HIP(c, hipStreamSynchronize(c->stream));
+    if (bad) return pk_abort(pk, c->fail(CQ_ERR_ARG, "pk: field element not below the modulus"));
   }
   // b0_g1_bound: n-1 points (best_multiexp asserts equal lengths, arithmetic.rs:133)
   if (b0_g1_bound) {
@@ -393,6 +498,81 @@ int cq_pk_create(cq_ctx* c, cq_params* params, const cq_circuit* cs, cq_table_co
   CQ_HIP(c, hipStreamSynchronize(c->stream));
   *out = pk;
   return CQ_OK;
+}
+
+int cq_pk_create(cq_ctx* c, cq_params* params, const cq_circuit* cs, cq_table_config* cfg, const uint64_t* b0_g1_bound,
+                 int b0_on_device, cq_pk** out) {
+  return pk_create_impl(c, params, cs, cfg, b0_g1_bound, b0_on_device, nullptr, 0, 0, 0, out);
+}
+
+int cq_pk_read_raw(cq_ctx* c, cq_params* params, const cq_circuit* cs, cq_table_config* cfg, const uint64_t* b0_g1_bound,
+                   int b0_on_device, const uint8_t* buf, size_t len, uint32_t num_selectors, int checked, cq_pk** out) {
+  if (!buf) return CQ_ERR_ARG;
+  return pk_create_impl(c, params, cs, cfg, b0_g1_bound, b0_on_device, buf, len, num_selectors, checked, out);
+}
+
+size_t cq_pk_raw_size(const cq_pk* pk, uint32_t num_selectors) {
+  if (!pk) return 0;
+  const size_t n = (size_t)1 << pk->k, ext = pk->domain->ext(), F = pk->num_fixed, PC = pk->perm_columns.size();
+  const size_t poly_n = 4 + n * sizeof(Fr), poly_e = 4 + ext * sizeof(Fr);
+  return 8 + (F + PC) * sizeof(G1Affine) + (size_t)num_selectors * ((n + 7) / 8) + 3 * poly_e + 3 * 4 + F * (2 * poly_n + poly_e) + 3 * 4 +
+         PC * (2 * poly_n + poly_e);
+}
+
+// ProvingKey::write, SerdeFormat::RawBytes (plonk.rs:349-362)
+int cq_pk_write_raw(cq_pk* pk, const uint8_t* selector_bits, uint32_t num_selectors, uint8_t* buf, size_t cap, size_t* written) {
+  if (!pk || !buf || !written || (num_selectors && !selector_bits)) return CQ_ERR_ARG;
+  cq_ctx* c = pk->ctx;
+  CQ_HIP(c, hipSetDevice(c->device));
+  const size_t n = (size_t)1 << pk->k, ext = pk->domain->ext(), F = pk->num_fixed, PC = pk->perm_columns.size();
+  const size_t total = cq_pk_raw_size(pk, num_selectors);
+  if (cap < total) return c->fail(CQ_ERR_ARG, "pk: output buffer too small");
+  uint8_t* o = buf;
+  // VerifyingKey::write (:92-113): k, fixed commitments, permutation commitments, packed selector bits
+  put_be32(o, pk->k);
+  put_be32(o, (uint32_t)F);
+  std::vector<uint64_t> cm((F + PC) * 8 + 8);
+  int rc = cq_pk_vk_commitments(pk, cm.data(), cm.data() + F * 8);
+  if (rc != CQ_OK) return rc;
+  memcpy(o, cm.data(), (F + PC) * sizeof(G1Affine));
+  o += (F + PC) * sizeof(G1Affine);
+  const size_t sel_bytes = (size_t)num_selectors * ((n + 7) / 8);
+  if (sel_bytes) memcpy(o, selector_bits, sel_bytes);
+  o += sel_bytes;
+  auto write_poly = [&](const Fr* src, size_t len) -> int {
+    put_be32(o, (uint32_t)len);
+    CQ_HIP(c, hipMemcpyAsync(o, src, len * sizeof(Fr), hipMemcpyDeviceToHost, c->stream));
+    o += len * sizeof(Fr);
+    return CQ_OK;
+  };
+  auto write_slice = [&](const Fr* src, size_t count, size_t each) -> int {
+    put_be32(o, (uint32_t)count);
+    for (size_t i = 0; i < count; i++) {
+      int r2 = write_poly(src + i * each, each);
+      if (r2 != CQ_OK) return r2;
+    }
+    return CQ_OK;
+  };
+  // l0, l_last (a CQ-only key does not keep them: computed here), l_active_row
+  void* tmp;
+  if ((rc = c->ensure_scratch(1, (n + 2 * ext) * sizeof(Fr), &tmp)) != CQ_OK) return rc;
+  Fr* l0 = pk->l0;
+  Fr* l_last = pk->l_last;
+  if (!l0) {
+    l0 = (Fr*)tmp + n;
+    l_last = l0 + ext;
+    if ((rc = unit_coset(pk, 0, (Fr*)tmp, l0)) != CQ_OK || (rc = unit_coset(pk, n - pk->bf - 1, (Fr*)tmp, l_last)) != CQ_OK) return rc;
+  }
+  if ((rc = write_poly(l0, ext)) != CQ_OK || (rc = write_poly(l_last, ext)) != CQ_OK || (rc = write_poly(pk->l_active_row, ext)) != CQ_OK) return rc;
+  if ((rc = write_slice(pk->fixed_values, F, n)) != CQ_OK || (rc = write_slice(pk->fixed_polys, F, n)) != CQ_OK ||
+      (rc = write_slice(pk->fixed_cosets, F, ext)) != CQ_OK)
+    return rc;
+  if ((rc = write_slice(pk->perm_values, PC, n)) != CQ_OK || (rc = write_slice(pk->perm_polys, PC, n)) != CQ_OK ||
+      (rc = write_slice(pk->perm_cosets, PC, ext)) != CQ_OK)
+    return rc;
+  CQ_HIP(c, hipStreamSynchronize(c->stream));
+  *written = (size_t)(o - buf);
+  return *written == total ? CQ_OK : c->fail(CQ_ERR_INTERNAL, "pk: serialized size mismatch");
 }
 
 int cq_pk_set_opener(cq_pk* pk, int opener) {

@@ -348,6 +348,26 @@ __global__ void g1_validate_kernel(const G1Affine* __restrict__ pts, uint32_t n,
   if (!ok) atomicExch(bad, 1u);
 }
 
+// SerdeFormat::RawBytes for field elements (helpers.rs:62-79): raw Montgomery limbs must be below the modulus
+__global__ void fr_validate_kernel(const Fr* __restrict__ v, size_t n, uint32_t* __restrict__ bad) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint4* q = reinterpret_cast<const uint4*>(v + i);
+  const uint4 a = q[0], b = q[1];
+  const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+  bool lt = false;
+  for (int k = 7; k >= 0; k--) {
+    if (w[k] < FrP::MOD[k]) { lt = true; break; }
+    if (w[k] > FrP::MOD[k]) break;
+  }
+  if (!lt) atomicExch(bad, 1u);
+}
+
+int fr_validate(cq_ctx* c, const Fr* v, size_t n, uint32_t* bad_dev) {
+  if (n) fr_validate_kernel<<<(uint32_t)((n + 255) / 256), 256, 0, c->stream>>>(v, n, bad_dev);
+  return hipGetLastError() == hipSuccess ? CQ_OK : c->fail(CQ_ERR_HIP, "fr_validate launch failed");
+}
+
 int g1_validate(cq_ctx* c, const G1Affine* pts, uint32_t n, uint32_t* bad_dev) {
   if (n) g1_validate_kernel<<<(n + 255) / 256, 256, 0, c->stream>>>(pts, n, bad_dev);
   return hipGetLastError() == hipSuccess ? CQ_OK : c->fail(CQ_ERR_HIP, "g1_validate launch failed");

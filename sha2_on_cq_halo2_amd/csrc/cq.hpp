@@ -41,6 +41,7 @@ int sha_decomposition_table(cq_ctx* c, uint32_t first, uint32_t second, uint32_t
 int cq_table_quotients(cq_ctx* c, const Fr* coeffs, uint32_t N, const Fr& omega, const Fr& n_inv, uint32_t first_root,
                        uint32_t nroots, Fr* out);
 int g1_validate(cq_ctx* c, const G1Affine* pts, uint32_t n, uint32_t* bad_dev);
+int fr_validate(cq_ctx* c, const Fr* v, size_t n, uint32_t* bad_dev);
 
 }  // namespace cq
 

@@ -136,3 +136,43 @@ def test_plonk_large_proof_verifies(ctx, k, kw):
     bad_cols = [B.to_mont_limbs(list(c) + [0] * (n - len(c))) for c in adv]
     bad = gpk.create_proof(bad_cols, seed=5, instances=inst)
     assert not verify(bad)
+
+
+@pytest.mark.parametrize("kw", [dict(degree5=True), dict(with_lookup=True)], ids=["deg5", "lookup"])
+def test_proving_key_raw_bytes_roundtrip(ctx, kw):
+    """`ProvingKey::write` / `read` in SerdeFormat::RawBytes (plonk.rs:349-403): the backend's stream equals the
+    oracle's serialization of the same key byte for byte (cosets included), and a key READ from those bytes
+    (polynomials uploaded, nothing recomputed) proves to the same bytes."""
+    from oracle import serde as SD
+    from sha2_on_cq_halo2_amd import CqError, ProvingKey
+
+    k = 5
+    n = 1 << k
+    fx = oracle_env(k, **kw)
+    gpk, gparams = _backend_pk(ctx, fx, k, fx["s"], b0=fx["pk"].b0_g1_bound)
+    fixed_cm = B.batch_to_affine([fx["params"].commit_lagrange(c) for c in fx["pk"].fixed_values])
+    perm_cm = B.batch_to_affine([fx["params"].commit_lagrange(c) for c in fx["pk"].permutations])
+    selectors = [[(r * 7 + 1) % 3 == 0 for r in range(n)], [r % 2 == 1 for r in range(n)]]
+    want = SD.proving_key_to_bytes(fx["pk"], fixed_cm, perm_cm, selectors)
+    got = gpk.to_bytes(SD.pack_selectors(selectors, n), 2)
+    assert got == want
+    # read it back: no fixed columns / mapping handed over, only the circuit's shape
+    gtables, gcfg, b0_arg = {}, None, None
+    if fx["tables"]:
+        gcfg, gtables = gpk._keep[1], {name: t for name, t in zip(fx["tables"], gpk._keep[2])}
+        b0_arg = B.points_to_mont_limbs(fx["pk"].b0_g1_bound)
+    cs = to_backend_cs(fx["circuit"], gtables)
+    rpk = ProvingKey(ctx, gparams, k, 0, [], gcfg, b0_arg, B.to_mont_limbs([424242])[0], cs=cs, raw=want, num_selectors=2)
+    cols = _advice_cols(fx, n)
+    inst = [B.to_mont_limbs(i) for i in fx["instances"]]
+    assert rpk.create_proof(cols, seed=3, instances=inst) == gpk.create_proof(cols, seed=3, instances=inst)
+    assert rpk.to_bytes(SD.pack_selectors(selectors, n), 2) == want
+    # RawBytes checks: a limb vector >= the modulus is rejected; truncated input too
+    bad = bytearray(want)
+    off = 8 + 64 * (len(fixed_cm) + len(perm_cm)) + 2 * (n // 8) + 4  # first element of l0
+    bad[off:off + 32] = b"\xff" * 32
+    with pytest.raises(CqError):
+        ProvingKey(ctx, gparams, k, 0, [], gcfg, b0_arg, B.to_mont_limbs([424242])[0], cs=cs, raw=bytes(bad), num_selectors=2)
+    ProvingKey(ctx, gparams, k, 0, [], gcfg, b0_arg, B.to_mont_limbs([424242])[0], cs=cs, raw=bytes(bad), num_selectors=2, checked=False)
+    with pytest.raises(CqError):
+        ProvingKey(ctx, gparams, k, 0, [], gcfg, b0_arg, B.to_mont_limbs([424242])[0], cs=cs, raw=want[:-5], num_selectors=2)
