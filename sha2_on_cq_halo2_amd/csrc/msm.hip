@@ -8,25 +8,28 @@
 // MSMs of equal length (e.g. all advice columns of a phase, plonk/prover.rs:356-360); every
 // (msm, window, bucket) triple is one entry of a flat bucket array, so the batch only adds
 // parallelism.  GPU pipeline, all on one stream:
-//   1. digits    : scalar -> canonical (one Montgomery reduction) -> SIGNED c-bit digits
-//                  (halves the bucket count); flat histogram with wave-aggregated L2 atomics.
+//   1. digits    : scalar -> canonical (one Montgomery reduction) -> SIGNED c-bit digits (halves the bucket
+//                  count) and the histogram.  Table mode: per-block LDS histogram of 8192 scalars, one device
+//                  atomic per non-empty bucket per block (device-scope atomics on the small counter array are
+//                  the throughput limit otherwise); plain mode: one atomic per entry, issued back to back.
+//                  The value an atomic returns is the entry's rank inside its bucket.
 //   2. plan      : exclusive scans of the histogram (reduce / spine / apply): where each bucket's
 //                  index list starts, and how many bounded sub-lists it is cut into per level.
-//   3. scatter   : counting sort of point indices by bucket; sign kept in bit 31.
-//   4. accumulate: level 1 -- one lane per sub-list of <= MSM_S1 indices gathers affine bases
-//                  (64 B each; the SRS stays resident in HBM / Infinity Cache) into an XYZZ
-//                  accumulator (8M+2S per mixed add, no inversion).  Levels >= 2: one WAVE per
-//                  sub-list of <= MSM_S2 partial sums (strided lane sums + 6-step shuffle tree).
-//                  A bucket is written as soon as one lane/wave owns all of it.  Bounding the
-//                  per-lane work keeps the kernel balanced for skewed digit distributions (0/1
-//                  selector columns, SHA limb columns, the short top window) where a
-//                  lane-per-bucket kernel would serialise on one huge bucket.
-//                  256-bit modular integer work: VALU-bound, MFMA does not apply.
-//   5. reduce    : sum_b b*B_b per window: lane-local running sums, an LDS suffix scan and a tree
-//                  reduction, spread over M/256 workgroups per window plus one combining
-//                  workgroup (the reference does this serially, arithmetic.rs:95-99).
-//   6. host      : W window sums per MSM (<= 2 KiB) come back; Horner over windows (c doublings
-//                  each) on the host, O(254) group operations.
+//   3. scatter   : entries dropped at list start + rank; sign kept in bit 31, window in bits 26..30.
+//   4. accumulate: level 1 -- one lane per sub-list of <= MSM_S1 entries gathers affine points (64 B each, from
+//                  the per-window tables or the caller's array) into an XYZZ accumulator (8M+2S per mixed add,
+//                  no inversion) on the lazy 9x29-bit field (curve29.hpp); the next point's gather is in flight
+//                  while the current addition runs.  Levels >= 2: one LANE per short list of partial sums, one
+//                  WAVE per long one (strided lane sums + 6-step shuffle tree).  A bucket is written as soon
+//                  as one lane/wave owns all of it.  Bounding the per-lane work keeps the kernel balanced for
+//                  skewed digit distributions (0/1 selector columns, SHA limb columns) where a lane-per-bucket
+//                  kernel would serialise on one huge bucket.  256-bit modular integer work: VALU-bound, MFMA
+//                  does not apply.
+//   5. reduce    : sum_b b*B_b per bucket set, shaped for depth: buckets as a rows x cols matrix, one wave per
+//                  row / column sum, then two weighted wave sums (the reference does this serially,
+//                  arithmetic.rs:95-99).
+//   6. host      : table mode returns one Jacobian point per MSM; plain mode W window sums per MSM, folded by a
+//                  Horner over windows (c doublings each) on the host.
 #include "msm.hpp"
 #include "curve29.hpp"
 #include "ctx.hpp"
