@@ -33,8 +33,8 @@ from .bn254 import (
     to_jac,
     to_repr,
 )
-from .plonk import (ADVICE, FIXED, INSTANCE, build_permutation_pk, expr_degree, expr_eval, expr_queries,
-                    permutation_commit, permutation_h_terms, rotation_idx)
+from .plonk import (ADVICE, FIXED, INSTANCE, build_permutation_pk, expr_degree, expr_eval, expr_queries, lookup_h_terms,
+                    lookup_product, permutation_commit, permutation_h_terms, permute_expression_pair, rotation_idx)
 from .poly import EvaluationDomain, best_multiexp, eval_polynomial, kate_division
 from .shplonk import shplonk_prove
 
@@ -94,6 +94,8 @@ class CqCircuit:
     gates: list = field(default_factory=list)
     perm_columns: list = field(default_factory=list)
     queries: dict = None
+    # legacy (plookup-style) lookups, `cs.lookups`: [(input expressions, table expressions)] (plonk/lookup.rs:9-36)
+    plookups: list = field(default_factory=list)
 
     def _all_queries(self):
         if self.queries is not None:
@@ -102,6 +104,9 @@ class CqCircuit:
         for kind, idx in self.perm_columns:  # enable_equality -> query_any_index(col, cur) (circuit.rs:1523-1527)
             if (kind, idx, 0) not in q:
                 q.append((kind, idx, 0))
+        for ins, tabs in self.plookups:
+            for e in list(ins) + list(tabs):
+                expr_queries(e, q)
         for g in self.gates:
             expr_queries(g, q)
         for lk in self.lookups:
@@ -133,6 +138,8 @@ class CqCircuit:
         d = 3
         for g in self.gates:
             d = max(d, expr_degree(g))
+        for ins, tabs in self.plookups:  # lookup.rs:37-52: max(4, 2 + input degree + table degree)
+            d = max(d, 4, 2 + max([1] + [expr_degree(e) for e in ins]) + max([1] + [expr_degree(e) for e in tabs]))
         for lk in self.lookups:  # static_lookup.rs:181-190: max(3, 2 + input degree)
             for col, _ in lk:
                 d = max(d, 2 + expr_degree(_lookup_input(col)))
@@ -259,6 +266,28 @@ def create_proof(params, pk: ProvingKey, advice_usable, rng, msm=None, instances
     theta = tr.squeeze_challenge_scalar()  # :472
     out.challenges["theta"] = theta
 
+    # ---- legacy lookups: commit_permuted (lookup/prover.rs:57-160) -------------
+    cols_now = {ADVICE: advice, FIXED: pk.fixed_values, INSTANCE: instance_values}
+
+    def compress_lagrange(exprs):  # `evaluate(expr, n, 1, ..)` folded with theta (:98-117)
+        acc = [0] * n
+        for e in exprs:
+            vals = [expr_eval(e, lambda kind, c_, rot, row=row: cols_now[kind][c_][rotation_idx(row, rot, 1, n)]) for row in range(n)]
+            acc = [(a * theta + b) % P for a, b in zip(acc, vals)]
+        return acc
+
+    permuted = []
+    for ins, tabs in cs.plookups:
+        ci, ct = compress_lagrange(ins), compress_lagrange(tabs)
+        pi, pt = permute_expression_pair(n, bf, ci, ct, rng)
+        fr_random(rng)  # permuted_input_blind (:133-137)
+        pi_cm = commit_affine(msm(pi, params.g_lagrange))
+        fr_random(rng)  # permuted_table_blind
+        pt_cm = commit_affine(msm(pt, params.g_lagrange))
+        tr.write_point(pi_cm)
+        tr.write_point(pt_cm)
+        permuted.append((ci, ct, pi, pt, dom.lagrange_to_coeff(pi), dom.lagrange_to_coeff(pt)))
+
     # ---- CQ round 1 (static_lookup/prover.rs:51-183) -----------------------
     committed = []
     for li, lk in enumerate(cs.lookups):
@@ -315,6 +344,14 @@ def create_proof(params, pk: ProvingKey, advice_usable, rng, msm=None, instances
             tr.write_point(z_cm)
             perm_sets.append(dom.lagrange_to_coeff(z))
             out.points.setdefault("perm_z", []).append(z_cm)
+
+    # ---- legacy lookups: commit_product (lookup/prover.rs:163-300) --------------
+    plk = []
+    for (ci, ct, pi, pt, pi_poly, pt_poly) in permuted:
+        z = lookup_product(n, bf, ci, ct, pi, pt, beta, gamma, rng)
+        fr_random(rng)  # product_blind (:283)
+        tr.write_point(commit_affine(msm(z, params.g_lagrange)))
+        plk.append((dom.lagrange_to_coeff(z), pi_poly, pt_poly))
 
     # ---- CQ round 2 (static_lookup/prover.rs:187-342) ----------------------
     logd = []
@@ -376,7 +413,7 @@ def create_proof(params, pk: ProvingKey, advice_usable, rng, msm=None, instances
     rot_scale = 1 << (dom.extended_k - dom.k)
     h = [0] * ext
     advice_cosets = instance_cosets = None
-    if cs.gates or cs.perm_columns:
+    if cs.gates or cs.perm_columns or cs.plookups:
         advice_cosets = [dom.coeff_to_extended(p_) for p_ in advice_polys]  # :317-335
         instance_cosets = [dom.coeff_to_extended(p_) for p_ in instance_polys]
         src = {ADVICE: advice_cosets, FIXED: pk.fixed_cosets, INSTANCE: instance_cosets}
@@ -389,6 +426,16 @@ def create_proof(params, pk: ProvingKey, advice_usable, rng, msm=None, instances
         z_cosets = [dom.coeff_to_extended(z) for z in perm_sets]
         h = permutation_h_terms(dom, cs.degree(), bf, cs.perm_columns, lambda col: src[col[0]][col[1]], pk.perm_cosets,
                                 z_cosets, pk.l0, pk.l_last, pk.l_active_row, beta, gamma, y, h)
+    for (ins, tabs), (z_poly, pi_poly, pt_poly) in zip(cs.plookups, plk):  # legacy lookups (:461-531)
+        def compress_coset(exprs):
+            acc = [0] * ext
+            for e in exprs:
+                vals = [expr_eval(e, lambda kind, c_, rot, idx=idx: src[kind][c_][rotation_idx(idx, rot, rot_scale, ext)]) for idx in range(ext)]
+                acc = [(a * theta + b) % P for a, b in zip(acc, vals)]
+            return acc
+        tv = [((a + beta) % P) * ((b + gamma) % P) % P for a, b in zip(compress_coset(ins), compress_coset(tabs))]
+        h = lookup_h_terms(dom, dom.coeff_to_extended(z_poly), dom.coeff_to_extended(pi_poly), dom.coeff_to_extended(pt_poly), tv,
+                           pk.l0, pk.l_last, pk.l_active_row, beta, gamma, y, h)
     for (b_poly, _b0, f_coeff, _a0) in logd:  # :533-548
         b_coset = dom.coeff_to_extended(b_poly)
         f_coset = dom.coeff_to_extended(f_coeff)
@@ -434,6 +481,10 @@ def create_proof(params, pk: ProvingKey, advice_usable, rng, msm=None, instances
         tr.write_scalar(eval_polynomial(z, x_next))
         if si + 1 < len(perm_sets):
             tr.write_scalar(eval_polynomial(z, x_last))
+    x_inv = dom.rotate_omega(x, -1)
+    for (z_poly, pi_poly, pt_poly) in plk:  # lookup::Committed::evaluate (lookup/prover.rs:303-340)
+        for poly, pt_ in ((z_poly, x), (z_poly, x_next), (pi_poly, x), (pi_poly, x_inv), (pt_poly, x)):
+            tr.write_scalar(eval_polynomial(poly, pt_))
     for (b_poly, b0, f_coeff, a_at_zero) in logd:  # static_lookup/prover.rs:360-370
         tr.write_scalar(eval_polynomial(b0, x))
         tr.write_scalar(eval_polynomial(f_coeff, x))
@@ -448,6 +499,8 @@ def create_proof(params, pk: ProvingKey, advice_usable, rng, msm=None, instances
         queries.append((x_next, z))
     for z in reversed(perm_sets[:-1]):
         queries.append((x_last, z))
+    for (z_poly, pi_poly, pt_poly) in plk:  # lookup::Evaluated::open (lookup/prover.rs:343-392)
+        queries += [(x, z_poly), (x, pi_poly), (x, pt_poly), (x_inv, pi_poly), (x_next, z_poly)]
     for (b_poly, b0, f_coeff, _a) in logd:
         queries.append((x, b0))
         queries.append((x, f_coeff))

@@ -143,12 +143,14 @@ def verify_proof(proof: bytes, circuit, vk_repr: int, s: int, tables: dict, tabl
             tr.common_scalar(v_ % P)
     advice_cm = [tr.read_point() for _ in range(cs.num_advice)]
     theta = tr.squeeze()
+    plk_perm = [(tr.read_point(), tr.read_point()) for _ in cs.plookups]  # lookup/verifier.rs:39-52
     lk1 = [(tr.read_point(), tr.read_point()) for _ in cs.lookups]  # f, m
     beta = tr.squeeze()
     gamma = tr.squeeze()
     chunk_len = cs.degree() - 2
     n_sets = (len(cs.perm_columns) + chunk_len - 1) // chunk_len
     perm_z_cm = [tr.read_point() for _ in range(n_sets)]  # permutation/verifier.rs:37-57
+    plk_z = [tr.read_point() for _ in cs.plookups]  # lookup/verifier.rs:55-66
     lk2 = [tuple(tr.read_point() for _ in range(5)) for _ in cs.lookups]  # a, qa, a0, b0, p
     random_cm = tr.read_point()
     y = tr.squeeze()
@@ -165,6 +167,7 @@ def verify_proof(proof: bytes, circuit, vk_repr: int, s: int, tables: dict, tabl
         ze, zn = tr.read_scalar(), tr.read_scalar()
         zl = tr.read_scalar() if si + 1 < n_sets else None
         perm_evals.append((ze, zn, zl))
+    plk_evals = [tuple(tr.read_scalar() for _ in range(5)) for _ in cs.plookups]  # z, z_next, a', a'_inv, s' (:69-92)
     lk_evals = [(tr.read_scalar(), tr.read_scalar(), tr.read_scalar()) for _ in cs.lookups]
 
     xn = pow(x, n, P)
@@ -223,6 +226,17 @@ def verify_proof(proof: bytes, circuit, vk_repr: int, s: int, tables: dict, tabl
             exprs.append((left - right) * active % P)
         for e in exprs:
             h_eval = (h_eval * y + e) % P
+    for (ins, tabs), (ze, zn, ae, ai, se) in zip(cs.plookups, plk_evals):  # lookup/verifier.rs:96-157
+        def compress(exprs):
+            acc = 0
+            for e in exprs:
+                acc = (acc * theta + expr_eval(e, query_eval)) % P
+            return acc
+        left = zn * ((ae + beta) % P) % P * ((se + gamma) % P) % P
+        right = ze * ((compress(ins) + beta) % P) % P * ((compress(tabs) + gamma) % P) % P
+        for e in (l_0 * (1 - ze) % P, l_last * ((ze * ze - ze) % P) % P, (left - right) * active % P, l_0 * (ae - se) % P,
+                  (ae - se) * (ae - ai) % P * active % P):
+            h_eval = (h_eval * y + e) % P
     beta_inv = inv_mod(beta, P)
     n_inv = inv_mod(n % P, P)
     for (b0_eval, f_eval, a_at_zero) in lk_evals:
@@ -247,6 +261,10 @@ def verify_proof(proof: bytes, circuit, vk_repr: int, s: int, tables: dict, tabl
         queries.append((x_next, to_jac(zc), zn, ("z", si)))
     for si, (zc, (_ze, _zn, zl)) in reversed(zsets[:-1]):
         queries.append((x_last, to_jac(zc), zl, ("z", si)))
+    x_inv = dom.rotate_omega(x, -1)
+    for li, ((a_cm, s_cm), z_cm, (ze, zn, ae, ai, se)) in enumerate(zip(plk_perm, plk_z, plk_evals)):  # lookup/verifier.rs:159-216
+        queries += [(x, to_jac(z_cm), ze, ("lz", li)), (x, to_jac(a_cm), ae, ("la", li)), (x, to_jac(s_cm), se, ("ls", li)),
+                    (x_inv, to_jac(a_cm), ai, ("la", li)), (x_next, to_jac(z_cm), zn, ("lz", li))]
     for li, ((f_cm, _m), (a, qa, a0, b0, p_), (b0_eval, f_eval, _az)) in enumerate(zip(lk1, lk2, lk_evals)):
         queries.append((x, to_jac(b0), b0_eval, ("b0", li)))
         queries.append((x, to_jac(f_cm), f_eval, ("f", li)))

@@ -7,6 +7,8 @@ columns + copy constraints) circuit adds to the CQ-only path:
   (`evaluate`, plonk/evaluation.rs:776-818; `get_rotation_idx` :37-39);
 * `permutation::keygen::Assembly` (plonk/permutation/keygen.rs:14-113) and `build_pk` (:151-208);
 * `permutation::Argument::commit` (plonk/permutation/prover.rs:47-198);
+* the legacy (plookup-style) lookup argument: `permute_expression_pair`, `commit_permuted`, `commit_product`
+  (plonk/lookup/prover.rs:57-300, 400-502) and its terms of `evaluate_h` (plonk/evaluation.rs:461-531);
 * the permutation terms of `evaluate_h` (plonk/evaluation.rs:367-459).
 
 Parity status: no reference test pins any of these numerically (the permutation argument is only
@@ -244,4 +246,67 @@ def permutation_h_terms(dom, cs_degree, bf, columns, column_coset, perm_cosets, 
             v = (v * y + (left - right) * l_active[idx]) % P
         out[idx] = v
         beta_term = beta_term * dom.extended_omega % P
+    return out
+
+
+# ---- legacy lookup argument (plonk/lookup/prover.rs) ----------------------------------------------------------
+def permute_expression_pair(n, bf, input_expression, table_expression, rng):
+    """lookup/prover.rs:400-502.  `sort()` and the BTreeMap order field elements by canonical value
+    (derive/field.rs `Ord`: big-endian comparison of `to_repr`)."""
+    usable = n - (bf + 1)
+    permuted_input = sorted(input_expression[:usable])
+    leftover = {}
+    for v in table_expression[:usable]:
+        leftover[v] = leftover.get(v, 0) + 1
+    permuted_table = [0] * usable
+    repeated = []
+    for row, v in enumerate(permuted_input):
+        if row == 0 or v != permuted_input[row - 1]:
+            permuted_table[row] = v
+            if leftover.get(v, 0) > 0:
+                leftover[v] -= 1
+            else:
+                raise ValueError("ConstraintSystemFailure: lookup input not in table")
+        else:
+            repeated.append(row)
+    for v in sorted(leftover):
+        for _ in range(leftover[v]):
+            permuted_table[repeated.pop()] = v
+    assert not repeated
+    permuted_input += [fr_random(rng) for _ in range(bf + 1)]
+    permuted_table += [fr_random(rng) for _ in range(bf + 1)]
+    return permuted_input, permuted_table
+
+
+def lookup_product(n, bf, compressed_input, compressed_table, permuted_input, permuted_table, beta, gamma, rng):
+    """lookup/prover.rs:163-300: Lagrange values of the grand product z (without its blind)."""
+    prod = [((beta + a) % P) * ((gamma + s_) % P) % P for a, s_ in zip(permuted_input, permuted_table)]
+    prod = batch_invert(prod)
+    prod = [p_ * ((ci + beta) % P) % P * ((ct + gamma) % P) % P for p_, ci, ct in zip(prod, compressed_input, compressed_table)]
+    z = [1]
+    for v in prod:
+        z.append(z[-1] * v % P)
+    z = z[: n - bf]
+    z += [fr_random(rng) for _ in range(bf)]
+    assert len(z) == n
+    return z
+
+
+def lookup_h_terms(dom, z_coset, a_coset, s_coset, table_value, l0, l_last, l_active, beta, gamma, y, h):
+    """evaluation.rs:461-531; `table_value[idx]` = (compressed input + beta)(compressed table + gamma) on the coset."""
+    size = dom.extended_len
+    rot_scale = 1 << (dom.extended_k - dom.k)
+    out = list(h)
+    for idx in range(size):
+        r_next = rotation_idx(idx, 1, rot_scale, size)
+        r_prev = rotation_idx(idx, -1, rot_scale, size)
+        a_minus_s = (a_coset[idx] - s_coset[idx]) % P
+        v = out[idx]
+        v = (v * y + (1 - z_coset[idx]) * l0[idx]) % P
+        v = (v * y + (z_coset[idx] * z_coset[idx] - z_coset[idx]) * l_last[idx]) % P
+        v = (v * y + (z_coset[r_next] * ((a_coset[idx] + beta) % P) % P * ((s_coset[idx] + gamma) % P)
+                      - z_coset[idx] * table_value[idx]) % P * l_active[idx]) % P
+        v = (v * y + a_minus_s * l0[idx]) % P
+        v = (v * y + a_minus_s * ((a_coset[idx] - a_coset[r_prev]) % P) % P * l_active[idx]) % P
+        out[idx] = v
     return out

@@ -18,7 +18,7 @@ A, F, I = PL.ADVICE, PL.FIXED, PL.INSTANCE
 TABLE = [0, 1, 6, 8, 10, 12, 14, 16, 18, 20, 22, 24, 26, 28, 30, 32]
 
 
-def chain_circuit(k, degree5=False, with_lookup=False, lookup_expr=False, seed=1):
+def chain_circuit(k, degree5=False, with_lookup=False, lookup_expr=False, plookup=False, seed=1):
     """Returns dict(circuit, fixed, advice, instances, mapping, tables)."""
     n = 1 << k
     q_add, q_mul, q_next, q_prev, q_fix, kc = range(6)
@@ -43,7 +43,17 @@ def chain_circuit(k, degree5=False, with_lookup=False, lookup_expr=False, seed=1
         num_fixed += 1
         lookups = [[(PL.mul(PL.fix(q_lk), PL.add(PL.sub(PL.adv(3), PL.adv(3, -1)), PL.const(6))), "t")]]
     perm_columns = [(A, 0), (A, 1), (A, 2), (I, 0), (F, kc)]
-    circuit = CP.CqCircuit(k, num_advice, lookups, num_fixed, 1, gates, perm_columns)
+    plookups = []
+    if plookup:
+        # legacy lookup (plonk/lookup.rs): the pair (q_pl * p, q_pl * (2 p + 1)) must be a row of the fixed table
+        # (t0, t1); rows with q_pl = 0 look up (0, 0), which the table holds as its padding row
+        num_advice += 1
+        pcol = num_advice - 1
+        q_pl, t0, t1 = num_fixed, num_fixed + 1, num_fixed + 2
+        num_fixed += 3
+        plookups = [([PL.mul(PL.fix(q_pl), PL.adv(pcol)), PL.mul(PL.fix(q_pl), PL.add(PL.scale(PL.adv(pcol), 2), PL.const(1)))],
+                     [PL.fix(t0), PL.fix(t1)])]
+    circuit = CP.CqCircuit(k, num_advice, lookups, num_fixed, 1, gates, perm_columns, None, plookups)
     bf = circuit.blinding_factors()
     u = n - (bf + 1)
     R = u - 2  # chain rows
@@ -92,6 +102,16 @@ def chain_circuit(k, degree5=False, with_lookup=False, lookup_expr=False, seed=1
     elif with_lookup:
         for r in range(u):
             adv[3][r] = TABLE[(r * 7 + 3) % len(TABLE)]
+    if plookup:
+        vals = [3, 5, 8, 13, 21, 34, 55]
+        for i, v_ in enumerate(vals):  # table rows (v, 2v + 1); the remaining rows stay (0, 0)
+            fixed[t0][1 + i], fixed[t1][1 + i] = v_, 2 * v_ + 1
+        for r in range(u):
+            if r % 4 != 3:
+                fixed[q_pl][r] = 1
+                adv[pcol][r] = vals[(r * 5 + 2) % len(vals)]
+            else:
+                adv[pcol][r] = 777 + r  # unconstrained
     return dict(circuit=circuit, fixed=fixed, advice=adv, instances=instances, mapping=asm.mapping,
                 tables={"t": TABLE} if with_lookup else {})
 

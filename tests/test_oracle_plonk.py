@@ -47,19 +47,20 @@ def test_assembly_cycles():
         asm.copy(cols[0], 4, cols[1], 0)
 
 
-@pytest.mark.parametrize("kw", [dict(), dict(degree5=True), dict(with_lookup=True), dict(lookup_expr=True)],
-                         ids=["deg3", "deg5", "lookup", "lookup-expr"])
+@pytest.mark.parametrize("kw", [dict(), dict(degree5=True), dict(with_lookup=True), dict(lookup_expr=True), dict(plookup=True),
+                                dict(plookup=True, with_lookup=True)],
+                         ids=["deg3", "deg5", "lookup", "lookup-expr", "plookup", "plookup+cq"])
 def test_plonk_proof_verifies(kw):
     fx = oracle_env(5, **kw)
     cs = fx["circuit"]
-    assert cs.degree() == (5 if kw.get("degree5") else 4 if kw.get("lookup_expr") else 3)
+    assert cs.degree() == (5 if kw.get("degree5") else 5 if kw.get("plookup") else 4 if kw.get("lookup_expr") else 3)
     assert cs.blinding_factors() == 5  # at most two distinct queries per advice column (circuit.rs:2022-2047)
     tr = CP.create_proof(fx["params"], fx["pk"], fx["advice"], B.Xoshiro256ss(7), instances=fx["instances"])
     chunk = cs.degree() - 2
     sets = -(-len(cs.perm_columns) // chunk)
-    L = len(cs.lookups)
-    points = cs.num_advice + 2 * L + sets + 5 * L + 1 + (cs.degree() - 1) + 3  # + one W per distinct point
-    scalars = (len(cs.advice_queries()) + len(cs.fixed_queries()) + 1 + len(cs.perm_columns) + 3 * sets - 1 + 3 * L)
+    L, PLK = len(cs.lookups), len(cs.plookups)
+    points = cs.num_advice + 2 * L + 3 * PLK + sets + 5 * L + 1 + (cs.degree() - 1) + 3  # + one W per distinct point
+    scalars = (len(cs.advice_queries()) + len(cs.fixed_queries()) + 1 + len(cs.perm_columns) + 3 * sets - 1 + 3 * L + 5 * PLK)
     x_last_used = sets > 1
     assert len(tr.proof) == 32 * (points + scalars + (1 if x_last_used else 0))
     assert _verify(fx, tr.proof)
