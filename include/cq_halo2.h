@@ -246,6 +246,14 @@ typedef struct {
    * (static_lookup/prover.rs:91-107).  NULL = every input is advice[lookup_columns[i]] @ Rotation::cur(). */
   const uint32_t* lookup_input_program_lens;
   const uint32_t* lookup_input_programs;
+  /* Legacy (plookup-style) lookups, `cs.lookups` (plonk/lookup.rs:9-36): lookup l has legacy_lookup_widths[l] input
+   * expressions and as many table expressions; programs are flattened lookup by lookup, inputs first, then tables,
+   * and share `constants`.  The grand product, its quotient terms and all commitments run on the GPU; the sort of
+   * `permute_expression_pair` (lookup/prover.rs:400-502) runs on the host. */
+  uint32_t num_legacy_lookups;
+  const uint32_t* legacy_lookup_widths;
+  const uint32_t* legacy_program_lens;
+  const uint32_t* legacy_programs;
 } cq_plonk;
 
 /* Shape of the constraint system (stands in for ConstraintSystem, plonk/circuit.rs):

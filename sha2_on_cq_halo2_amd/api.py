@@ -464,6 +464,10 @@ class _CqPlonk(C.Structure):
         ("perm_mapping", C.POINTER(C.c_uint32)),
         ("lookup_input_program_lens", C.POINTER(C.c_uint32)),
         ("lookup_input_programs", C.POINTER(C.c_uint32)),
+        ("num_legacy_lookups", C.c_uint32),
+        ("legacy_lookup_widths", C.POINTER(C.c_uint32)),
+        ("legacy_program_lens", C.POINTER(C.c_uint32)),
+        ("legacy_programs", C.POINTER(C.c_uint32)),
     ]
 
 
@@ -521,6 +525,16 @@ def _lower_plonk(cs, fixed, mapping, keep: list, from_raw: bool = False) -> _CqP
             llens.append(len(prog))
             lwords += prog
         pl.lookup_input_program_lens, pl.lookup_input_programs = u32(llens), u32(lwords)
+    if cs.lookups:  # legacy lookups: per lookup the input programs, then the table programs
+        widths, plens, pwords = [], [], []
+        for ins, tabs in cs.lookups:
+            widths.append(len(ins))
+            for e in list(ins) + list(tabs):
+                prog = e.compile(constants)
+                plens.append(len(prog))
+                pwords += prog
+        pl.num_legacy_lookups = len(widths)
+        pl.legacy_lookup_widths, pl.legacy_program_lens, pl.legacy_programs = u32(widths), u32(plens), u32(pwords)
     cst = np.zeros((max(len(constants), 1), 4), dtype=np.uint64)
     for i, v in enumerate(constants):
         cst[i] = fr_to_mont(v)

@@ -280,6 +280,80 @@ static int pk_create_impl(cq_ctx* c, cq_params* params, const cq_circuit* cs, cq
       pk->perm_columns.push_back({kind, idx});
     }
   }
+  // ---- expression programs (gates, legacy lookups, static lookup inputs): validated and uploaded ----
+  int rc;
+  if (pl && pl->num_gate_polys) {
+    const char* why = nullptr;
+    size_t words = 0;
+    if (!gate_program_check(pl->gate_program_lens, pl->gate_programs, pl->num_gate_polys, pl->num_constants, cs->num_advice,
+                            pl->num_fixed, pl->num_instance, &why, &words))
+      return pk_abort(pk, c->fail(CQ_ERR_ARG, why));
+    std::vector<uint32_t> blob;
+    size_t o = 0;
+    for (uint32_t g = 0; g < pl->num_gate_polys; g++) {
+      blob.push_back(pl->gate_program_lens[g]);
+      blob.insert(blob.end(), pl->gate_programs + o, pl->gate_programs + o + pl->gate_program_lens[g]);
+      o += pl->gate_program_lens[g];
+    }
+    pk->num_gate_polys = pl->num_gate_polys;
+    if (hipMalloc(&pk->gate_prog, blob.size() * sizeof(uint32_t)) != hipSuccess) return pk_abort(pk, c->fail(CQ_ERR_HIP, "hipMalloc(gate program)"));
+    CQ_HIP(c, hipMemcpy(pk->gate_prog, blob.data(), blob.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+  }
+  if (pl && pl->num_constants) {
+    if (hipMalloc(&pk->constants, pl->num_constants * sizeof(Fr)) != hipSuccess) return pk_abort(pk, c->fail(CQ_ERR_HIP, "hipMalloc(gate constants)"));
+    CQ_HIP(c, hipMemcpy(pk->constants, pl->constants, pl->num_constants * sizeof(Fr), hipMemcpyHostToDevice));
+  }
+  if (pl && pl->num_legacy_lookups) {
+    if (!pl->legacy_lookup_widths || !pl->legacy_program_lens || !pl->legacy_programs) return pk_abort(pk, c->fail(CQ_ERR_ARG, "pk: null pointer in cq_plonk"));
+    size_t nprog = 0;
+    for (uint32_t l = 0; l < pl->num_legacy_lookups; l++) {
+      if (pl->legacy_lookup_widths[l] == 0 || pl->legacy_lookup_widths[l] > 64) return pk_abort(pk, c->fail(CQ_ERR_ARG, "pk: legacy lookup width out of range"));
+      nprog += 2 * (size_t)pl->legacy_lookup_widths[l];
+    }
+    const char* why = nullptr;
+    size_t words = 0;
+    if (!gate_program_check(pl->legacy_program_lens, pl->legacy_programs, (uint32_t)nprog, pl->num_constants, cs->num_advice, pl->num_fixed,
+                            pl->num_instance, &why, &words))
+      return pk_abort(pk, c->fail(CQ_ERR_ARG, why));
+    std::vector<uint32_t> blob;
+    size_t o = 0, idx = 0;
+    for (uint32_t l = 0; l < pl->num_legacy_lookups; l++) {
+      cq_pk::LegacyLookup lk;
+      lk.width = pl->legacy_lookup_widths[l];
+      for (int side = 0; side < 2; side++) {
+        (side ? lk.tab_off : lk.in_off) = blob.size();
+        for (uint32_t j = 0; j < lk.width; j++, idx++) {
+          blob.push_back(pl->legacy_program_lens[idx]);
+          blob.insert(blob.end(), pl->legacy_programs + o, pl->legacy_programs + o + pl->legacy_program_lens[idx]);
+          o += pl->legacy_program_lens[idx];
+        }
+      }
+      pk->legacy.push_back(lk);
+    }
+    if (hipMalloc(&pk->legacy_prog, blob.size() * sizeof(uint32_t)) != hipSuccess) return pk_abort(pk, c->fail(CQ_ERR_HIP, "hipMalloc(legacy lookup programs)"));
+    CQ_HIP(c, hipMemcpy(pk->legacy_prog, blob.data(), blob.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+  }
+  if (pl && pl->lookup_input_program_lens && off) {
+    // static lookup inputs given as expressions: one single-polynomial program each
+    if (!pl->lookup_input_programs) return pk_abort(pk, c->fail(CQ_ERR_ARG, "pk: null pointer in cq_plonk"));
+    const char* why = nullptr;
+    size_t words = 0;
+    if (!gate_program_check(pl->lookup_input_program_lens, pl->lookup_input_programs, (uint32_t)off, pl->num_constants,
+                            cs->num_advice, pl->num_fixed, pl->num_instance, &why, &words))
+      return pk_abort(pk, c->fail(CQ_ERR_ARG, why));
+    std::vector<uint32_t> blob;
+    size_t o = 0, idx = 0;
+    for (auto& lk : pk->lookups)
+      for (size_t j = 0; j < lk.cols.size(); j++, idx++) {
+        lk.prog[j] = (int64_t)blob.size();
+        blob.push_back(pl->lookup_input_program_lens[idx]);
+        blob.insert(blob.end(), pl->lookup_input_programs + o, pl->lookup_input_programs + o + pl->lookup_input_program_lens[idx]);
+        o += pl->lookup_input_program_lens[idx];
+      }
+    pk->lookup_exprs = true;
+    if (hipMalloc(&pk->lookup_prog, blob.size() * sizeof(uint32_t)) != hipSuccess) return pk_abort(pk, c->fail(CQ_ERR_HIP, "hipMalloc(lookup programs)"));
+    CQ_HIP(c, hipMemcpy(pk->lookup_prog, blob.data(), blob.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+  }
   // blinding_factors (plonk/circuit.rs:2022-2047)
   if (pl && pl->blinding_factors) {
     pk->bf = pl->blinding_factors;
@@ -293,7 +367,6 @@ static int pk_create_impl(cq_ctx* c, cq_params* params, const cq_circuit* cs, cq
   if (n < (size_t)pk->bf + 3)  // minimum_rows (circuit.rs:2051-2059)
     return pk_abort(pk, c->fail(CQ_ERR_ARG, "pk: not enough rows available"));
   pk->u = (uint32_t)(n - (pk->bf + 1));
-  int rc;
   // extended domain for cs.degree(): 3 for permutation / static lookups (static_lookup.rs:181-190), more with gates
   if ((rc = domain_create(c, pk->cs_degree, pk->k, &pk->domain)) != CQ_OK) return pk_abort(pk, rc);
   const size_t ext = pk->domain->ext();
@@ -372,48 +445,6 @@ static int pk_create_impl(cq_ctx* c, cq_params* params, const cq_circuit* cs, cq
   } else if (raw) {
     if ((rc = read_slice(nullptr, 0, n)) != CQ_OK || (rc = read_slice(nullptr, 0, n)) != CQ_OK || (rc = read_slice(nullptr, 0, ext)) != CQ_OK)
       return pk_abort(pk, rc);
-  }
-  if (pl && pl->num_gate_polys) {
-    const char* why = nullptr;
-    size_t words = 0;
-    if (!gate_program_check(pl->gate_program_lens, pl->gate_programs, pl->num_gate_polys, pl->num_constants, cs->num_advice,
-                            pl->num_fixed, pl->num_instance, &why, &words))
-      return pk_abort(pk, c->fail(CQ_ERR_ARG, why));
-    std::vector<uint32_t> blob;
-    size_t o = 0;
-    for (uint32_t g = 0; g < pl->num_gate_polys; g++) {
-      blob.push_back(pl->gate_program_lens[g]);
-      blob.insert(blob.end(), pl->gate_programs + o, pl->gate_programs + o + pl->gate_program_lens[g]);
-      o += pl->gate_program_lens[g];
-    }
-    pk->num_gate_polys = pl->num_gate_polys;
-    if (hipMalloc(&pk->gate_prog, blob.size() * sizeof(uint32_t)) != hipSuccess) return pk_abort(pk, c->fail(CQ_ERR_HIP, "hipMalloc(gate program)"));
-    CQ_HIP(c, hipMemcpy(pk->gate_prog, blob.data(), blob.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-  }
-  if (pl && pl->num_constants) {
-    if (hipMalloc(&pk->constants, pl->num_constants * sizeof(Fr)) != hipSuccess) return pk_abort(pk, c->fail(CQ_ERR_HIP, "hipMalloc(gate constants)"));
-    CQ_HIP(c, hipMemcpy(pk->constants, pl->constants, pl->num_constants * sizeof(Fr), hipMemcpyHostToDevice));
-  }
-  if (pl && pl->lookup_input_program_lens && off) {
-    // static lookup inputs given as expressions: one single-polynomial program each
-    if (!pl->lookup_input_programs) return pk_abort(pk, c->fail(CQ_ERR_ARG, "pk: null pointer in cq_plonk"));
-    const char* why = nullptr;
-    size_t words = 0;
-    if (!gate_program_check(pl->lookup_input_program_lens, pl->lookup_input_programs, (uint32_t)off, pl->num_constants,
-                            cs->num_advice, pl->num_fixed, pl->num_instance, &why, &words))
-      return pk_abort(pk, c->fail(CQ_ERR_ARG, why));
-    std::vector<uint32_t> blob;
-    size_t o = 0, idx = 0;
-    for (auto& lk : pk->lookups)
-      for (size_t j = 0; j < lk.cols.size(); j++, idx++) {
-        lk.prog[j] = (int64_t)blob.size();
-        blob.push_back(pl->lookup_input_program_lens[idx]);
-        blob.insert(blob.end(), pl->lookup_input_programs + o, pl->lookup_input_programs + o + pl->lookup_input_program_lens[idx]);
-        o += pl->lookup_input_program_lens[idx];
-      }
-    pk->lookup_exprs = true;
-    if (hipMalloc(&pk->lookup_prog, blob.size() * sizeof(uint32_t)) != hipSuccess) return pk_abort(pk, c->fail(CQ_ERR_HIP, "hipMalloc(lookup programs)"));
-    CQ_HIP(c, hipMemcpy(pk->lookup_prog, blob.data(), blob.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
   }
   if (!pk->perm_columns.empty()) {
     // permutation::keygen::Assembly::build_pk (permutation/keygen.rs:151-208)
@@ -596,7 +627,7 @@ void cq_pk_destroy(cq_pk* pk) {
   if (pk->domain) domain_destroy(pk->domain);
   if (pk->l_active_row) hipFree(pk->l_active_row);
   for (void* p : {(void*)pk->fixed_values, (void*)pk->fixed_polys, (void*)pk->fixed_cosets, (void*)pk->l0, (void*)pk->l_last,
-                  (void*)pk->gate_prog, (void*)pk->constants, (void*)pk->lookup_prog, (void*)pk->perm_values, (void*)pk->perm_polys, (void*)pk->perm_cosets,
+                  (void*)pk->gate_prog, (void*)pk->constants, (void*)pk->lookup_prog, (void*)pk->legacy_prog, (void*)pk->perm_values, (void*)pk->perm_polys, (void*)pk->perm_cosets,
                   (void*)pk->omega_powers})
     if (p) hipFree(p);
   if (pk->b0_g1_bound) msm_unregister_tables(pk->ctx, pk->b0_g1_bound);
@@ -620,11 +651,13 @@ size_t cq_pk_proof_size(const cq_pk* pk) {
   };
   for (auto& q : pk->advice_queries) seen(q.second);
   for (auto& q : pk->fixed_queries) seen(q.second);
-  if (S) seen(1);
+  const size_t PL = pk->legacy.size();
+  if (S || PL) seen(1);
+  if (PL) seen(-1);
   if (S > 1) seen(-(int32_t)(pk->bf + 1));
   const size_t openings = pk->opener == CQ_OPENER_SHPLONK ? 2 : rots.size();
-  const size_t points = pk->num_advice + 2 * L + S + 5 * L + 1 + pk->domain->quotient_poly_degree + openings;
-  const size_t scalars = pk->advice_queries.size() + pk->fixed_queries.size() + 1 + pk->perm_columns.size() + (S ? 3 * S - 1 : 0) + 3 * L;
+  const size_t points = pk->num_advice + 2 * L + 3 * PL + S + 5 * L + 1 + pk->domain->quotient_poly_degree + openings;
+  const size_t scalars = pk->advice_queries.size() + pk->fixed_queries.size() + 1 + pk->perm_columns.size() + (S ? 3 * S - 1 : 0) + 3 * L + 5 * PL;
   return 32 * (points + scalars);
 }
 

@@ -104,13 +104,18 @@ struct cq_pk {
   cq::Fr* constants = nullptr;      // device
   uint32_t* lookup_prog = nullptr;  // device: [1-poly program] per expression-valued lookup input
   bool lookup_exprs = false;
+  // legacy lookups: per lookup the number of (input, table) expression pairs and the word offsets of the two
+  // program lists ([len, words...] x width each) in `legacy_prog`
+  struct LegacyLookup { uint32_t width; size_t in_off, tab_off; };
+  std::vector<LegacyLookup> legacy;
+  uint32_t* legacy_prog = nullptr;
   std::vector<std::pair<uint32_t, uint32_t>> perm_columns;  // (CQ_COL_*, index) = cs.permutation.columns
   cq::Fr* perm_values = nullptr;    // columns x n   (permutation::ProvingKey::permutations)
   cq::Fr* perm_polys = nullptr;     // columns x n   (::polys)
   cq::Fr* perm_cosets = nullptr;    // columns x ext (::cosets)
   cq::Fr* omega_powers = nullptr;   // omega^i, i < n
   int opener = CQ_OPENER_GWC;
-  bool general() const { return num_gate_polys || !perm_columns.empty(); }
+  bool general() const { return num_gate_polys || !perm_columns.empty() || !legacy.empty(); }
   size_t perm_sets() const {
     const size_t chunk = cs_degree - 2;
     return (perm_columns.size() + chunk - 1) / chunk;

@@ -334,6 +334,79 @@ __global__ __launch_bounds__(256) void perm_h_kernel(PermHArgs a, Fr* __restrict
   st(h + i, v);
 }
 
+// ---- legacy (plookup-style) lookup argument --------------------------------------------------------------------
+// den[i] = (beta + a'[i]) (gamma + s'[i])   (lookup/prover.rs:200-209)
+__global__ __launch_bounds__(256) void lookup_den_kernel(const Fr* __restrict__ a, const Fr* __restrict__ s, Fr beta, Fr gamma, uint32_t n,
+                                                         Fr* __restrict__ out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  st(out + i, (beta + ld(a + i)) * (gamma + ld(s + i)));
+}
+// v[i] *= (A[i] + beta) (S[i] + gamma), A / S the compressed input / table expressions   (:213-221)
+__global__ __launch_bounds__(256) void lookup_num_kernel(const Fr* __restrict__ cin, const Fr* __restrict__ ctab, Fr beta, Fr gamma, uint32_t n,
+                                                         Fr* __restrict__ v) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  st(v + i, ld(v + i) * (ld(cin + i) + beta) * (ld(ctab + i) + gamma));
+}
+int lookup_denominators(cq_ctx* c, const Fr* a, const Fr* s, const Fr& beta, const Fr& gamma, uint32_t n, Fr* out) {
+  lookup_den_kernel<<<blocks_for(n), 256, 0, c->stream>>>(a, s, beta, gamma, n, out);
+  return hipGetLastError() == hipSuccess ? CQ_OK : c->fail(CQ_ERR_HIP, "lookup_den launch failed");
+}
+int lookup_numerators(cq_ctx* c, const Fr* cin, const Fr* ctab, const Fr& beta, const Fr& gamma, uint32_t n, Fr* inout) {
+  lookup_num_kernel<<<blocks_for(n), 256, 0, c->stream>>>(cin, ctab, beta, gamma, n, inout);
+  return hipGetLastError() == hipSuccess ? CQ_OK : c->fail(CQ_ERR_HIP, "lookup_num launch failed");
+}
+
+// the five lookup constraints of evaluate_h (evaluation.rs:461-531)
+__global__ __launch_bounds__(256) void lookup_h_kernel(LookupHArgs a, Fr* __restrict__ h) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.ext) return;
+  const uint32_t r_next = rot_idx(i, 1, a.rot_scale, a.ext), r_prev = rot_idx(i, -1, a.rot_scale, a.ext);
+  const Fr one = Fr::one();
+  const Fr l0 = ld(a.l0 + i), ll = ld(a.l_last + i), la = ld(a.l_active + i);
+  const Fr z = ld(a.z + i), pa = ld(a.a + i), ps = ld(a.s + i);
+  const Fr table_value = (ld(a.cin + i) + a.beta) * (ld(a.ctab + i) + a.gamma);
+  const Fr a_minus_s = pa - ps;
+  Fr v = ld(h + i);
+  v = v * a.y + (one - z) * l0;                                                      // l_0 (1 - z)
+  v = v * a.y + (z * z - z) * ll;                                                    // l_last (z^2 - z)
+  v = v * a.y + (ld(a.z + r_next) * (pa + a.beta) * (ps + a.gamma) - z * table_value) * la;
+  v = v * a.y + a_minus_s * l0;                                                      // l_0 (a' - s')
+  v = v * a.y + a_minus_s * (pa - ld(a.a + r_prev)) * la;                           // (a' - s')(a' - a'(w^-1 X))
+  st(h + i, v);
+}
+int lookup_h_terms(cq_ctx* c, const LookupHArgs& a, Fr* h) {
+  lookup_h_kernel<<<blocks_for(a.ext), 256, 0, c->stream>>>(a, h);
+  return hipGetLastError() == hipSuccess ? CQ_OK : c->fail(CQ_ERR_HIP, "lookup_h launch failed");
+}
+
+__global__ void fr_to_canonical_kernel(const Fr* __restrict__ in, uint32_t n, uint64_t* __restrict__ out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const U256 c = ld(in + i).to_canonical();
+  uint4* q = reinterpret_cast<uint4*>(out + 4 * (size_t)i);
+  q[0] = make_uint4(c.l[0], c.l[1], c.l[2], c.l[3]);
+  q[1] = make_uint4(c.l[4], c.l[5], c.l[6], c.l[7]);
+}
+__global__ void fr_from_canonical_kernel(const uint64_t* __restrict__ in, uint32_t n, Fr* __restrict__ out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint4* q = reinterpret_cast<const uint4*>(in + 4 * (size_t)i);
+  const uint4 a = q[0], b = q[1];
+  U256 c;
+  c.l[0] = a.x; c.l[1] = a.y; c.l[2] = a.z; c.l[3] = a.w; c.l[4] = b.x; c.l[5] = b.y; c.l[6] = b.z; c.l[7] = b.w;
+  st(out + i, Fr::from_canonical(c));
+}
+int fr_to_canonical(cq_ctx* c, const Fr* in, uint32_t n, uint64_t* out) {
+  if (n) fr_to_canonical_kernel<<<blocks_for(n), 256, 0, c->stream>>>(in, n, out);
+  return hipGetLastError() == hipSuccess ? CQ_OK : c->fail(CQ_ERR_HIP, "to_canonical launch failed");
+}
+int fr_from_canonical(cq_ctx* c, const uint64_t* in, uint32_t n, Fr* out) {
+  if (n) fr_from_canonical_kernel<<<blocks_for(n), 256, 0, c->stream>>>(in, n, out);
+  return hipGetLastError() == hipSuccess ? CQ_OK : c->fail(CQ_ERR_HIP, "from_canonical launch failed");
+}
+
 int perm_h_terms(cq_ctx* c, const PermHArgs& a, Fr* h) {
   perm_h_kernel<<<blocks_for(a.ext), 256, 0, c->stream>>>(a, h);
   return hipGetLastError() == hipSuccess ? CQ_OK : c->fail(CQ_ERR_HIP, "perm_h launch failed");

@@ -62,6 +62,14 @@ struct PermHArgs {
   uint32_t ext, rot_scale, last_rot;  // last_rot = blinding_factors + 1
 };
 
+struct LookupHArgs {
+  const Fr *z, *a, *s;            // product, permuted input, permuted table on the extended coset
+  const Fr *cin, *ctab;           // theta-compressed input / table expressions on the extended coset
+  const Fr *l0, *l_last, *l_active;
+  Fr beta, gamma, y;
+  uint32_t ext, rot_scale;
+};
+
 // checks a gate program blob on the host; returns false with `why` set if malformed
 bool gate_program_check(const uint32_t* lens, const uint32_t* words, uint32_t num_polys, uint32_t num_constants,
                         uint32_t num_advice, uint32_t num_fixed, uint32_t num_instance, const char** why,
@@ -77,5 +85,12 @@ int perm_numerators(cq_ctx* c, const PermProductArgs& a, uint32_t n, Fr* den_inv
 int prefix_product(cq_ctx* c, const Fr* in, Fr* out, uint32_t n, uint32_t batch);
 int perm_scale(cq_ctx* c, Fr* z, uint32_t n, uint32_t rows, uint32_t sets, const PermScaleArgs& a);
 int perm_h_terms(cq_ctx* c, const PermHArgs& a, Fr* h);  // h <- fold of the permutation constraints, in place
+// legacy lookup argument (plonk/lookup/prover.rs:163-300, plonk/evaluation.rs:461-531)
+int lookup_denominators(cq_ctx* c, const Fr* a, const Fr* s, const Fr& beta, const Fr& gamma, uint32_t n, Fr* out);
+int lookup_numerators(cq_ctx* c, const Fr* cin, const Fr* ctab, const Fr& beta, const Fr& gamma, uint32_t n, Fr* inout);
+int lookup_h_terms(cq_ctx* c, const LookupHArgs& a, Fr* h);
+// Montgomery <-> canonical limbs (the host sorts canonical values, derive/field.rs `Ord`)
+int fr_to_canonical(cq_ctx* c, const Fr* in, uint32_t n, uint64_t* out);
+int fr_from_canonical(cq_ctx* c, const uint64_t* in, uint32_t n, Fr* out);
 
 }  // namespace cq

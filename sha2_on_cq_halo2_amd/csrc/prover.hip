@@ -14,6 +14,7 @@
 // every advice / instance polynomial to the extended coset even when no term reads them (a CQ-only
 // circuit); that dead work is skipped.
 #include <algorithm>
+#include <array>
 #include <cstring>
 #include <vector>
 #include "blake2b.hpp"
@@ -234,7 +235,7 @@ struct Arena {
 };
 struct Buffers {
   Fr *adv, *inst_lag, *inst_coeff, *f_lag, *f_coeff, *bpoly, *random_poly, *z, *mv, *cosets, *adv_cosets, *inst_cosets,
-      *z_cosets, *lk_inputs, *h_ext, *h_coeff, *gwc_batch, *gwc_wit, *shplonk, *t_comp, *den, *a_val, *m_fr, *a_scaled;
+      *z_cosets, *lk_inputs, *plk, *plk_cosets, *h_ext, *h_coeff, *gwc_batch, *gwc_wit, *shplonk, *t_comp, *den, *a_val, *m_fr, *a_scaled;
   uint64_t* rng_dev;
   uint32_t *m_counts, *err_dev;
 };
@@ -246,7 +247,8 @@ std::vector<int32_t> opening_rotations(const cq_pk* pk) {
   };
   for (auto& q : pk->advice_queries) seen(q.second);
   for (auto& q : pk->fixed_queries) seen(q.second);
-  if (pk->perm_sets()) seen(1);
+  if (pk->perm_sets() || !pk->legacy.empty()) seen(1);
+  if (!pk->legacy.empty()) seen(-1);
   if (pk->perm_sets() > 1) seen(-(int32_t)(pk->bf + 1));
   return rots;
 }
@@ -273,6 +275,10 @@ void carve(const cq_pk* pk, Arena& ar, Buffers& b) {
   b.inst_cosets = ar.take(general ? I * ext : 0);
   b.z_cosets = ar.take(S * ext);
   b.lk_inputs = ar.take(pk->lookup_exprs ? wsum * n : 0);  // evaluated input expressions of the static lookups
+  // legacy lookups, per lookup: compressed input / table, permuted input / table, product (n each; the last three
+  // become coefficients in place) and the five extended-coset vectors of its quotient terms
+  b.plk = ar.take(pk->legacy.size() * 5 * n);
+  b.plk_cosets = ar.take(pk->legacy.size() * 5 * ext);
   b.h_ext = ar.take(ext);
   b.h_coeff = ar.take(ext);          // n * (degree - 1) coefficients
   const bool shplonk = pk->opener == CQ_OPENER_SHPLONK;
@@ -333,6 +339,53 @@ int eval_many(cq_ctx* c, const std::vector<const Fr*>& ps, const std::vector<uin
   return CQ_OK;
 }
 
+// `permute_expression_pair` (plonk/lookup/prover.rs:400-502) on canonical values (4 x u64, little-endian limbs),
+// first `usable` rows.  The reference sorts with `Ord` on field elements (canonical big-endian comparison) and keeps
+// the unused table values in a BTreeMap; here: one sort of each side and a run-length walk.  Runs on the host.
+struct U256Less {
+  bool operator()(const std::array<uint64_t, 4>& a, const std::array<uint64_t, 4>& b) const {
+    for (int i = 3; i >= 0; i--)
+      if (a[i] != b[i]) return a[i] < b[i];
+    return false;
+  }
+};
+bool permute_expression_pair_host(std::vector<std::array<uint64_t, 4>>& input, std::vector<std::array<uint64_t, 4>>& table) {
+  const size_t usable = input.size();
+  std::sort(input.begin(), input.end(), U256Less());
+  std::vector<std::array<uint64_t, 4>> sorted_table(table);
+  std::sort(sorted_table.begin(), sorted_table.end(), U256Less());
+  // leftover_table_map: distinct values ascending with their multiplicities
+  std::vector<std::array<uint64_t, 4>> keys;
+  std::vector<uint32_t> counts;
+  for (size_t i = 0; i < usable; i++) {
+    if (i == 0 || sorted_table[i] != sorted_table[i - 1]) {
+      keys.push_back(sorted_table[i]);
+      counts.push_back(1);
+    } else {
+      counts.back()++;
+    }
+  }
+  std::vector<std::array<uint64_t, 4>> out(usable, std::array<uint64_t, 4>{0, 0, 0, 0});
+  std::vector<size_t> repeated;
+  for (size_t row = 0; row < usable; row++) {
+    if (row == 0 || input[row] != input[row - 1]) {
+      out[row] = input[row];
+      auto it = std::lower_bound(keys.begin(), keys.end(), input[row], U256Less());
+      if (it == keys.end() || *it != input[row] || counts[it - keys.begin()] == 0) return false;  // Error::ConstraintSystemFailure
+      counts[it - keys.begin()]--;
+    } else {
+      repeated.push_back(row);
+    }
+  }
+  for (size_t kq = 0; kq < keys.size(); kq++)
+    for (uint32_t q = 0; q < counts[kq]; q++) {
+      out[repeated.back()] = keys[kq];
+      repeated.pop_back();
+    }
+  table.swap(out);
+  return repeated.empty();
+}
+
 }  // namespace
 
 size_t prover_arena_elems(const cq_pk* pk) {
@@ -354,6 +407,7 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, const uint64_
   const size_t N = pk->table_cfg ? pk->table_cfg->N : 0;
   const size_t S = pk->perm_sets(), PC = pk->perm_columns.size(), chunk_len = pk->cs_degree - 2;
   const bool general = pk->general();
+  const size_t PL = pk->legacy.size();
   hipStream_t s = c->stream;
   Rng rng{rng_next, rng_state};
   Transcript tr;
@@ -389,7 +443,7 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, const uint64_
   // ---- advice: copy in, blind rows u..n (prover.rs:346-350), one unused blind per column (:352-355) ----
   for (size_t a = 0; a < A; a++)
     CQ_HIP(c, hipMemcpyAsync(adv + a * n, advice_dev[a], (size_t)u * sizeof(Fr), hipMemcpyDeviceToDevice, s));
-  std::vector<Fr> z_tails(S * bf);
+  std::vector<Fr> z_tails(S * bf), plk_tails(PL * 2 * (bf + 1)), plkz_tails(PL * bf);
   uint64_t* rng_pin = nullptr;
   size_t rng_first = 0;
   // second half of the vanishing argument's draws + the blind, upload, and the words -> field elements kernel
@@ -427,19 +481,30 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, const uint64_
     // (vanishing/prover.rs:51-55): the CQ rounds in between draw nothing, so taking them now keeps the
     // stream order, overlaps the host-side draws with the advice MSMs, and lets the random
     // polynomial's commitment ride along with round 2's launch.
+    // legacy lookups, commit_permuted (lookup/prover.rs:491-494, 133-145): bf+1 rows of a', bf+1 rows of s', two blinds
+    for (size_t l = 0; l < PL; l++) {
+      for (uint32_t r = 0; r < 2 * (bf + 1); r++) plk_tails[l * 2 * (bf + 1) + r] = rng.fr();
+      (void)rng.fr();
+      (void)rng.fr();
+    }
     for (size_t st = 0; st < S; st++) {
       for (uint32_t r = 0; r < bf; r++) z_tails[st * bf + r] = rng.fr();
       (void)rng.fr();  // permutation_product_blind
+    }
+    // legacy lookups, commit_product (:237, 283): bf rows of z, one blind
+    for (size_t l = 0; l < PL; l++) {
+      for (uint32_t r = 0; r < bf; r++) plkz_tails[l * bf + r] = rng.fr();
+      (void)rng.fr();
     }
     // Drawing 8n words on the host (2^21 at k = 18) takes longer than the advice MSMs run, so only the first
     // half is drawn here; the second half is drawn while the round-1 commitments are computed (no other draw
     // comes in between).  The uploads ride a side stream so that they overlap the kernels queued on `s`.
     CQ_TRY(c->ensure_copy_stream());
     rng_pin = (uint64_t*)pin;
-    rng_first = L ? 4 * n : 8 * n;
+    rng_first = (L || PL) ? 4 * n : 8 * n;
     rng.fill(rng_pin, rng_first);
     CQ_HIP(c, hipMemcpyAsync(rng_dev, rng_pin, rng_first * sizeof(uint64_t), hipMemcpyHostToDevice, c->copy_stream));
-    if (!L) CQ_TRY(finish_random_poly());
+    if (!L && !PL) CQ_TRY(finish_random_poly());
     // batch_normalize (:363-366), write (:370-374)
     if (A) {
       std::vector<G1Affine> pts;
@@ -451,6 +516,48 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, const uint64_
     }
   }
   const Fr theta = tr.squeeze();  // :472
+
+  // ---- legacy lookups: commit_permuted (lookup/prover.rs:57-160) ---------------------------------------------
+  auto plk_buf = [&](size_t l, int which) { return B.plk + (l * 5 + which) * n; };  // 0 A, 1 S, 2 a', 3 s', 4 z
+  auto lagrange_compress = [&](const uint32_t* prog, uint32_t width, const Fr& chal, Fr* dst) {
+    GateEvalArgs ga;  // `evaluate(expr, n, 1, ..)` of every expression, folded with theta (:98-117)
+    ga.prog = prog;
+    ga.num_polys = width;
+    ga.constants = pk->constants;
+    ga.advice = adv;
+    ga.fixed = pk->fixed_values;
+    ga.instance = B.inst_lag;
+    ga.stride = n;
+    ga.size = (uint32_t)n;
+    ga.rot_scale = 1;
+    ga.y = chal;
+    return gate_eval(c, ga, dst);
+  };
+  if (PL) {
+    void* stage_v;
+    CQ_TRY(c->ensure_scratch(7, (size_t)2 * u * 32 + 64, &stage_v));
+    uint64_t* stage = (uint64_t*)stage_v;
+    std::vector<std::array<uint64_t, 4>> hin(u), htab(u);
+    for (size_t l = 0; l < PL; l++) {
+      const auto& lk = pk->legacy[l];
+      CQ_TRY(lagrange_compress(pk->legacy_prog + lk.in_off, lk.width, theta, plk_buf(l, 0)));
+      CQ_TRY(lagrange_compress(pk->legacy_prog + lk.tab_off, lk.width, theta, plk_buf(l, 1)));
+      // permute_expression_pair (:400-502): canonical values to the host, sorted there, back to Montgomery form
+      CQ_TRY(fr_to_canonical(c, plk_buf(l, 0), u, stage));
+      CQ_TRY(fr_to_canonical(c, plk_buf(l, 1), u, stage + 4 * (size_t)u));
+      CQ_HIP(c, hipMemcpyAsync(hin.data(), stage, (size_t)u * 32, hipMemcpyDeviceToHost, s));
+      CQ_HIP(c, hipMemcpyAsync(htab.data(), stage + 4 * (size_t)u, (size_t)u * 32, hipMemcpyDeviceToHost, s));
+      CQ_HIP(c, hipStreamSynchronize(s));
+      if (!permute_expression_pair_host(hin, htab)) return c->fail(CQ_ERR_LOOKUP, "lookup input not in table (Error::ConstraintSystemFailure)");
+      CQ_HIP(c, hipMemcpyAsync(stage, hin.data(), (size_t)u * 32, hipMemcpyHostToDevice, s));
+      CQ_HIP(c, hipMemcpyAsync(stage + 4 * (size_t)u, htab.data(), (size_t)u * 32, hipMemcpyHostToDevice, s));
+      CQ_TRY(fr_from_canonical(c, stage, u, plk_buf(l, 2)));
+      CQ_TRY(fr_from_canonical(c, stage + 4 * (size_t)u, u, plk_buf(l, 3)));
+      CQ_HIP(c, hipMemcpyAsync(plk_buf(l, 2) + u, plk_tails.data() + l * 2 * (bf + 1), (bf + 1) * sizeof(Fr), hipMemcpyHostToDevice, s));
+      CQ_HIP(c, hipMemcpyAsync(plk_buf(l, 3) + u, plk_tails.data() + l * 2 * (bf + 1) + (bf + 1), (bf + 1) * sizeof(Fr), hipMemcpyHostToDevice, s));
+      CQ_HIP(c, hipStreamSynchronize(s));  // hin / htab are reused by the next lookup
+    }
+  }
 
   // ---- CQ round 1 (static_lookup/prover.rs:51-183) ------------------------------------------------
   if (L) CQ_HIP(c, hipMemsetAsync(m_counts, 0, (L * N + 16) * sizeof(uint32_t), s));
@@ -509,10 +616,15 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, const uint64_
     CQ_HIP(c, hipStreamSynchronize(s));
     if (herr == 1) return c->fail(CQ_ERR_LOOKUP, "witness value not in table");
     if (herr == 2) return c->fail(CQ_ERR_LOOKUP, "Vector lookup must be on the same table row");
-    // f_cm (:165) and m_cm (:167-172, as a dense MSM over the table SRS): one launch
+  }
+  if (L || PL) {
+    // permuted input / table of every legacy lookup (lookup/prover.rs:136-151), then f_cm (:165) and m_cm
+    // (:167-172, as a dense MSM over the table SRS): one launch
     std::vector<const Fr*> sc;
     std::vector<const G1Affine*> bs;
     std::vector<size_t> ln;
+    for (size_t l = 0; l < PL; l++)
+      for (int which = 2; which <= 3; which++) { sc.push_back(plk_buf(l, which)); bs.push_back(pk->params->g_lagrange); ln.push_back(n); }
     for (size_t l = 0; l < L; l++) { sc.push_back(f_lag + l * n); bs.push_back(pk->params->g_lagrange); ln.push_back(n); }
     for (size_t l = 0; l < L; l++) { sc.push_back(m_fr + l * N); bs.push_back(pk->table_cfg->g1_lagrange); ln.push_back(N); }
     std::vector<G1Affine> cm;
@@ -520,9 +632,11 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, const uint64_
     CQ_TRY(r1.begin(pk, sc, bs, ln));
     CQ_TRY(finish_random_poly());  // host draws overlap the MSM kernels just queued
     CQ_TRY(r1.end(cm));
+    for (size_t q = 0; q < 2 * PL; q++)
+      if (!tr.write_point(cm[q])) return c->fail(CQ_ERR_TRANSCRIPT, "permuted lookup commitment is the identity");
     for (size_t l = 0; l < L; l++) {
-      if (!tr.write_point(cm[l])) return c->fail(CQ_ERR_TRANSCRIPT, "f commitment is the identity");
-      if (!tr.write_point(cm[L + l])) return c->fail(CQ_ERR_TRANSCRIPT, "m commitment is the identity");
+      if (!tr.write_point(cm[2 * PL + l])) return c->fail(CQ_ERR_TRANSCRIPT, "f commitment is the identity");
+      if (!tr.write_point(cm[2 * PL + L + l])) return c->fail(CQ_ERR_TRANSCRIPT, "m commitment is the identity");
     }
   }
   const Fr beta = tr.squeeze();   // prover.rs:529
@@ -573,6 +687,19 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, const uint64_
     // blinding rows (:169-171)
     for (size_t st = 0; st < S; st++)
       CQ_HIP(c, hipMemcpyAsync(B.z + st * n + (n - bf), z_tails.data() + st * bf, bf * sizeof(Fr), hipMemcpyHostToDevice, s));
+  }
+
+  // ---- legacy lookups: commit_product (lookup/prover.rs:163-300): z = running product of
+  //      (A + beta)(S + gamma) / ((a' + beta)(s' + gamma)), rows n-bf.. random ---------------------------------------
+  if (PL) {
+    for (size_t l = 0; l < PL; l++) CQ_TRY(lookup_denominators(c, plk_buf(l, 2), plk_buf(l, 3), beta, gamma, (uint32_t)n, plk_buf(l, 4)));
+    for (size_t l = 0; l < PL; l++) {
+      // the product vectors are not contiguous across lookups (stride 5n): one inversion launch each
+      CQ_TRY(poly_batch_invert(c, plk_buf(l, 4), (uint32_t)n));
+      CQ_TRY(lookup_numerators(c, plk_buf(l, 0), plk_buf(l, 1), beta, gamma, (uint32_t)n, plk_buf(l, 4)));
+      CQ_TRY(prefix_product(c, plk_buf(l, 4), plk_buf(l, 4), (uint32_t)n, 1));
+      CQ_HIP(c, hipMemcpyAsync(plk_buf(l, 4) + (n - bf), plkz_tails.data() + l * bf, bf * sizeof(Fr), hipMemcpyHostToDevice, s));
+    }
   }
 
   // ---- CQ round 2 (static_lookup/prover.rs:187-342) -------------------------------------------------
@@ -630,6 +757,7 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, const uint64_
       std::vector<const G1Affine*> bs;
       std::vector<size_t> ln;
       for (size_t st = 0; st < S; st++) { sc.push_back(B.z + st * n); bs.push_back(pk->params->g_lagrange); ln.push_back(n); }
+      for (size_t l = 0; l < PL; l++) { sc.push_back(plk_buf(l, 4)); bs.push_back(pk->params->g_lagrange); ln.push_back(n); }
       woff = 0;
       for (size_t l = 0; l < L; l++) {
         const uint32_t w = (uint32_t)pk->lookups[l].cols.size();
@@ -647,12 +775,17 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, const uint64_
       if (!tr.write_point(r2[st])) return c->fail(CQ_ERR_TRANSCRIPT, "permutation product commitment is the identity");
     // z -> coefficients (permutation/prover.rs:179), in place
     if (S) CQ_TRY(domain_lagrange_to_coeff(dom, B.z, B.z, (uint32_t)S, n, n));
+    for (size_t l = 0; l < PL; l++) {
+      if (!tr.write_point(r2[S + l])) return c->fail(CQ_ERR_TRANSCRIPT, "lookup product commitment is the identity");
+      // a', s', z -> coefficients (lookup/prover.rs:133, 285), in place (three consecutive vectors)
+      CQ_TRY(domain_lagrange_to_coeff(dom, plk_buf(l, 2), plk_buf(l, 2), 3, n, n));
+    }
     for (size_t l = 0; l < L; l++) {
       // write order :306-313: a, q_a, a0, b0, p
       for (size_t q = 0; q < 5; q++)
-        if (!tr.write_point(r2[S + 5 * l + q])) return c->fail(CQ_ERR_TRANSCRIPT, "a CQ round-2 commitment is the identity");
+        if (!tr.write_point(r2[S + PL + 5 * l + q])) return c->fail(CQ_ERR_TRANSCRIPT, "a CQ round-2 commitment is the identity");
     }
-    random_cm = r2[S + 5 * L];
+    random_cm = r2[S + PL + 5 * L];
     // a(0) = (n*b(0) - (bf+1)/beta) / N   (:318-324)
     if (L) {
       std::vector<Fr> b0(L);
@@ -724,6 +857,41 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, const uint64_
         CQ_TRY(perm_h_terms(c, ph, h_ext));
       }
     }
+    for (size_t l = 0; l < PL; l++) {  // legacy lookup constraints (:461-531)
+      const auto& lk = pk->legacy[l];
+      Fr* co = B.plk_cosets + l * 5 * ext;  // a', s', z cosets, then the compressed input / table on the coset
+      CQ_TRY(domain_coeff_to_extended(dom, plk_buf(l, 2), co, 3, n, ext));
+      const uint32_t rot_scale = 1u << (dom->extended_k - dom->k);
+      for (int side = 0; side < 2; side++) {
+        GateEvalArgs ga;
+        ga.prog = pk->legacy_prog + (side ? lk.tab_off : lk.in_off);
+        ga.num_polys = lk.width;
+        ga.constants = pk->constants;
+        ga.advice = B.adv_cosets;
+        ga.fixed = pk->fixed_cosets;
+        ga.instance = B.inst_cosets;
+        ga.stride = ext;
+        ga.size = (uint32_t)ext;
+        ga.rot_scale = rot_scale;
+        ga.y = theta;
+        CQ_TRY(gate_eval(c, ga, co + (3 + side) * ext));
+      }
+      LookupHArgs la;
+      la.a = co;
+      la.s = co + ext;
+      la.z = co + 2 * ext;
+      la.cin = co + 3 * ext;
+      la.ctab = co + 4 * ext;
+      la.l0 = pk->l0;
+      la.l_last = pk->l_last;
+      la.l_active = pk->l_active_row;
+      la.beta = beta;
+      la.gamma = gamma;
+      la.y = y;
+      la.ext = (uint32_t)ext;
+      la.rot_scale = rot_scale;
+      CQ_TRY(lookup_h_terms(c, la, h_ext));
+    }
     if (L) {
       CQ_TRY(domain_coeff_to_extended(dom, bpoly, cosets, (uint32_t)L, n, ext));
       CQ_TRY(domain_coeff_to_extended(dom, f_coeff, cosets + L * ext, (uint32_t)L, n, ext));
@@ -782,6 +950,10 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, const uint64_
     q_z_next.push_back(add_query(B.z + st * n, n, 1));
   }
   for (size_t st = S > 0 ? S - 1 : 0; st-- > 0;) q_z_last[st] = add_query(B.z + st * n, n, rot_last);
+  std::vector<std::array<size_t, 5>> q_plk(PL);  // lookup::Evaluated::open (lookup/prover.rs:343-392): z, a', s' @ x, a' @ x/w, z @ wx
+  for (size_t l = 0; l < PL; l++)
+    q_plk[l] = {add_query(plk_buf(l, 4), n, 0), add_query(plk_buf(l, 2), n, 0), add_query(plk_buf(l, 3), n, 0),
+                add_query(plk_buf(l, 2), n, -1), add_query(plk_buf(l, 4), n, 1)};
   for (size_t l = 0; l < L; l++) {  // static_lookup::Evaluated::open
     q_b0.push_back(add_query(bpoly + l * n + 1, n - 1, 0));  // b0 = (b - b(0))/X
     q_f.push_back(add_query(f_coeff + l * n, n, 0));
@@ -821,6 +993,8 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, const uint64_
     tr.write_scalar(qs[q_z_next[st]].eval);
     if (st + 1 < S) tr.write_scalar(qs[q_z_last[st]].eval);
   }
+  for (size_t l = 0; l < PL; l++)  // lookup::Committed::evaluate (lookup/prover.rs:303-340): z, z(wx), a', a'(x/w), s'
+    for (size_t which : {(size_t)0, (size_t)4, (size_t)1, (size_t)3, (size_t)2}) tr.write_scalar(qs[q_plk[l][which]].eval);
   for (size_t l = 0; l < L; l++) {  // static_lookup/prover.rs:360-370
     tr.write_scalar(qs[q_b0[l]].eval);
     tr.write_scalar(qs[q_f[l]].eval);

@@ -136,6 +136,7 @@ class ConstraintSystem:
         self.permutation_columns = []
         self.static_lookups = []   # [[(advice column index, table)]]
         self._lookup_exprs = []    # the input expression of every (lookup, table column) pair, flattened
+        self.lookups = []          # legacy lookups: [([input expressions], [table expressions])] (plonk/lookup.rs:9-36)
 
     # -- columns (circuit.rs:1903-1960)
     def advice_column(self) -> Column:
@@ -174,6 +175,14 @@ class ConstraintSystem:
         assert polys, "Gates must contain at least one constraint."
         self.gates.extend(polys)
 
+    def lookup(self, name: str, table_map):
+        """`lookup_any` (circuit.rs:1556-1577): [(input Expression, table Expression)] -- the legacy plookup-style
+        argument (plonk/lookup.rs); `lookup` with TableColumns is the same with fixed-column table expressions."""
+        ins, tabs = [i for i, _ in table_map], [t for _, t in table_map]
+        assert ins, "a lookup needs at least one (input, table) pair"
+        self.lookups.append((ins, tabs))
+        return len(self.lookups) - 1
+
     def lookup_static(self, name: str, table_map):
         """circuit.rs:1579-1602: [(input Expression (or a Column, queried at Rotation::cur()), StaticTable)]."""
         row = []
@@ -200,6 +209,8 @@ class ConstraintSystem:
             d = max(d, g.degree())
         for e in self._lookup_exprs:
             d = max(d, 2 + e.degree())
+        for ins, tabs in self.lookups:  # lookup.rs:37-52
+            d = max(d, 4, 2 + max([1] + [e.degree() for e in ins]) + max([1] + [e.degree() for e in tabs]))
         return d
 
     def blinding_factors(self) -> int:

@@ -116,15 +116,16 @@ def chain_circuit(k, degree5=False, with_lookup=False, lookup_expr=False, plooku
                 tables={"t": TABLE} if with_lookup else {})
 
 
-def plonk_api_circuit(k=5):
+def plonk_api_circuit(k=5, legacy_lookup=True):
     """`MyCircuit` of halo2_proofs/tests/plonk_api.rs:270-400 (StandardPlonk: "Combined add-mult" and
-    "Public input" gates, 12 equality-enabled columns, 10 multiply/add pairs with two copies each, public
-    input 2, a = 2834758237 * ZETA :401-405) WITHOUT its legacy `meta.lookup` (:316-319; that argument is not
-    built here).  Column allocation order as in `configure` (:281-298); rows as SimpleFloorPlanner lays the
-    one-row regions out in call order."""
+    "Public input" gates, the legacy `meta.lookup` of column a into the table column sl (:316-319), 12
+    equality-enabled columns, 10 multiply/add pairs with two copies each, public input 2,
+    a = 2834758237 * ZETA, table [2, a, a, 0] :401-413).  Column allocation order as in `configure` (:281-298);
+    rows as SimpleFloorPlanner lays the one-row regions out in call order; the table column is filled with its
+    first value from the first unused row on (`assign_table`, circuit/floor_planner/single_pass.rs:183-217)."""
     n = 1 << k
     e, a, b, c, d = range(5)
-    sf, sm, sa, sb, sc, sp = range(6)
+    sf, sm, sa, sb, sc, sp, sl = range(7)
     A_, F_, I_ = A, F, I
     # queries in registration order: enable_equality(a,b,c); gates; enable_equality(sf,e,d,p,sm,sa,sb,sc,sp)
     gate1 = PL.add(
@@ -136,12 +137,15 @@ def plonk_api_circuit(k=5):
     perm_columns = [(A_, a), (A_, b), (A_, c), (F_, sf), (A_, e), (A_, d), (I_, 0), (F_, sm), (F_, sa), (F_, sb), (F_, sc), (F_, sp)]
     queries = {
         A_: [(a, 0), (b, 0), (c, 0), (d, 1), (e, -1), (e, 0), (d, 0)],
-        F_: [(sf, 0), (sa, 0), (sb, 0), (sc, 0), (sm, 0), (sp, 0)],
+        # `meta.lookup` queries the table column before the gates are created (circuit.rs:1533-1557)
+        F_: ([(sl, 0)] if legacy_lookup else []) + [(sf, 0), (sa, 0), (sb, 0), (sc, 0), (sm, 0), (sp, 0)],
         I_: [(0, 0)],
     }
-    circuit = CP.CqCircuit(k, 5, [], 6, 1, [gate1, gate2], perm_columns, queries)
+    plookups = [([PL.adv(a)], [PL.fix(sl)])] if legacy_lookup else []
+    nfixed = 7 if legacy_lookup else 6
+    circuit = CP.CqCircuit(k, 5, [], nfixed, 1, [gate1, gate2], perm_columns, queries, plookups)
     u = n - (circuit.blinding_factors() + 1)
-    fixed = [[0] * n for _ in range(6)]
+    fixed = [[0] * n for _ in range(nfixed)]
     adv = [[0] * u for _ in range(5)]
     asm = PL.Assembly(n, perm_columns)
     av = 2834758237 * B.FR_ZETA % P
@@ -162,6 +166,10 @@ def plonk_api_circuit(k=5):
         for _twice in range(2):
             asm.copy((A_, b), r2, (A_, c), row)
         row += 2
+    if legacy_lookup:
+        table = [2, av, av, 0]
+        for r in range(u):
+            fixed[sl][r] = table[r] if r < len(table) else table[0]
     return dict(circuit=circuit, fixed=fixed, advice=adv, instances=[[2]], mapping=asm.mapping, tables={})
 
 
@@ -266,6 +274,8 @@ def to_backend_cs(circuit, gtables):
 
     for kind, idx in circuit.perm_columns:
         cs.enable_equality(cols[kind][idx])
+    for li, (ins, tabs) in enumerate(circuit.plookups):
+        cs.lookup(f"pl{li}", [(conv(i), conv(t)) for i, t in zip(ins, tabs)])
     for gi, g in enumerate(circuit.gates):
         cs.create_gate(f"g{gi}", [conv(g)])
     for li, lk in enumerate(circuit.lookups):

@@ -94,12 +94,13 @@ def test_plonk_unsatisfied_witness_is_rejected():
 
 
 def test_plonk_api_shape_verifies():
-    """The reference's general end-to-end circuit (halo2_proofs/tests/plonk_api.rs `MyCircuit`, minus its legacy
-    lookup): 12 permutation columns at degree 3 -> 12 product sets chained through z_i(w^last X), queries at
-    next / cur / prev, public input 2.  As in the reference test, acceptance is the assertion."""
+    """The reference's general end-to-end circuit (halo2_proofs/tests/plonk_api.rs `MyCircuit`): two gates, the
+    legacy lookup of column a into a 4-value table, 12 permutation columns at degree 4 -> 6 product sets chained
+    through z_i(w^last X), queries at next / cur / prev, public input 2.  As in the reference test, acceptance is
+    the assertion."""
     fx = oracle_env(5, builder=plonk_api_circuit)
     cs = fx["circuit"]
-    assert cs.degree() == 3 and cs.blinding_factors() == 5
+    assert cs.degree() == 4 and cs.blinding_factors() == 5
     tr = CP.create_proof(fx["params"], fx["pk"], fx["advice"], B.Xoshiro256ss(3), instances=fx["instances"])
     assert _verify(fx, tr.proof)
     assert not _verify(fx, tr.proof, [[3]])  # wrong public input (plonk_api.rs:495-520 expects a failure too)

@@ -36,8 +36,9 @@ def _advice_cols(fx, n):
     return [B.to_mont_limbs(list(c) + [0] * (n - len(c))) for c in fx["advice"]]
 
 
-@pytest.mark.parametrize("kw", [dict(), dict(degree5=True), dict(with_lookup=True), dict(lookup_expr=True)],
-                         ids=["deg3", "deg5", "lookup", "lookup-expr"])
+@pytest.mark.parametrize("kw", [dict(), dict(degree5=True), dict(with_lookup=True), dict(lookup_expr=True), dict(plookup=True),
+                                dict(plookup=True, with_lookup=True, degree5=True)],
+                         ids=["deg3", "deg5", "lookup", "lookup-expr", "plookup", "plookup+cq+deg5"])
 def test_plonk_proof_bytes_match_oracle(ctx, kw):
     k = 5
     n = 1 << k
@@ -68,7 +69,7 @@ def test_plonk_proof_bytes_match_oracle_k11(ctx, opener):
 
 
 def test_plonk_api_shape_proof_bytes(ctx):
-    """halo2_proofs/tests/plonk_api.rs `MyCircuit` without its legacy lookup: 12 chained product sets."""
+    """halo2_proofs/tests/plonk_api.rs `MyCircuit`, legacy lookup included: 6 chained product sets at degree 4."""
     k = 5
     fx = oracle_env(k, builder=plonk_api_circuit)
     gpk, _ = _backend_pk(ctx, fx, k, fx["s"])
@@ -176,3 +177,20 @@ def test_proving_key_raw_bytes_roundtrip(ctx, kw):
     ProvingKey(ctx, gparams, k, 0, [], gcfg, b0_arg, B.to_mont_limbs([424242])[0], cs=cs, raw=bytes(bad), num_selectors=2, checked=False)
     with pytest.raises(CqError):
         ProvingKey(ctx, gparams, k, 0, [], gcfg, b0_arg, B.to_mont_limbs([424242])[0], cs=cs, raw=want[:-5], num_selectors=2)
+
+
+def test_legacy_lookup_failure_is_an_error(ctx):
+    """An input that is not a table row: Error::ConstraintSystemFailure (lookup/prover.rs:431-437)."""
+    from sha2_on_cq_halo2_amd import CqError
+
+    k = 5
+    fx = oracle_env(k, plookup=True)
+    gpk, _ = _backend_pk(ctx, fx, k, fx["s"])
+    adv = [list(c) for c in fx["advice"]]
+    adv[3][0] = 4  # (4, 9) is not in the table
+    cols = [B.to_mont_limbs(list(c) + [0] * ((1 << k) - len(c))) for c in adv]
+    with pytest.raises(CqError) as e:
+        gpk.create_proof(cols, seed=1, instances=[B.to_mont_limbs(i) for i in fx["instances"]])
+    assert e.value.code == -4
+    with pytest.raises(ValueError):
+        CP.create_proof(fx["params"], fx["pk"], adv, B.Xoshiro256ss(1), instances=fx["instances"])
