@@ -453,6 +453,14 @@ static int pk_create_impl(cq_ctx* c, cq_params* params, const cq_circuit* cs, cq
         hipMalloc(&pk->perm_polys, PC * n * sizeof(Fr)) != hipSuccess || hipMalloc(&pk->perm_cosets, PC * ext * sizeof(Fr)) != hipSuccess)
       return pk_abort(pk, c->fail(CQ_ERR_HIP, "hipMalloc(permutation key)"));
     if ((rc = fr_powers(c, pk->domain->omega, (uint32_t)n, pk->omega_powers)) != CQ_OK) return pk_abort(pk, rc);
+    {
+      const size_t hi = std::max<size_t>(ext / 256, 1);
+      if (hipMalloc(&pk->ext_pow_lo, 256 * sizeof(Fr)) != hipSuccess || hipMalloc(&pk->ext_pow_hi, hi * sizeof(Fr)) != hipSuccess)
+        return pk_abort(pk, c->fail(CQ_ERR_HIP, "hipMalloc(extended omega powers)"));
+      if ((rc = fr_powers(c, pk->domain->extended_omega, 256, pk->ext_pow_lo)) != CQ_OK ||
+          (rc = fr_powers(c, pk->domain->extended_omega.pow_u64(256), (uint32_t)hi, pk->ext_pow_hi)) != CQ_OK)
+        return pk_abort(pk, rc);
+    }
     if (raw) {  // permutation::ProvingKey::read (permutation.rs:124-134)
       if ((rc = read_slice(pk->perm_values, PC, n)) != CQ_OK || (rc = read_slice(pk->perm_polys, PC, n)) != CQ_OK ||
           (rc = read_slice(pk->perm_cosets, PC, ext)) != CQ_OK)
@@ -628,7 +636,7 @@ void cq_pk_destroy(cq_pk* pk) {
   if (pk->l_active_row) hipFree(pk->l_active_row);
   for (void* p : {(void*)pk->fixed_values, (void*)pk->fixed_polys, (void*)pk->fixed_cosets, (void*)pk->l0, (void*)pk->l_last,
                   (void*)pk->gate_prog, (void*)pk->constants, (void*)pk->lookup_prog, (void*)pk->legacy_prog, (void*)pk->perm_values, (void*)pk->perm_polys, (void*)pk->perm_cosets,
-                  (void*)pk->omega_powers})
+                  (void*)pk->omega_powers, (void*)pk->ext_pow_lo, (void*)pk->ext_pow_hi})
     if (p) hipFree(p);
   if (pk->b0_g1_bound) msm_unregister_tables(pk->ctx, pk->b0_g1_bound);
   if (pk->own_b0 && pk->b0_g1_bound) hipFree(pk->b0_g1_bound);

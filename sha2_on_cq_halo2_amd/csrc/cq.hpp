@@ -114,6 +114,8 @@ struct cq_pk {
   cq::Fr* perm_polys = nullptr;     // columns x n   (::polys)
   cq::Fr* perm_cosets = nullptr;    // columns x ext (::cosets)
   cq::Fr* omega_powers = nullptr;   // omega^i, i < n
+  cq::Fr* ext_pow_lo = nullptr;     // extended_omega^t, t < 256
+  cq::Fr* ext_pow_hi = nullptr;     // extended_omega^(256 b), b < max(ext / 256, 1)
   int opener = CQ_OPENER_GWC;
   bool general() const { return num_gate_polys || !perm_columns.empty() || !legacy.empty(); }
   size_t perm_sets() const {

@@ -317,7 +317,7 @@ __global__ __launch_bounds__(256) void perm_h_kernel(PermHArgs a, Fr* __restrict
   }
   for (uint32_t s = 1; s < a.sets; s++)  // l_0(X) (z_i(X) - z_{i-1}(omega^last X))
     v = v * a.y + (ld(a.z + (size_t)s * a.ext + i) - ld(a.z + (size_t)(s - 1) * a.ext + r_last)) * l0;
-  Fr current_delta = a.delta_start * a.extended_omega.pow_u64(i);
+  Fr current_delta = a.delta_start * (ld(a.ext_pow_hi + (i >> 8)) * ld(a.ext_pow_lo + (i & 255)));  // beta zeta omega_ext^i
   uint32_t ci = 0;
   for (uint32_t s = 0; s < a.sets; s++) {
     const Fr* zs = a.z + (size_t)s * a.ext;

@@ -58,7 +58,8 @@ struct PermHArgs {
   const Fr* col[PERM_MAX_COLUMNS];  // value cosets per permutation column
   uint32_t sets, chunk_len, ncols;
   const Fr *l0, *l_last, *l_active;
-  Fr beta, gamma, y, delta_start, extended_omega, delta;
+  Fr beta, gamma, y, delta_start, delta;
+  const Fr *ext_pow_lo, *ext_pow_hi;  // extended_omega^t (t < 256) and extended_omega^(256 b): omega_ext^i from two loads
   uint32_t ext, rot_scale, last_rot;  // last_rot = blinding_factors + 1
 };
 

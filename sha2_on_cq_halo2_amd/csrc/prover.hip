@@ -849,7 +849,8 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, const uint64_
         ph.gamma = gamma;
         ph.y = y;
         ph.delta_start = beta * dom->g_coset;  // beta * ZETA (:375)
-        ph.extended_omega = dom->extended_omega;
+        ph.ext_pow_lo = pk->ext_pow_lo;
+        ph.ext_pow_hi = pk->ext_pow_hi;
         ph.delta = fr_from_raw(FR_DELTA_RAW);
         ph.ext = (uint32_t)ext;
         ph.rot_scale = rot_scale;
