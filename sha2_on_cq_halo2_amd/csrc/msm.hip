@@ -36,35 +36,6 @@
 
 namespace cq {
 
-// ---- wave-aggregated atomic increment ----------------------------------------------------------
-// Returns the value of counters[key] before this lane's increment (unique per lane), issuing one
-// atomic per DISTINCT hot key for the first few keys of the wave; same-address atomics serialise
-// in L2 (~20 ns each on MI355X), which is what skewed digit distributions would otherwise pay.
-static __device__ __forceinline__ uint32_t wave_atomic_inc(uint32_t* counters, uint32_t key, bool active) {
-  uint32_t result = 0;
-  bool pending = active;
-#pragma unroll 1
-  for (int round = 0; round < 3; round++) {
-    const unsigned long long pend = __ballot(pending);
-    if (!pend) return result;
-    const int leader = __ffsll((long long)pend) - 1;
-    const uint32_t lkey = __shfl(key, leader, 64);
-    const bool mine = pending && key == lkey;
-    const unsigned long long grp = __ballot(mine);
-    const uint32_t cntg = __popcll(grp);
-    uint32_t base = 0;
-    if ((int)(threadIdx.x & 63) == leader) base = atomicAdd(&counters[lkey], cntg);
-    base = __shfl(base, leader, 64);
-    if (mine) {
-      const unsigned long long below = grp & ((1ull << (threadIdx.x & 63)) - 1ull);
-      result = base + __popcll(below);
-      pending = false;
-    }
-  }
-  if (pending) result = atomicAdd(&counters[key], 1u);
-  return result;
-}
-
 // ---- pointer tables (per-MSM scalar / base arrays), written from a by-value kernel argument ------
 __global__ void msm_set_ptrs_kernel(MsmPtrs sc, MsmPtrs bs, MsmStrides st, MsmStrides ln, const void** dst, uint32_t batch) {
   const uint32_t t = threadIdx.x;
@@ -352,17 +323,6 @@ __global__ __launch_bounds__(256) void msm_scatter_kernel(const Fr* const* __res
 }
 
 // ---- 4. bucket accumulation ----------------------------------------------------------------
-static __device__ __forceinline__ G1Affine load_affine(const G1Affine* p) {
-  const uint4* q = reinterpret_cast<const uint4*>(p);
-  uint4 a = q[0], b = q[1], c = q[2], d = q[3];
-  G1Affine r;
-  r.x.v.l[0] = a.x; r.x.v.l[1] = a.y; r.x.v.l[2] = a.z; r.x.v.l[3] = a.w;
-  r.x.v.l[4] = b.x; r.x.v.l[5] = b.y; r.x.v.l[6] = b.z; r.x.v.l[7] = b.w;
-  r.y.v.l[0] = c.x; r.y.v.l[1] = c.y; r.y.v.l[2] = c.z; r.y.v.l[3] = c.w;
-  r.y.v.l[4] = d.x; r.y.v.l[5] = d.y; r.y.v.l[6] = d.z; r.y.v.l[7] = d.w;
-  return r;
-}
-
 // largest g in [0,B) with off[g] <= j   (off is non-decreasing, off[0] = 0, j < off[B])
 static __device__ __forceinline__ uint32_t owner_of(const uint32_t* __restrict__ off, uint32_t B, uint32_t j) {
   uint32_t lo = 0, hi = B;  // invariant: off[lo] <= j < off[hi]
