@@ -287,3 +287,69 @@ def to_backend_cs(circuit, gtables):
     assert cs.instance_queries == circuit.instance_queries()
     assert cs.degree() == circuit.degree() and cs.blinding_factors() == circuit.blinding_factors()
     return cs
+
+
+def random_circuit(k, seed):
+    """A random constraint system with a random (unsatisfying) witness: `create_proof` never checks satisfaction, so
+    oracle and backend must still agree byte for byte -- a fuzz of the expression interpreter, query bookkeeping,
+    rotation handling, permutation chunking and opening-point grouping.  Lookups use inputs that are in their tables
+    by construction (legacy: table expression == input expression; static: a column filled from TABLE)."""
+    rng = B.Xoshiro256ss(0xF00D + seed)
+    rnd = lambda m: rng.next_u64() % m
+    n = 1 << k
+    num_advice, num_fixed, num_instance = 2 + rnd(3), 1 + rnd(3), rnd(2)
+    static_col = None
+    if rnd(2):
+        static_col = num_advice
+        num_advice += 1
+
+    def leaf():
+        t = rnd(10)
+        if t < 5:
+            return PL.adv(rnd(num_advice if static_col is None else num_advice - 1), rnd(5) - 2)
+        if t < 8:
+            return PL.fix(rnd(num_fixed), rnd(3) - 1)
+        if t < 9 and num_instance:
+            return PL.inst(0, rnd(2))
+        return PL.const(rnd(1 << 20))
+
+    def expr(depth, max_deg):
+        if depth == 0 or rnd(4) == 0:
+            return leaf()
+        t = rnd(6)
+        if t == 0:
+            return PL.neg(expr(depth - 1, max_deg))
+        if t == 1:
+            return PL.scale(expr(depth - 1, max_deg), rng.next_u64())
+        if t in (2, 3):
+            return PL.add(expr(depth - 1, max_deg), expr(depth - 1, max_deg))
+        a_ = expr(depth - 1, max_deg)
+        da = PL.expr_degree(a_)
+        if da >= max_deg:
+            return a_
+        b_ = expr(depth - 1, max_deg - da)
+        return PL.mul(a_, b_) if PL.expr_degree(b_) <= max_deg - da else PL.add(a_, b_)
+
+    gates = [expr(3, 4) for _ in range(1 + rnd(3))]
+    cols_all = [(A, i) for i in range(num_advice if static_col is None else num_advice - 1)] + [(F, i) for i in range(num_fixed)] + \
+               [(I, i) for i in range(num_instance)]
+    perm_columns = [c for c in cols_all if rnd(2)][:5]
+    plookups = []
+    if rnd(2):
+        e1, e2 = expr(2, 2), expr(1, 1)
+        plookups = [([e1, e2], [e1, e2])]
+    lookups = [[(static_col, "t")]] if static_col is not None else []
+    circuit = CP.CqCircuit(k, num_advice, lookups, num_fixed, num_instance, gates, perm_columns, None, plookups)
+    # keep at most two distinct rotations per advice column modest: blinding_factors must leave usable rows
+    u = n - (circuit.blinding_factors() + 1)
+    assert u >= 4
+    fixed = [[B.fr_random(rng) for _ in range(n)] for _ in range(num_fixed)]
+    adv = [[B.fr_random(rng) for _ in range(u)] for _ in range(num_advice)]
+    if static_col is not None:
+        adv[static_col] = [TABLE[rnd(len(TABLE))] for _ in range(u)]
+    instances = [[B.fr_random(rng) for _ in range(1 + rnd(3))] for _ in range(num_instance)]
+    asm = PL.Assembly(n, perm_columns)
+    for _ in range(rnd(12) if perm_columns else 0):
+        asm.copy(perm_columns[rnd(len(perm_columns))], rnd(u), perm_columns[rnd(len(perm_columns))], rnd(u))
+    return dict(circuit=circuit, fixed=fixed, advice=adv, instances=instances, mapping=asm.mapping,
+                tables={"t": TABLE} if static_col is not None else {})

@@ -194,3 +194,21 @@ def test_legacy_lookup_failure_is_an_error(ctx):
     assert e.value.code == -4
     with pytest.raises(ValueError):
         CP.create_proof(fx["params"], fx["pk"], adv, B.Xoshiro256ss(1), instances=fx["instances"])
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_circuits_proof_bytes_match_oracle(ctx, seed):
+    """Fuzz: random gates (random expression trees, rotations in [-2, 2]), random column mix, random copy
+    constraints, optional legacy / static lookups, random witness (constraints NOT satisfied -- the prover never
+    checks them): the bytes must still agree, for both multi-open schemes."""
+    from tests.plonk_fixtures import random_circuit
+
+    k = 5
+    fx = oracle_env(k, builder=random_circuit, seed=seed)
+    gpk, _ = _backend_pk(ctx, fx, k, fx["s"], b0=fx["pk"].b0_g1_bound)
+    cols = _advice_cols(fx, 1 << k)
+    inst = [B.to_mont_limbs(i) for i in fx["instances"]]
+    for opener in ("gwc", "shplonk"):
+        gpk.set_opener(opener)
+        tr = CP.create_proof(fx["params"], fx["pk"], fx["advice"], B.Xoshiro256ss(100 + seed), instances=fx["instances"], opener=opener)
+        assert gpk.create_proof(cols, seed=100 + seed, instances=inst) == tr.proof, (seed, opener)
