@@ -204,6 +204,7 @@ int cq_static_table_download_qs(cq_static_table* table, uint64_t* qs_affine);
 #define CQ_GATE_ADD 5u
 #define CQ_GATE_MUL 6u
 #define CQ_GATE_SCALE 7u
+#define CQ_GATE_CHALLENGE 8u /* pushes user challenge `arg` (Expression::Challenge, circuit.rs:793-794) */
 /* column kinds (`Any`, plonk/circuit.rs:141-160) */
 #define CQ_COL_ADVICE 0u
 #define CQ_COL_FIXED 1u
@@ -254,6 +255,13 @@ typedef struct {
   const uint32_t* legacy_lookup_widths;
   const uint32_t* legacy_program_lens;
   const uint32_t* legacy_programs;
+  /* Phases (circuit.rs `advice_column_phase`, `challenge_phase`; prover.rs:392-464): advice column c is committed in
+   * phase advice_column_phases[c] (NULL = everything in the first phase); user challenge i is squeezed after the
+   * commitments of phase challenge_phases[i].  Circuits with more than one phase are proven with
+   * cq_create_proof_phases. */
+  const uint8_t* advice_column_phases;
+  uint32_t num_challenges;
+  const uint8_t* challenge_phases;
 } cq_plonk;
 
 /* Shape of the constraint system (stands in for ConstraintSystem, plonk/circuit.rs):
@@ -333,6 +341,16 @@ int cq_create_proof_host(cq_pk* pk, const uint64_t* const* advice, cq_rng_next_u
 int cq_create_proof_instances(cq_pk* pk, const uint64_t* const* advice, int advice_on_device,
                               const uint64_t* const* instances, const size_t* instance_lens, cq_rng_next_u64 rng,
                               void* rng_state, uint8_t* proof, size_t proof_cap, size_t* proof_len);
+/* Multi-phase circuits: the witness of phase p > 0 depends on the challenges squeezed after the commitments of the
+ * earlier phases (`WitnessCollection::next_phase`, prover.rs:299-391; the synthesis loop :436-463).  Before it
+ * commits the columns of phase p the library calls `phase_fn(user, p, challenges, advice_dev)`: `challenges` holds
+ * num_challenges x 4 limbs (those of later phases are zero), and the callback fills the phase-p advice columns
+ * (device memory, rows [0, usable_rows)) -- it stands in for re-running `FloorPlanner::synthesize` with
+ * `current_phase = p`.  A non-zero return aborts the proof (CQ_ERR_ARG). */
+typedef int (*cq_phase_fn)(void* user, uint32_t phase, const uint64_t* challenges, uint64_t* const* advice_dev);
+int cq_create_proof_phases(cq_pk* pk, uint64_t* const* advice_dev, const uint64_t* const* instances,
+                           const size_t* instance_lens, cq_phase_fn phase_fn, void* phase_user, cq_rng_next_u64 rng,
+                           void* rng_state, uint8_t* proof, size_t proof_cap, size_t* proof_len);
 /* The verifying-key commitments the prover's key implies: commit_lagrange of every fixed column
  * (keygen.rs:247-250) and of every permutation polynomial (permutation/keygen.rs:115-149), as affine
  * points (num_fixed x 8 and num_perm_columns x 8 words). */

@@ -96,6 +96,16 @@ class CqCircuit:
     queries: dict = None
     # legacy (plookup-style) lookups, `cs.lookups`: [(input expressions, table expressions)] (plonk/lookup.rs:9-36)
     plookups: list = field(default_factory=list)
+    # phases (circuit.rs `advice_column_phase` / `challenge_phase`): advice column c is committed in phase
+    # advice_phases[c] (default: all 0); user challenge i is squeezed after the commitments of challenge_phases[i]
+    advice_phases: list = None
+    challenge_phases: list = field(default_factory=list)
+
+    def phase_of(self, col):
+        return self.advice_phases[col] if self.advice_phases else 0
+
+    def num_phases(self):
+        return 1 + max([self.phase_of(c) for c in range(self.num_advice)] + list(self.challenge_phases) + [0])
 
     def _all_queries(self):
         if self.queries is not None:
@@ -218,7 +228,9 @@ def create_proof(params, pk: ProvingKey, advice_usable, rng, msm=None, instances
     """plonk/prover.rs:51-779 for a single circuit (ProverGWC: QUERY_INSTANCE = false).
 
     `advice_usable[c]` = the assigned values of advice column c on rows 0..u (shorter
-    lists are zero-padded: unassigned cells are zero, prover.rs:424).
+    lists are zero-padded: unassigned cells are zero, prover.rs:424); for a column of a later phase
+    it may be a callable `f(challenges) -> values`, evaluated when that phase starts (the witness of
+    a later phase depends on the challenges of the earlier ones, prover.rs:436-463).
     `msm(coeffs, bases) -> Jacobian` lets tests swap in a faster multiexp.
     """
     msm = msm or best_multiexp
@@ -247,21 +259,31 @@ def create_proof(params, pk: ProvingKey, advice_usable, rng, msm=None, instances
         for v in vals:
             tr.common_scalar(v % P)
 
-    # ---- phase 0 advice (prover.rs:299-391) ---------------------------------
-    advice = []
-    for c in range(cs.num_advice):
-        col = list(advice_usable[c]) + [0] * (u - len(advice_usable[c]))
-        assert len(col) == u, "advice assigned outside usable rows"
-        advice.append([v % P for v in col] + [0] * (n - u))
-    for c in range(cs.num_advice):  # :346-350
-        for r in range(u, n):
-            advice[c][r] = fr_random(rng)
-    for c in range(cs.num_advice):  # :352-355 (blinds drawn, unused by KZG)
-        fr_random(rng)
-    adv_cm = batch_to_affine([msm(advice[c], params.g_lagrange) for c in range(cs.num_advice)])
-    for A in adv_cm:
-        tr.write_point(A)
+    # ---- advice, phase by phase (prover.rs:299-391, 436-463) ----------------------
+    advice = [None] * cs.num_advice
+    adv_cm = [None] * cs.num_advice
+    challenges = [None] * len(cs.challenge_phases)
+    for phase in range(cs.num_phases()):
+        cols = [c for c in range(cs.num_advice) if cs.phase_of(c) == phase]
+        for c in cols:
+            vals = advice_usable[c](list(challenges)) if callable(advice_usable[c]) else advice_usable[c]
+            col = list(vals) + [0] * (u - len(vals))
+            assert len(col) == u, "advice assigned outside usable rows"
+            advice[c] = [v % P for v in col] + [0] * (n - u)
+        for c in cols:  # :346-350
+            for r in range(u, n):
+                advice[c][r] = fr_random(rng)
+        for c in cols:  # :352-355 (blinds drawn, unused by KZG)
+            fr_random(rng)
+        cms = batch_to_affine([msm(advice[c], params.g_lagrange) for c in cols])
+        for c, A in zip(cols, cms):
+            tr.write_point(A)
+            adv_cm[c] = A
+        for i, ph in enumerate(cs.challenge_phases):  # :383-389
+            if ph == phase:
+                challenges[i] = tr.squeeze_challenge_scalar()
     out.points["advice"] = adv_cm
+    out.challenges["user"] = list(challenges)
 
     theta = tr.squeeze_challenge_scalar()  # :472
     out.challenges["theta"] = theta
@@ -272,7 +294,7 @@ def create_proof(params, pk: ProvingKey, advice_usable, rng, msm=None, instances
     def compress_lagrange(exprs):  # `evaluate(expr, n, 1, ..)` folded with theta (:98-117)
         acc = [0] * n
         for e in exprs:
-            vals = [expr_eval(e, lambda kind, c_, rot, row=row: cols_now[kind][c_][rotation_idx(row, rot, 1, n)]) for row in range(n)]
+            vals = [expr_eval(e, lambda kind, c_, rot, row=row: cols_now[kind][c_][rotation_idx(row, rot, 1, n)], challenges) for row in range(n)]
             acc = [(a * theta + b) % P for a, b in zip(acc, vals)]
         return acc
 
@@ -297,7 +319,7 @@ def create_proof(params, pk: ProvingKey, advice_usable, rng, msm=None, instances
         exprs = []
         for col, _ in lk:  # `evaluate(expression, n, 1, ...)` (:91-107, evaluation.rs:776-818)
             e = _lookup_input(col)
-            exprs.append([expr_eval(e, lambda kind, c, rot, row=row: cols_now[kind][c][rotation_idx(row, rot, 1, n)])
+            exprs.append([expr_eval(e, lambda kind, c, rot, row=row: cols_now[kind][c][rotation_idx(row, rot, 1, n)], challenges)
                           for row in range(n)])
         f = [0] * n
         for e in exprs:  # :108-116
@@ -421,7 +443,7 @@ def create_proof(params, pk: ProvingKey, advice_usable, rng, msm=None, instances
             get = lambda kind, col, rot: src[kind][col][rotation_idx(idx, rot, rot_scale, ext)]
             v = h[idx]
             for g in cs.gates:
-                v = (v * y + expr_eval(g, get)) % P
+                v = (v * y + expr_eval(g, get, challenges)) % P
             h[idx] = v
         z_cosets = [dom.coeff_to_extended(z) for z in perm_sets]
         h = permutation_h_terms(dom, cs.degree(), bf, cs.perm_columns, lambda col: src[col[0]][col[1]], pk.perm_cosets,
@@ -430,7 +452,7 @@ def create_proof(params, pk: ProvingKey, advice_usable, rng, msm=None, instances
         def compress_coset(exprs):
             acc = [0] * ext
             for e in exprs:
-                vals = [expr_eval(e, lambda kind, c_, rot, idx=idx: src[kind][c_][rotation_idx(idx, rot, rot_scale, ext)]) for idx in range(ext)]
+                vals = [expr_eval(e, lambda kind, c_, rot, idx=idx: src[kind][c_][rotation_idx(idx, rot, rot_scale, ext)], challenges) for idx in range(ext)]
                 acc = [(a * theta + b) % P for a, b in zip(acc, vals)]
             return acc
         tv = [((a + beta) % P) * ((b + gamma) % P) % P for a, b in zip(compress_coset(ins), compress_coset(tabs))]

@@ -141,7 +141,15 @@ def verify_proof(proof: bytes, circuit, vk_repr: int, s: int, tables: dict, tabl
     for vals in instances:  # verifier.rs:93-101
         for v_ in vals:
             tr.common_scalar(v_ % P)
-    advice_cm = [tr.read_point() for _ in range(cs.num_advice)]
+    advice_cm = [None] * cs.num_advice
+    challenges = [None] * len(cs.challenge_phases)
+    for phase in range(cs.num_phases()):  # verifier.rs:108-131
+        for c_ in range(cs.num_advice):
+            if cs.phase_of(c_) == phase:
+                advice_cm[c_] = tr.read_point()
+        for i_, ph in enumerate(cs.challenge_phases):
+            if ph == phase:
+                challenges[i_] = tr.squeeze()
     theta = tr.squeeze()
     plk_perm = [(tr.read_point(), tr.read_point()) for _ in cs.plookups]  # lookup/verifier.rs:39-52
     lk1 = [(tr.read_point(), tr.read_point()) for _ in cs.lookups]  # f, m
@@ -206,7 +214,7 @@ def verify_proof(proof: bytes, circuit, vk_repr: int, s: int, tables: dict, tabl
     # expressions (static_lookup/verifier.rs:182-221), folded by y (vanishing/verifier.rs:105-106)
     h_eval = 0
     for g in cs.gates:  # verifier.rs:300-323
-        h_eval = (h_eval * y + expr_eval(g, query_eval)) % P
+        h_eval = (h_eval * y + expr_eval(g, query_eval, challenges)) % P
     if n_sets:  # permutation/verifier.rs:108-206
         exprs = [l_0 * (1 - perm_evals[0][0]) % P,
                  (perm_evals[-1][0] * perm_evals[-1][0] - perm_evals[-1][0]) * l_last % P]
@@ -230,7 +238,7 @@ def verify_proof(proof: bytes, circuit, vk_repr: int, s: int, tables: dict, tabl
         def compress(exprs):
             acc = 0
             for e in exprs:
-                acc = (acc * theta + expr_eval(e, query_eval)) % P
+                acc = (acc * theta + expr_eval(e, query_eval, challenges)) % P
             return acc
         left = zn * ((ae + beta) % P) % P * ((se + gamma) % P) % P
         right = ze * ((compress(ins) + beta) % P) % P * ((compress(tabs) + gamma) % P) % P

@@ -42,6 +42,11 @@ def inst(col, rot=0):
     return (INSTANCE, col, rot)
 
 
+def chal(idx):
+    """`Expression::Challenge` (circuit.rs:793-794): the idx-th user challenge of the constraint system."""
+    return ("challenge", idx)
+
+
 def neg(a):
     return ("neg", a)
 
@@ -66,7 +71,7 @@ def scale(a, v):
 def expr_degree(e) -> int:
     """circuit.rs:1040-1056."""
     t = e[0]
-    if t == "const":
+    if t in ("const", "challenge"):
         return 0
     if t in (ADVICE, FIXED, INSTANCE):
         return 1
@@ -92,21 +97,24 @@ def expr_queries(e, out):
         expr_queries(e[2], out)
 
 
-def expr_eval(e, get):
-    """`Expression::evaluate` (circuit.rs:880-960); `get(kind, col, rot)` resolves a query."""
+def expr_eval(e, get, challenges=()):
+    """`Expression::evaluate` (circuit.rs:880-960); `get(kind, col, rot)` resolves a query, `challenges` the
+    user challenges squeezed so far."""
     t = e[0]
     if t == "const":
         return e[1]
+    if t == "challenge":
+        return challenges[e[1]]
     if t in (ADVICE, FIXED, INSTANCE):
         return get(t, e[1], e[2])
     if t == "neg":
-        return (-expr_eval(e[1], get)) % P
+        return (-expr_eval(e[1], get, challenges)) % P
     if t == "add":
-        return (expr_eval(e[1], get) + expr_eval(e[2], get)) % P
+        return (expr_eval(e[1], get, challenges) + expr_eval(e[2], get, challenges)) % P
     if t == "mul":
-        return expr_eval(e[1], get) * expr_eval(e[2], get) % P
+        return expr_eval(e[1], get, challenges) * expr_eval(e[2], get, challenges) % P
     if t == "scale":
-        return expr_eval(e[1], get) * e[2] % P
+        return expr_eval(e[1], get, challenges) * e[2] % P
     raise ValueError(t)
 
 

@@ -468,6 +468,9 @@ class _CqPlonk(C.Structure):
         ("legacy_lookup_widths", C.POINTER(C.c_uint32)),
         ("legacy_program_lens", C.POINTER(C.c_uint32)),
         ("legacy_programs", C.POINTER(C.c_uint32)),
+        ("advice_column_phases", C.POINTER(C.c_uint8)),
+        ("num_challenges", C.c_uint32),
+        ("challenge_phases", C.POINTER(C.c_uint8)),
     ]
 
 
@@ -535,6 +538,12 @@ def _lower_plonk(cs, fixed, mapping, keep: list, from_raw: bool = False) -> _CqP
                 pwords += prog
         pl.num_legacy_lookups = len(widths)
         pl.legacy_lookup_widths, pl.legacy_program_lens, pl.legacy_programs = u32(widths), u32(plens), u32(pwords)
+    if any(cs.advice_column_phase) or cs.challenge_phase:
+        ap = (C.c_uint8 * max(cs.num_advice_columns, 1))(*cs.advice_column_phase)
+        cp = (C.c_uint8 * max(len(cs.challenge_phase), 1))(*cs.challenge_phase)
+        keep += [ap, cp]
+        pl.advice_column_phases = C.cast(ap, C.POINTER(C.c_uint8))
+        pl.num_challenges, pl.challenge_phases = len(cs.challenge_phase), C.cast(cp, C.POINTER(C.c_uint8))
     cst = np.zeros((max(len(constants), 1), 4), dtype=np.uint64)
     for i, v in enumerate(constants):
         cst[i] = fr_to_mont(v)
@@ -672,6 +681,37 @@ class ProvingKey(_Handle):
         assert len(cols) == self.num_advice and all(c.shape == (1 << self.k, 4) for c in cols)
         fn, st = self._rng(rng_words, seed)
         return self._run(self.ctx.lib.cq_create_proof_host, [c.ctypes.data for c in cols], fn, st, instances)
+
+    def create_proof_phases(self, advice_bufs, phase_fn, rng_words=None, seed=None, instances=None) -> bytes:
+        """Multi-phase circuits (prover.rs:436-463): `advice_bufs` are DevBufs of 2^k elements; before phase p > 0 is
+        committed `phase_fn(p, challenges)` is called with the user challenges so far (Python ints, canonical) and
+        returns {advice column index: uint64[usable_rows.., 4] Montgomery limbs} for the columns of that phase."""
+        fn, st = self._rng(rng_words, seed)
+        ptrs = [b.ptr for b in advice_bufs]
+        arr = (C.c_void_p * max(len(ptrs), 1))(*ptrs)
+        nch = len(self.cs.challenge_phase)
+
+        def _cb(_user, phase, ch_ptr, _adv):
+            try:
+                raw = np.ctypeslib.as_array(C.cast(ch_ptr, C.POINTER(C.c_uint64)), shape=(max(nch, 1), 4))
+                chal = [fr_from_mont(raw[i]) for i in range(nch)]
+                for col, vals in phase_fn(phase, chal).items():
+                    advice_bufs[col].upload(_fr(vals))
+                return 0
+            except Exception:  # the C side maps a non-zero status to CQ_ERR_ARG
+                import traceback
+
+                traceback.print_exc()
+                return 1
+
+        cb = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p)(_cb)
+        cols = [_fr(i) if len(i) else np.zeros((0, 4), dtype=np.uint64) for i in (instances or [])]
+        iptr = (C.c_void_p * max(len(cols), 1))(*[c_.ctypes.data for c_ in cols])
+        ilen = (C.c_size_t * max(len(cols), 1))(*[c_.shape[0] for c_ in cols])
+        proof = (C.c_uint8 * self.proof_size)()
+        plen = C.c_size_t()
+        self.ctx._chk(self.ctx.lib.cq_create_proof_phases(self.h, arr, iptr, ilen, cb, None, fn, st, proof, self.proof_size, C.byref(plen)))
+        return bytes(proof[: plen.value])
 
     def create_proof_dev(self, advice_ptrs, rng_words=None, seed=None, instances=None) -> bytes:
         fn, st = self._rng(rng_words, seed)

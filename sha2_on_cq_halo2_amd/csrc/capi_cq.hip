@@ -273,6 +273,14 @@ static int pk_create_impl(cq_ctx* c, cq_params* params, const cq_circuit* cs, cq
       if (pl->fixed_query_columns[q] >= pl->num_fixed) return pk_abort(pk, c->fail(CQ_ERR_ARG, "pk: fixed query column out of range"));
       pk->fixed_queries.push_back({pl->fixed_query_columns[q], pl->fixed_query_rotations[q]});
     }
+    // phases (circuit.rs advice_column_phase / challenge_phase)
+    pk->advice_phase.assign(cs->num_advice, 0);
+    for (uint32_t a = 0; a < cs->num_advice && pl->advice_column_phases; a++) pk->advice_phase[a] = pl->advice_column_phases[a];
+    if (pl->num_challenges && !pl->challenge_phases) return pk_abort(pk, c->fail(CQ_ERR_ARG, "pk: null pointer in cq_plonk"));
+    pk->challenge_phase.assign(pl->challenge_phases, pl->challenge_phases + pl->num_challenges);
+    for (uint8_t ph : pk->advice_phase) pk->num_phases = std::max<uint32_t>(pk->num_phases, ph + 1u);
+    for (uint8_t ph : pk->challenge_phase) pk->num_phases = std::max<uint32_t>(pk->num_phases, ph + 1u);
+    if (pk->num_phases > 3) return pk_abort(pk, c->fail(CQ_ERR_ARG, "pk: the API only supports 3 phases (prover.rs:337)"));
     for (uint32_t q = 0; q < pl->num_perm_columns; q++) {
       const uint32_t kind = pl->perm_column_kinds[q], idx = pl->perm_column_indices[q];
       const uint32_t lim = kind == CQ_COL_ADVICE ? cs->num_advice : kind == CQ_COL_FIXED ? pl->num_fixed : kind == CQ_COL_INSTANCE ? pl->num_instance : 0;
@@ -286,7 +294,7 @@ static int pk_create_impl(cq_ctx* c, cq_params* params, const cq_circuit* cs, cq
     const char* why = nullptr;
     size_t words = 0;
     if (!gate_program_check(pl->gate_program_lens, pl->gate_programs, pl->num_gate_polys, pl->num_constants, cs->num_advice,
-                            pl->num_fixed, pl->num_instance, &why, &words))
+                            pl->num_fixed, pl->num_instance, pl->num_challenges, &why, &words))
       return pk_abort(pk, c->fail(CQ_ERR_ARG, why));
     std::vector<uint32_t> blob;
     size_t o = 0;
@@ -313,7 +321,7 @@ static int pk_create_impl(cq_ctx* c, cq_params* params, const cq_circuit* cs, cq
     const char* why = nullptr;
     size_t words = 0;
     if (!gate_program_check(pl->legacy_program_lens, pl->legacy_programs, (uint32_t)nprog, pl->num_constants, cs->num_advice, pl->num_fixed,
-                            pl->num_instance, &why, &words))
+                            pl->num_instance, pl->num_challenges, &why, &words))
       return pk_abort(pk, c->fail(CQ_ERR_ARG, why));
     std::vector<uint32_t> blob;
     size_t o = 0, idx = 0;
@@ -339,7 +347,7 @@ static int pk_create_impl(cq_ctx* c, cq_params* params, const cq_circuit* cs, cq
     const char* why = nullptr;
     size_t words = 0;
     if (!gate_program_check(pl->lookup_input_program_lens, pl->lookup_input_programs, (uint32_t)off, pl->num_constants,
-                            cs->num_advice, pl->num_fixed, pl->num_instance, &why, &words))
+                            cs->num_advice, pl->num_fixed, pl->num_instance, pl->num_challenges, &why, &words))
       return pk_abort(pk, c->fail(CQ_ERR_ARG, why));
     std::vector<uint32_t> blob;
     size_t o = 0, idx = 0;
@@ -671,14 +679,15 @@ size_t cq_pk_proof_size(const cq_pk* pk) {
 
 static int create_proof_any(cq_pk* pk, const uint64_t* const* advice_dev, const uint64_t* const* instances,
                             const size_t* instance_lens, cq_rng_next_u64 rng, void* rng_state, uint8_t* proof,
-                            size_t proof_cap, size_t* proof_len) {
+                            size_t proof_cap, size_t* proof_len, cq_phase_fn phase_fn = nullptr, void* phase_user = nullptr) {
   if (!pk || (!advice_dev && pk->num_advice) || !rng || !proof || !proof_len) return CQ_ERR_ARG;
   cq_ctx* c = pk->ctx;
   // "InvalidInstances" (prover.rs:73-82)
   if (pk->num_instance && (!instances || !instance_lens)) return c->fail(CQ_ERR_ARG, "create_proof: instance columns missing");
   CQ_HIP(c, hipSetDevice(c->device));
   std::vector<uint8_t> out;
-  int rc = create_proof_dev(pk, advice_dev, instances, instance_lens, rng, rng_state, out);
+  if (pk->num_phases > 1 && !phase_fn) return c->fail(CQ_ERR_ARG, "create_proof: a multi-phase circuit needs cq_create_proof_phases");
+  int rc = create_proof_dev(pk, advice_dev, instances, instance_lens, phase_fn, phase_user, rng, rng_state, out);
   if (rc != CQ_OK) return rc;
   if (out.size() > proof_cap) return c->fail(CQ_ERR_ARG, "proof buffer too small");
   memcpy(proof, out.data(), out.size());
@@ -713,6 +722,12 @@ static int create_proof_host_any(cq_pk* pk, const uint64_t* const* advice, const
 int cq_create_proof_host(cq_pk* pk, const uint64_t* const* advice, cq_rng_next_u64 rng, void* rng_state, uint8_t* proof,
                          size_t proof_cap, size_t* proof_len) {
   return create_proof_host_any(pk, advice, nullptr, nullptr, rng, rng_state, proof, proof_cap, proof_len);
+}
+
+int cq_create_proof_phases(cq_pk* pk, uint64_t* const* advice_dev, const uint64_t* const* instances, const size_t* instance_lens,
+                           cq_phase_fn phase_fn, void* phase_user, cq_rng_next_u64 rng, void* rng_state, uint8_t* proof,
+                           size_t proof_cap, size_t* proof_len) {
+  return create_proof_any(pk, advice_dev, instances, instance_lens, rng, rng_state, proof, proof_cap, proof_len, phase_fn, phase_user);
 }
 
 int cq_create_proof_instances(cq_pk* pk, const uint64_t* const* advice, int advice_on_device, const uint64_t* const* instances,

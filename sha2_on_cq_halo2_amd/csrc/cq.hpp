@@ -117,6 +117,9 @@ struct cq_pk {
   cq::Fr* ext_pow_lo = nullptr;     // extended_omega^t, t < 256
   cq::Fr* ext_pow_hi = nullptr;     // extended_omega^(256 b), b < max(ext / 256, 1)
   int opener = CQ_OPENER_GWC;
+  std::vector<uint8_t> advice_phase;     // phase of every advice column
+  std::vector<uint8_t> challenge_phase;  // phase after which user challenge i is squeezed
+  uint32_t num_phases = 1;
   bool general() const { return num_gate_polys || !perm_columns.empty() || !legacy.empty(); }
   size_t perm_sets() const {
     const size_t chunk = cs_degree - 2;

@@ -60,6 +60,9 @@ __global__ __launch_bounds__(256) void gate_eval_kernel(GateEvalArgs a, Fr* __re
           stack[sp++] = ld(base + (size_t)arg * a.stride + rot_idx(i, rot, a.rot_scale, a.size));
           break;
         }
+        case GATE_CHALLENGE:
+          stack[sp++] = ld(a.challenges + arg);
+          break;
         case GATE_NEG:
           stack[sp - 1] = stack[sp - 1].neg();
           break;
@@ -82,8 +85,8 @@ __global__ __launch_bounds__(256) void gate_eval_kernel(GateEvalArgs a, Fr* __re
 }
 
 bool gate_program_check(const uint32_t* lens, const uint32_t* words, uint32_t num_polys, uint32_t num_constants,
-                        uint32_t num_advice, uint32_t num_fixed, uint32_t num_instance, const char** why,
-                        size_t* total_words) {
+                        uint32_t num_advice, uint32_t num_fixed, uint32_t num_instance, uint32_t num_challenges,
+                        const char** why, size_t* total_words) {
   size_t off = 0;
   for (uint32_t p = 0; p < num_polys; p++) {
     const uint32_t len = lens[p];
@@ -104,6 +107,10 @@ bool gate_program_check(const uint32_t* lens, const uint32_t* words, uint32_t nu
           sp++;
           break;
         }
+        case CQ_GATE_CHALLENGE:
+          if (arg >= num_challenges) { *why = "gate program: challenge index out of range"; return false; }
+          sp++;
+          break;
         case CQ_GATE_NEG:
           if (sp < 1) { *why = "gate program: stack underflow"; return false; }
           break;

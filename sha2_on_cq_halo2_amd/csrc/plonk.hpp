@@ -24,12 +24,14 @@ enum GateOp : uint32_t {
   GATE_ADD = CQ_GATE_ADD,
   GATE_MUL = CQ_GATE_MUL,
   GATE_SCALE = CQ_GATE_SCALE,
+  GATE_CHALLENGE = CQ_GATE_CHALLENGE,
 };
 
 struct GateEvalArgs {
   const uint32_t* prog;      // device: [len_0, words..., len_1, words..., ...]
   uint32_t num_polys;
   const Fr* constants;       // device
+  const Fr* challenges;      // device: user challenges (Expression::Challenge)
   const Fr* advice;          // column c at advice + c * stride
   const Fr* fixed;
   const Fr* instance;
@@ -73,8 +75,8 @@ struct LookupHArgs {
 
 // checks a gate program blob on the host; returns false with `why` set if malformed
 bool gate_program_check(const uint32_t* lens, const uint32_t* words, uint32_t num_polys, uint32_t num_constants,
-                        uint32_t num_advice, uint32_t num_fixed, uint32_t num_instance, const char** why,
-                        size_t* total_words);
+                        uint32_t num_advice, uint32_t num_fixed, uint32_t num_instance, uint32_t num_challenges,
+                        const char** why, size_t* total_words);
 
 int gate_eval(cq_ctx* c, const GateEvalArgs& a, Fr* h);  // h[i] = Horner_y(gate polynomials)(i)
 int perm_sigma(cq_ctx* c, const uint32_t* mapping_dev, uint32_t ncols, uint32_t n, const Fr* omega_powers,

@@ -236,6 +236,7 @@ struct Arena {
 struct Buffers {
   Fr *adv, *inst_lag, *inst_coeff, *f_lag, *f_coeff, *bpoly, *random_poly, *z, *mv, *cosets, *adv_cosets, *inst_cosets,
       *z_cosets, *lk_inputs, *plk, *plk_cosets, *h_ext, *h_coeff, *gwc_batch, *gwc_wit, *shplonk, *t_comp, *den, *a_val, *m_fr, *a_scaled;
+  Fr* challenges;  // user challenges (Expression::Challenge), uploaded as the phases complete
   uint64_t* rng_dev;
   uint32_t *m_counts, *err_dev;
 };
@@ -290,6 +291,7 @@ void carve(const cq_pk* pk, Arena& ar, Buffers& b) {
   b.a_val = ar.take(L * N);
   b.m_fr = ar.take(L * N);
   b.a_scaled = ar.take(wsum * N);
+  b.challenges = ar.take(pk->challenge_phase.size() + 8);
   b.rng_dev = (uint64_t*)ar.take(2 * n);  // 64 B per element = 2 Fr
   b.m_counts = (uint32_t*)ar.take(L * N / 8 + 64);
   b.err_dev = b.m_counts ? b.m_counts + L * N : nullptr;
@@ -396,8 +398,8 @@ size_t prover_arena_elems(const cq_pk* pk) {
 }
 
 int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, const uint64_t* const* instances,
-                     const size_t* instance_lens, cq_rng_next_u64 rng_next, void* rng_state,
-                     std::vector<uint8_t>& proof_out) {
+                     const size_t* instance_lens, cq_phase_fn phase_fn, void* phase_user, cq_rng_next_u64 rng_next,
+                     void* rng_state, std::vector<uint8_t>& proof_out) {
   cq_ctx* c = pk->ctx;
   cq_domain* dom = pk->domain;
   const uint32_t k = pk->k;
@@ -440,9 +442,6 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, const uint64_
       for (size_t r = 0; r < instance_lens[i]; r++) tr.common_scalar(Fr::from_limbs64(instances[i] + 4 * r));
   }
 
-  // ---- advice: copy in, blind rows u..n (prover.rs:346-350), one unused blind per column (:352-355) ----
-  for (size_t a = 0; a < A; a++)
-    CQ_HIP(c, hipMemcpyAsync(adv + a * n, advice_dev[a], (size_t)u * sizeof(Fr), hipMemcpyDeviceToDevice, s));
   std::vector<Fr> z_tails(S * bf), plk_tails(PL * 2 * (bf + 1)), plkz_tails(PL * bf);
   uint64_t* rng_pin = nullptr;
   size_t rng_first = 0;
@@ -458,24 +457,46 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, const uint64_
     CQ_HIP(c, hipStreamWaitEvent(s, c->copy_done, 0));
     return poly_from_u512(c, rng_dev, (uint32_t)n, random_poly);
   };
-  {
-    std::vector<Fr> tails(A * (n - u));
+  // ---- advice, phase by phase (`next_phase`, prover.rs:299-391; the synthesis loop :436-463): copy the phase's
+  //      columns in, blind rows u..n (:346-350), one unused blind per column (:352-355), commit, squeeze the phase's
+  //      challenges ----------------------------------------------------------------------------------------------
+  const size_t NC = pk->challenge_phase.size();
+  std::vector<Fr> user_challenges(NC, Fr::zero());
+  auto phase_of = [&](size_t a) -> uint32_t { return pk->advice_phase.empty() ? 0u : pk->advice_phase[a]; };
+  for (uint32_t phase = 0; phase < pk->num_phases; phase++) {
+    const bool last_phase = phase + 1 == pk->num_phases;
+    std::vector<size_t> cols;
     for (size_t a = 0; a < A; a++)
-      for (size_t r = 0; r < n - u; r++) tails[a * (n - u) + r] = rng.fr();
-    for (size_t a = 0; a < A; a++) (void)rng.fr();
+      if (phase_of(a) == phase) cols.push_back(a);
+    if (phase > 0) {
+      // the caller computes this phase's witness from the challenges of the earlier phases
+      std::vector<uint64_t> ch(4 * std::max<size_t>(NC, 1), 0);
+      for (size_t i = 0; i < NC; i++) user_challenges[i].to_limbs64(ch.data() + 4 * i);
+      CQ_HIP(c, hipStreamSynchronize(s));
+      if (!phase_fn || phase_fn(phase_user, phase, ch.data(), (uint64_t* const*)advice_dev) != 0)
+        return c->fail(CQ_ERR_ARG, "create_proof: the phase callback failed");
+    }
+    for (size_t a : cols)
+      CQ_HIP(c, hipMemcpyAsync(adv + a * n, advice_dev[a], (size_t)u * sizeof(Fr), hipMemcpyDeviceToDevice, s));
+    const size_t AC = cols.size();
+    std::vector<Fr> tails(AC * (n - u));
+    for (size_t j = 0; j < AC; j++)
+      for (size_t r = 0; r < n - u; r++) tails[j * (n - u) + r] = rng.fr();
+    for (size_t j = 0; j < AC; j++) (void)rng.fr();
     void* pin;
     CQ_TRY(c->ensure_pinned(std::max(tails.size() * sizeof(Fr), (size_t)64 * n), &pin));
     memcpy(pin, tails.data(), tails.size() * sizeof(Fr));
-    for (size_t a = 0; a < A; a++)
-      CQ_HIP(c, hipMemcpyAsync(adv + a * n + u, (Fr*)pin + a * (n - u), (n - u) * sizeof(Fr), hipMemcpyHostToDevice, s));
+    for (size_t j = 0; j < AC; j++)
+      CQ_HIP(c, hipMemcpyAsync(adv + cols[j] * n + u, (Fr*)pin + j * (n - u), (n - u) * sizeof(Fr), hipMemcpyHostToDevice, s));
     CQ_HIP(c, hipStreamSynchronize(s));  // pinned buffer is reused below
     // commit_lagrange per column (:356-360): enqueue now, collect after the host work below
-    std::vector<const Fr*> sc(A);
-    std::vector<const G1Affine*> bs(A, pk->params->g_lagrange);
-    std::vector<size_t> ln(A, n);
-    for (size_t a = 0; a < A; a++) sc[a] = adv + a * n;
+    std::vector<const Fr*> sc(AC);
+    std::vector<const G1Affine*> bs(AC, pk->params->g_lagrange);
+    std::vector<size_t> ln(AC, n);
+    for (size_t j = 0; j < AC; j++) sc[j] = adv + cols[j] * n;
     Commit adv_cm;
-    if (A) CQ_TRY(adv_cm.begin(pk, sc, bs, ln));
+    if (AC) CQ_TRY(adv_cm.begin(pk, sc, bs, ln));
+    if (last_phase) {
     // The next draws from the RNG are, per permutation set, `bf` blinding rows of z and one blind
     // (permutation/prover.rs:169-175), then the vanishing argument's n coefficients + 1 blind
     // (vanishing/prover.rs:51-55): the CQ rounds in between draw nothing, so taking them now keeps the
@@ -505,8 +526,9 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, const uint64_
     rng.fill(rng_pin, rng_first);
     CQ_HIP(c, hipMemcpyAsync(rng_dev, rng_pin, rng_first * sizeof(uint64_t), hipMemcpyHostToDevice, c->copy_stream));
     if (!L && !PL) CQ_TRY(finish_random_poly());
+    }
     // batch_normalize (:363-366), write (:370-374)
-    if (A) {
+    if (AC) {
       std::vector<G1Affine> pts;
       CQ_TRY(adv_cm.end(pts));
       for (auto& p : pts)
@@ -514,7 +536,10 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, const uint64_
     } else {
       CQ_HIP(c, hipStreamSynchronize(s));
     }
+    for (size_t i = 0; i < NC; i++)  // :383-389
+      if (pk->challenge_phase[i] == phase) user_challenges[i] = tr.squeeze();
   }
+  if (NC) CQ_HIP(c, hipMemcpyAsync(B.challenges, user_challenges.data(), NC * sizeof(Fr), hipMemcpyHostToDevice, s));
   const Fr theta = tr.squeeze();  // :472
 
   // ---- legacy lookups: commit_permuted (lookup/prover.rs:57-160) ---------------------------------------------
@@ -524,6 +549,7 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, const uint64_
     ga.prog = prog;
     ga.num_polys = width;
     ga.constants = pk->constants;
+    ga.challenges = B.challenges;
     ga.advice = adv;
     ga.fixed = pk->fixed_values;
     ga.instance = B.inst_lag;
@@ -576,6 +602,7 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, const uint64_
       ga.prog = pk->lookup_prog + lk.prog[j];
       ga.num_polys = 1;
       ga.constants = pk->constants;
+      ga.challenges = B.challenges;
       ga.advice = adv;
       ga.fixed = pk->fixed_values;
       ga.instance = B.inst_lag;
@@ -818,6 +845,7 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, const uint64_
         ga.prog = pk->gate_prog;
         ga.num_polys = pk->num_gate_polys;
         ga.constants = pk->constants;
+        ga.challenges = B.challenges;
         ga.advice = B.adv_cosets;
         ga.fixed = pk->fixed_cosets;
         ga.instance = B.inst_cosets;
@@ -868,6 +896,7 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, const uint64_
         ga.prog = pk->legacy_prog + (side ? lk.tab_off : lk.in_off);
         ga.num_polys = lk.width;
         ga.constants = pk->constants;
+        ga.challenges = B.challenges;
         ga.advice = B.adv_cosets;
         ga.fixed = pk->fixed_cosets;
         ga.instance = B.inst_cosets;

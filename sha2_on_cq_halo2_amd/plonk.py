@@ -14,7 +14,7 @@ import numpy as np
 
 FR_MODULUS = 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001
 
-GATE_CONST, GATE_ADVICE, GATE_FIXED, GATE_INSTANCE, GATE_NEG, GATE_ADD, GATE_MUL, GATE_SCALE = range(8)
+GATE_CONST, GATE_ADVICE, GATE_FIXED, GATE_INSTANCE, GATE_NEG, GATE_ADD, GATE_MUL, GATE_SCALE, GATE_CHALLENGE = range(9)
 COL_ADVICE, COL_FIXED, COL_INSTANCE = 0, 1, 2
 _QUERY_OP = {COL_ADVICE: GATE_ADVICE, COL_FIXED: GATE_FIXED, COL_INSTANCE: GATE_INSTANCE}
 
@@ -55,6 +55,11 @@ class Expression:
     def query(column: Column, rotation: int = 0) -> "Expression":
         return Expression("query", column, rotation)
 
+    @staticmethod
+    def challenge(index: int) -> "Expression":
+        """`Expression::Challenge` (circuit.rs:793-794)."""
+        return Expression("challenge", index)
+
     def __neg__(self):
         return Expression("neg", self)
 
@@ -77,7 +82,7 @@ class Expression:
 
     def degree(self) -> int:
         """circuit.rs:1040-1056."""
-        if self.op == "const":
+        if self.op in ("const", "challenge"):
             return 0
         if self.op == "query":
             return 1
@@ -100,6 +105,8 @@ class Expression:
         def walk(e):
             if e.op == "const":
                 out.append(GATE_CONST | const_index(e.a) << 8)
+            elif e.op == "challenge":
+                out.append(GATE_CHALLENGE | e.a << 8)
             elif e.op == "query":
                 out.append(_QUERY_OP[e.a.kind] | e.a.index << 8)
                 out.append(e.b & 0xFFFFFFFF)
@@ -137,11 +144,20 @@ class ConstraintSystem:
         self.static_lookups = []   # [[(advice column index, table)]]
         self._lookup_exprs = []    # the input expression of every (lookup, table column) pair, flattened
         self.lookups = []          # legacy lookups: [([input expressions], [table expressions])] (plonk/lookup.rs:9-36)
+        self.advice_column_phase = []  # phase of every advice column (circuit.rs `advice_column_phase`)
+        self.challenge_phase = []      # phase after which each user challenge becomes available
 
     # -- columns (circuit.rs:1903-1960)
-    def advice_column(self) -> Column:
+    def advice_column(self, phase: int = 0) -> Column:
+        """`advice_column` / `advice_column_in(phase)` (circuit.rs:1903-1935)."""
         self.num_advice_columns += 1
+        self.advice_column_phase.append(phase)
         return Column(COL_ADVICE, self.num_advice_columns - 1)
+
+    def challenge_usable_after(self, phase: int) -> Expression:
+        """circuit.rs:1962-1977: a challenge squeezed once the commitments of `phase` are in the transcript."""
+        self.challenge_phase.append(phase)
+        return Expression.challenge(len(self.challenge_phase) - 1)
 
     def fixed_column(self) -> Column:
         self.num_fixed_columns += 1

@@ -18,7 +18,7 @@ A, F, I = PL.ADVICE, PL.FIXED, PL.INSTANCE
 TABLE = [0, 1, 6, 8, 10, 12, 14, 16, 18, 20, 22, 24, 26, 28, 30, 32]
 
 
-def chain_circuit(k, degree5=False, with_lookup=False, lookup_expr=False, plookup=False, seed=1):
+def chain_circuit(k, degree5=False, with_lookup=False, lookup_expr=False, plookup=False, phases=False, seed=1):
     """Returns dict(circuit, fixed, advice, instances, mapping, tables)."""
     n = 1 << k
     q_add, q_mul, q_next, q_prev, q_fix, kc = range(6)
@@ -53,7 +53,17 @@ def chain_circuit(k, degree5=False, with_lookup=False, lookup_expr=False, plooku
         num_fixed += 3
         plookups = [([PL.mul(PL.fix(q_pl), PL.adv(pcol)), PL.mul(PL.fix(q_pl), PL.add(PL.scale(PL.adv(pcol), 2), PL.const(1)))],
                      [PL.fix(t0), PL.fix(t1)])]
-    circuit = CP.CqCircuit(k, num_advice, lookups, num_fixed, 1, gates, perm_columns, None, plookups)
+    advice_phases, challenge_phases = None, []
+    if phases:
+        # three phases (circuit.rs FirstPhase..ThirdPhase): ph1 = c0 * a in phase 1, ph2 = ph1 + c1 in phase 2, with
+        # c0 squeezed after the first-phase commitments and c1 after the second-phase ones (prover.rs:436-463)
+        ph1, ph2 = num_advice, num_advice + 1
+        num_advice += 2
+        advice_phases = [0] * (num_advice - 2) + [1, 2]
+        challenge_phases = [0, 1]
+        gates.append(PL.mul(PL.fix(q_add), PL.sub(PL.adv(ph1), PL.mul(PL.chal(0), a))))
+        gates.append(PL.mul(PL.fix(q_add), PL.sub(PL.sub(PL.adv(ph2), PL.adv(ph1)), PL.chal(1))))
+    circuit = CP.CqCircuit(k, num_advice, lookups, num_fixed, 1, gates, perm_columns, None, plookups, advice_phases, challenge_phases)
     bf = circuit.blinding_factors()
     u = n - (bf + 1)
     R = u - 2  # chain rows
@@ -102,6 +112,10 @@ def chain_circuit(k, degree5=False, with_lookup=False, lookup_expr=False, plooku
     elif with_lookup:
         for r in range(u):
             adv[3][r] = TABLE[(r * 7 + 3) % len(TABLE)]
+    if phases:
+        a_col, sel = list(adv[0]), list(fixed[q_add])
+        adv[ph1] = lambda ch: [ch[0] * a_col[r] % P if sel[r] else 0 for r in range(u)]
+        adv[ph2] = lambda ch: [(ch[0] * a_col[r] + ch[1]) % P if sel[r] else 0 for r in range(u)]
     if plookup:
         vals = [3, 5, 8, 13, 21, 34, 55]
         for i, v_ in enumerate(vals):  # table rows (v, 2v + 1); the remaining rows stay (0, 0)
@@ -252,7 +266,7 @@ def to_backend_cs(circuit, gtables):
     from sha2_on_cq_halo2_amd import plonk as GP
 
     cs = GP.ConstraintSystem()
-    cols = {A: [cs.advice_column() for _ in range(circuit.num_advice)],
+    cols = {A: [cs.advice_column(circuit.phase_of(c_)) for c_ in range(circuit.num_advice)],
             F: [cs.fixed_column() for _ in range(circuit.num_fixed)],
             I: [cs.instance_column() for _ in range(circuit.num_instance)]}
 
@@ -260,6 +274,8 @@ def to_backend_cs(circuit, gtables):
         t = e[0]
         if t == "const":
             return GP.Expression.constant(e[1])
+        if t == "challenge":
+            return GP.Expression.challenge(e[1])
         if t in (A, F, I):
             return cs.query_any(cols[t][e[1]], e[2])
         if t == "neg":
@@ -272,6 +288,8 @@ def to_backend_cs(circuit, gtables):
             return conv(e[1]) * int(e[2])
         raise ValueError(t)
 
+    for ph in circuit.challenge_phases:
+        cs.challenge_usable_after(ph)
     for kind, idx in circuit.perm_columns:
         cs.enable_equality(cols[kind][idx])
     for li, (ins, tabs) in enumerate(circuit.plookups):

@@ -48,8 +48,8 @@ def test_assembly_cycles():
 
 
 @pytest.mark.parametrize("kw", [dict(), dict(degree5=True), dict(with_lookup=True), dict(lookup_expr=True), dict(plookup=True),
-                                dict(plookup=True, with_lookup=True)],
-                         ids=["deg3", "deg5", "lookup", "lookup-expr", "plookup", "plookup+cq"])
+                                dict(plookup=True, with_lookup=True), dict(phases=True)],
+                         ids=["deg3", "deg5", "lookup", "lookup-expr", "plookup", "plookup+cq", "phases"])
 def test_plonk_proof_verifies(kw):
     fx = oracle_env(5, **kw)
     cs = fx["circuit"]

@@ -212,3 +212,40 @@ def test_random_circuits_proof_bytes_match_oracle(ctx, seed):
         gpk.set_opener(opener)
         tr = CP.create_proof(fx["params"], fx["pk"], fx["advice"], B.Xoshiro256ss(100 + seed), instances=fx["instances"], opener=opener)
         assert gpk.create_proof(cols, seed=100 + seed, instances=inst) == tr.proof, (seed, opener)
+
+
+def test_multi_phase_proof_bytes_match_oracle(ctx):
+    """Three phases (circuit.rs FirstPhase..ThirdPhase): the phase-1 and phase-2 advice columns are computed from the
+    challenges squeezed after the earlier phases' commitments (prover.rs:436-463) through the phase callback; gates
+    read the challenges (Expression::Challenge).  Bytes equal the oracle's; a single-shot call is refused."""
+    from sha2_on_cq_halo2_amd import CqError
+
+    k = 5
+    n = 1 << k
+    fx = oracle_env(k, phases=True)
+    cs = fx["circuit"]
+    assert cs.num_phases() == 3
+    gpk, _ = _backend_pk(ctx, fx, k, fx["s"])
+    tr = CP.create_proof(fx["params"], fx["pk"], fx["advice"], B.Xoshiro256ss(41), instances=fx["instances"])
+    bufs = []
+    for col in fx["advice"]:
+        vals = [0] * n if callable(col) else list(col) + [0] * (n - len(col))
+        bufs.append(ctx.to_device(B.to_mont_limbs(vals)))
+    calls = []
+
+    def phase_fn(phase, challenges):
+        calls.append((phase, list(challenges)))
+        out = {}
+        for c_, col in enumerate(fx["advice"]):
+            if callable(col) and cs.phase_of(c_) == phase:
+                vals = col(challenges)
+                out[c_] = B.to_mont_limbs(list(vals) + [0] * (n - len(vals)))
+        return out
+
+    inst = [B.to_mont_limbs(i) for i in fx["instances"]]
+    proof = gpk.create_proof_phases(bufs, phase_fn, seed=41, instances=inst)
+    assert [c_[0] for c_ in calls] == [1, 2]
+    assert calls[0][1][0] == tr.challenges["user"][0] and calls[1][1] == tr.challenges["user"]
+    assert proof == tr.proof
+    with pytest.raises(CqError):
+        gpk.create_proof_dev([b_.ptr for b_ in bufs], seed=41, instances=inst)
