@@ -93,10 +93,14 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(NttPassArgs a) {
         // exponent of w_n: (n >> lgp >> deg) * k * i  < n
         const uint32_t ex = ((n >> a.lgp) >> a.deg) * k * i;
         if (ex) {
-          Fr w = g_load(a.tw_lo + (ex & ((1u << a.tw_l) - 1)));
-          const uint32_t h = ex >> a.tw_l;
-          if (h) w = w * g_load(a.tw_hi + h);
-          x = x * w;
+          if (a.tw_full) {
+            x = x * g_load(a.tw_full + ex);
+          } else {
+            Fr w = g_load(a.tw_lo + (ex & ((1u << a.tw_l) - 1)));
+            const uint32_t h = ex >> a.tw_l;
+            if (h) w = w * g_load(a.tw_hi + h);
+            x = x * w;
+          }
         }
       }
     } else {
@@ -146,6 +150,7 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(NttPassArgs a) {
 NttTables::~NttTables() {
   if (tw_lo) hipFree(tw_lo);
   if (tw_hi) hipFree(tw_hi);
+  if (tw_full) hipFree(tw_full);
   if (pq) hipFree(pq);
 }
 
@@ -162,6 +167,12 @@ int NttTables::build(uint32_t log_n_, const Fr& omega_, hipStream_t stream) {
   if (hipMalloc(&pq, sizeof(Fr) * pq_cnt) != hipSuccess) return -1;
   fr_powers_kernel<<<(lo_cnt + 255) / 256, 256, 0, stream>>>(tw_lo, omega, 1, lo_cnt);
   fr_powers_kernel<<<(hi_cnt + 255) / 256, 256, 0, stream>>>(tw_hi, omega, (uint64_t)lo_cnt, hi_cnt);
+  // full table (the kernels are bound by field products, not by HBM: a 32-byte load is cheaper than the product that
+  // composes the two-level entry); skipped for very large domains and when memory is short
+  if (log_n >= 8 && log_n <= 24 && hipMalloc(&tw_full, sizeof(Fr) << log_n) == hipSuccess)
+    fr_powers_kernel<<<((1u << log_n) + 255) / 256, 256, 0, stream>>>(tw_full, omega, 1, 1u << log_n);
+  else
+    (void)hipGetLastError();
   // pq[j] = (w_n^(n / 2^pq_log))^j : roots for the largest in-LDS FFT
   fr_powers_kernel<<<(pq_cnt + 255) / 256, 256, 0, stream>>>(pq, omega, (uint64_t)1 << (log_n - pq_log), pq_cnt);
   return hipGetLastError() == hipSuccess ? 0 : -1;
@@ -204,6 +215,7 @@ int ntt_run(const NttTables& tb, const Fr* in, Fr* out, Fr* scratch, const NttIo
     a.log_t = log_t;
     a.tw_lo = tb.tw_lo;
     a.tw_hi = tb.tw_hi;
+    a.tw_full = tb.tw_full;
     a.tw_l = tb.tw_l;
     a.pq = tb.pq;
     a.pq_shift = tb.pq_log - degs[ps];

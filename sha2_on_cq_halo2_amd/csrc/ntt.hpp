@@ -26,6 +26,7 @@ struct NttPassArgs {
   uint32_t log_n, lgp, deg, log_t;
   const Fr* tw_lo;  // w^j, j < 2^tw_l
   const Fr* tw_hi;  // w^(j << tw_l)
+  const Fr* tw_full;  // w^j, j < n (nullptr: compose tw_lo * tw_hi)
   uint32_t tw_l;
   const Fr* pq;  // (w^(n >> pq_log))^j, j < 2^(pq_log-1)
   uint32_t pq_shift;
@@ -42,6 +43,7 @@ struct NttTables {
   Fr omega;
   Fr* tw_lo = nullptr;
   Fr* tw_hi = nullptr;
+  Fr* tw_full = nullptr;  // every power of omega (n x 32 B): the inter-pass twiddle is then one load, not a product
   Fr* pq = nullptr;
   uint32_t tw_l = 0, pq_log = 0;
   NttTables() = default;
