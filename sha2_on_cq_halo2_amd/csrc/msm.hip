@@ -413,19 +413,32 @@ __global__ __launch_bounds__(256) void msm_combine_kernel(
   if (lane == 0) store_xyzz29(t_cur[g] == 1 ? buckets + g : partial + j, acc);
 }
 
-// level k >= 2, short sub-lists (<= MSM_SHORT partial sums, always the whole bucket): one LANE each
+// level k >= 2, short sub-lists (<= MSM_SHORT partial sums, always the whole bucket): FOUR lanes each -- the
+// additions of one list are dependent, so a quad sums strided quarters and folds them with two shuffles
+// (depth tp/4 + 2 instead of tp)
+constexpr uint32_t COMBINE_QUAD = 4;
 __global__ __launch_bounds__(MSM_ACC_THREADS) void msm_combine_short_kernel(
     const XYZZ* __restrict__ prev, const uint32_t* __restrict__ t_prev, const uint32_t* __restrict__ off_prev,
     const uint32_t* __restrict__ off_cur, uint32_t Bt, XYZZ* __restrict__ buckets) {
-  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= off_cur[Bt]) return;
-  const uint32_t g = owner_of(off_cur, Bt, j);
-  const uint32_t tp = t_prev[g];
-  if (tp > MSM_SHORT) return;
-  const uint32_t lo = off_prev[g];
-  XYZZ29 acc = load_xyzz29(prev + lo);
-  for (uint32_t e = 1; e < tp; e++) xyzz29_add(acc, load_xyzz29(prev + lo + e));
-  store_xyzz29(buckets + g, acc);  // tp <= MSM_SHORT <= MSM_S2  =>  t_cur[g] == 1
+  const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t j = gt / COMBINE_QUAD, sub = gt % COMBINE_QUAD;
+  const bool live = j < off_cur[Bt];
+  uint32_t g = 0, tp = 0, lo = 0;
+  if (live) {
+    g = owner_of(off_cur, Bt, j);
+    tp = t_prev[g];
+    lo = off_prev[g];
+  }
+  const bool mine = live && tp <= MSM_SHORT;
+  XYZZ29 acc = XYZZ29::identity();
+  if (mine)
+    for (uint32_t e = sub; e < tp; e += COMBINE_QUAD) xyzz29_add(acc, load_xyzz29(prev + lo + e));
+#pragma unroll 1
+  for (int delta = COMBINE_QUAD / 2; delta >= 1; delta >>= 1) {
+    XYZZ29 o = xyzz29_shfl_down(acc, delta);  // all lanes take part in the shuffle
+    if (mine && sub + delta < COMBINE_QUAD) xyzz29_add(acc, o);
+  }
+  if (mine && sub == 0) store_xyzz29(buckets + g, acc);  // tp <= MSM_SHORT <= MSM_S2  =>  t_cur[g] == 1
 }
 
 // ---- precomputed window tables (one-off setup) -----------------------------------------------------------
@@ -654,7 +667,7 @@ int msm_run(cq_ctx* ctx, const Fr* const* scalars_host_ptrs, const G1Affine* con
     const uint32_t* t_cur = tk + (size_t)k * Bt;
     const uint32_t* off_cur = off + (size_t)(k + 1) * (Bt + 1);
     // ping-pong: level k+1 reads part[(k-1)&1], writes part[k&1]; one wave per sub-list
-    msm_combine_short_kernel<<<(uint32_t)((L.tmax[k] + MSM_ACC_THREADS - 1) / MSM_ACC_THREADS), MSM_ACC_THREADS, 0, s>>>(
+    msm_combine_short_kernel<<<(uint32_t)((L.tmax[k] * COMBINE_QUAD + MSM_ACC_THREADS - 1) / MSM_ACC_THREADS), MSM_ACC_THREADS, 0, s>>>(
         part[(k - 1) & 1], t_prev, off_prev, off_cur, Bt, buckets);
     msm_combine_kernel<<<(uint32_t)((L.tmax[k] + 3) / 4), 256, 0, s>>>(part[(k - 1) & 1], t_prev, off_prev, t_cur, off_cur, Bt,
                                                                        part[k & 1], buckets);
