@@ -91,27 +91,76 @@ __global__ __launch_bounds__(256) void kate_fill_kernel(const Fr* __restrict__ a
 }
 
 // ---- ff::BatchInvert (Montgomery's trick), zeros stay zero -----------------------------------------
-// lane t owns elements t, t+T, t+2T, ... (coalesced); one Fermat inversion per BI_CHUNK elements.
-constexpr int BI_CHUNK = 8;
+// A Fermat inversion is ~380 dependent products, so it is shared by a whole workgroup: 256 lanes x BI_PER_LANE
+// strided (coalesced) elements.  Each lane keeps its elements in registers, parks the running prefix products in
+// the output array, the lane totals are scanned in LDS (prefix and suffix), lane 0 inverts the block total, and
+// every lane unwinds its own elements: ~5 products per element + one inversion per 2048 elements.
+constexpr int BI_PER_LANE = 8;
+static __device__ __forceinline__ void bi_put(uint4* lo, uint4* hi, uint32_t t, const Fr& v) {
+  lo[t] = make_uint4(v.v.l[0], v.v.l[1], v.v.l[2], v.v.l[3]);
+  hi[t] = make_uint4(v.v.l[4], v.v.l[5], v.v.l[6], v.v.l[7]);
+}
+static __device__ __forceinline__ Fr bi_get(const uint4* lo, const uint4* hi, uint32_t t) {
+  const uint4 a = lo[t], b = hi[t];
+  Fr r;
+  r.v.l[0] = a.x; r.v.l[1] = a.y; r.v.l[2] = a.z; r.v.l[3] = a.w;
+  r.v.l[4] = b.x; r.v.l[5] = b.y; r.v.l[6] = b.z; r.v.l[7] = b.w;
+  return r;
+}
 __global__ __launch_bounds__(256) void batch_invert_kernel(Fr* __restrict__ a, uint32_t n) {
-  const uint32_t T = gridDim.x * blockDim.x;
-  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  Fr v[BI_CHUNK], pref[BI_CHUNK];
+  __shared__ uint4 lo[256], hi[256];
+  const uint32_t t = threadIdx.x;
+  const uint32_t base = blockIdx.x * (256 * BI_PER_LANE);
+  Fr v[BI_PER_LANE];
   Fr acc = Fr::one();
 #pragma unroll
-  for (int k = 0; k < BI_CHUNK; k++) {
-    const uint32_t i = t + k * T;
+  for (int k = 0; k < BI_PER_LANE; k++) {
+    const uint32_t i = base + k * 256 + t;
     v[k] = i < n ? ld(a + i) : Fr::zero();
-    pref[k] = acc;
-    if (!v[k].is_zero()) acc = acc * v[k];
-  }
-  acc = acc.inv();
-#pragma unroll
-  for (int k = BI_CHUNK - 1; k >= 0; k--) {
-    const uint32_t i = t + k * T;
-    if (i < n && !v[k].is_zero()) {
-      st(a + i, pref[k] * acc);
+    if (!v[k].is_zero()) {
+      st(a + i, acc);  // product of the lane's earlier non-zero elements, read back while unwinding
       acc = acc * v[k];
+    }
+  }
+  // inclusive prefix scan of the lane totals (Hillis-Steele), then the exclusive prefix and the block total
+  Fr inc = acc;
+#pragma unroll 1
+  for (uint32_t d = 1; d < 256; d <<= 1) {
+    bi_put(lo, hi, t, inc);
+    __syncthreads();
+    if (t >= d) inc = bi_get(lo, hi, t - d) * inc;
+    __syncthreads();
+  }
+  bi_put(lo, hi, t, inc);
+  __syncthreads();
+  const Fr exc = t ? bi_get(lo, hi, t - 1) : Fr::one();
+  const Fr total = bi_get(lo, hi, 255);
+  __syncthreads();
+  // suffix products of the lane totals AFTER lane t
+  Fr suf = acc;
+#pragma unroll 1
+  for (uint32_t d = 1; d < 256; d <<= 1) {
+    bi_put(lo, hi, t, suf);
+    __syncthreads();
+    if (t + d < 256) suf = suf * bi_get(lo, hi, t + d);
+    __syncthreads();
+  }
+  bi_put(lo, hi, t, suf);
+  __syncthreads();
+  const Fr after = t < 255 ? bi_get(lo, hi, t + 1) : Fr::one();
+  __syncthreads();
+  if (t == 0) bi_put(lo, hi, 0, total.inv());
+  __syncthreads();
+  const Fr total_inv = bi_get(lo, hi, 0);
+  // inverse of (everything up to and including this lane) = total^-1 * (product of the later lanes)
+  Fr r = total_inv * after;
+#pragma unroll
+  for (int k = BI_PER_LANE - 1; k >= 0; k--) {
+    const uint32_t i = base + k * 256 + t;
+    if (i < n && !v[k].is_zero()) {
+      const Fr before = exc * ld(a + i);  // block-wide product of everything before this element
+      st(a + i, before * r);
+      r = r * v[k];
     }
   }
 }
@@ -266,8 +315,7 @@ int poly_kate_division(cq_ctx* c, const Fr* a, uint32_t n, const Fr& z, Fr* q) {
 
 int poly_batch_invert(cq_ctx* c, Fr* a, uint32_t n) {
   if (!n) return CQ_OK;
-  const uint32_t threads = (n + BI_CHUNK - 1) / BI_CHUNK;
-  batch_invert_kernel<<<blocks_for(threads), 256, 0, c->stream>>>(a, n);
+  batch_invert_kernel<<<(n + 256 * BI_PER_LANE - 1) / (256 * BI_PER_LANE), 256, 0, c->stream>>>(a, n);
   return hipGetLastError() == hipSuccess ? CQ_OK : c->fail(CQ_ERR_HIP, "batch_invert launch failed");
 }
 

@@ -268,6 +268,7 @@ void carve(const cq_pk* pk, Arena& ar, Buffers& b) {
   b.f_lag = ar.take(L * n);
   b.f_coeff = ar.take(L * n);
   b.bpoly = ar.take(L * n);
+  b.den = ar.take(L * N + 8);        // directly after bpoly: both are inverted by one batch inversion
   b.random_poly = ar.take(n);
   b.z = ar.take(S * n);              // permutation products (lagrange -> coeff in place)
   b.mv = ar.take(S * n);
@@ -287,7 +288,6 @@ void carve(const cq_pk* pk, Arena& ar, Buffers& b) {
   b.gwc_wit = ar.take(shplonk ? 0 : npts * n);
   b.shplonk = ar.take(shplonk ? 5 * n + 64 * 8 : 0);  // h, two division buffers, h_x, l_x, low-degree remainders
   b.t_comp = ar.take(N);
-  b.den = ar.take(L * N + 8);
   b.a_val = ar.take(L * N);
   b.m_fr = ar.take(L * N);
   b.a_scaled = ar.take(wsum * N);
@@ -755,8 +755,7 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, const uint64_
     }
     if (L) {
       // all inversions of the round in two launches (one Fermat inversion per lane dominates the latency)
-      CQ_TRY(poly_batch_invert(c, den, (uint32_t)(L * N)));
-      CQ_TRY(poly_batch_invert(c, bpoly, (uint32_t)(L * n)));
+      CQ_TRY(poly_batch_invert(c, bpoly, (uint32_t)(L * n + L * N)));  // bpoly and den are adjacent
     }
     woff = 0;
     for (size_t l = 0; l < L; l++) {
