@@ -94,8 +94,8 @@ __global__ __launch_bounds__(256) void kate_fill_kernel(const Fr* __restrict__ a
 // A Fermat inversion is ~380 dependent products, so it is shared by a whole workgroup: 256 lanes x BI_PER_LANE
 // strided (coalesced) elements.  Each lane keeps its elements in registers, parks the running prefix products in
 // the output array, the lane totals are scanned in LDS (prefix and suffix), lane 0 inverts the block total, and
-// every lane unwinds its own elements: ~5 products per element + one inversion per 2048 elements.
-constexpr int BI_PER_LANE = 8;
+// every lane unwinds its own elements: ~5 products per element + one inversion per 4096 elements.
+constexpr int BI_PER_LANE = 16;
 static __device__ __forceinline__ void bi_put(uint4* lo, uint4* hi, uint32_t t, const Fr& v) {
   lo[t] = make_uint4(v.v.l[0], v.v.l[1], v.v.l[2], v.v.l[3]);
   hi[t] = make_uint4(v.v.l[4], v.v.l[5], v.v.l[6], v.v.l[7]);
