@@ -156,6 +156,12 @@ int cq_fixed_base_mul_dev(cq_ctx* ctx, const uint64_t* scalars_dev, size_t n, ui
  * 4 + 128 n byte G1 part. */
 int cq_params_read_raw(cq_ctx* ctx, const uint8_t* buf, size_t len, int checked, cq_params** out);
 int cq_params_write_raw(cq_params* params, uint8_t* buf, size_t cap, size_t* written);
+/* g_to_lagrange(g, k) (arithmetic.rs:277-301): the Lagrange-basis SRS from the monomial one by an inverse FFT
+ * over G1 (device arrays of 2^k affine points). */
+int cq_g_to_lagrange_dev(cq_ctx* ctx, const uint64_t* g_dev, uint32_t k, uint64_t* g_lagrange_dev);
+/* ParamsKZG::downsize(k) (kzg/commitment.rs:480-492): the first 2^k powers and their Lagrange basis (recomputed with
+ * g_to_lagrange), as a new object. */
+int cq_params_downsize(cq_params* params, uint32_t k, cq_params** out);
 void cq_params_destroy(cq_params* params);
 const uint64_t* cq_params_g_dev(const cq_params* params);
 const uint64_t* cq_params_g_lagrange_dev(const cq_params* params);
@@ -188,6 +194,9 @@ int cq_static_table_setup_from_toxic_waste(cq_ctx* ctx, size_t size, const uint6
  * iNTT of the values, one kate_division + (N-1)-term multiexp per root -- run on the GPU.
  * `srs_g1`: `size` affine powers [s^i]_1 (host). */
 int cq_static_table_new(cq_ctx* ctx, size_t size, const uint64_t* values, const uint64_t* srs_g1, cq_static_table** out);
+/* Same result as cq_static_table_new (bit-identical qs), computed FK-style ("fast amortized KZG proofs"): one cyclic
+ * convolution of size 2N over G1 and one G1 DFT instead of N multiexps -- O(N log N) group operations. */
+int cq_static_table_new_fk(cq_ctx* ctx, size_t size, const uint64_t* values, const uint64_t* srs_g1, cq_static_table** out);
 void cq_static_table_destroy(cq_static_table* table);
 int cq_static_table_download_qs(cq_static_table* table, uint64_t* qs_affine);
 

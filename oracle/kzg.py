@@ -5,6 +5,7 @@ out of scope.
 """
 from __future__ import annotations
 
+from .bn254 import Q_MOD
 from .bn254 import (
     FR_ROOT_OF_UNITY_INV,
     FR_S,
@@ -55,6 +56,38 @@ def _lagrange_g1(s: int, k: int):
         scalar = multiplier * rp % P * inv_mod((s - rp) % P, P) % P
         out.append(jac_mul(to_jac(G1_GEN), scalar))
     return batch_to_affine(out)
+
+
+def g_to_lagrange(g, k: int):
+    """arithmetic.rs:277-301: inverse FFT over G1 (`best_fft` with omega^-1, arithmetic.rs:171-234: bit-reversal, then
+    radix-2 butterflies (a, b) -> (a + w b, a - w b)), every point times n^-1.  Affine in, affine out."""
+    from .bn254 import JAC_ID, batch_to_affine, jac_add, jac_mul, to_jac
+
+    n = 1 << k
+    assert len(g) == n
+    root = _root_for(k)
+    omega_inv = inv_mod(root, P)
+    a = [to_jac(p_) for p_ in g]
+    for i in range(n):  # :186-192
+        r = int(format(i, "0%db" % k)[::-1], 2) if k else 0
+        if i < r:
+            a[i], a[r] = a[r], a[i]
+    m = 2
+    while m <= n:  # :202-231 (serial shape)
+        half = m // 2
+        step = pow(omega_inv, n // m, P)
+        for start in range(0, n, m):
+            w = 1
+            for j in range(half):
+                t = jac_mul(a[start + j + half], w)
+                u = a[start + j]
+                a[start + j] = jac_add(u, t)
+                neg_t = (t[0], (-t[1]) % Q_MOD, t[2])
+                a[start + j + half] = jac_add(u, neg_t)
+                w = w * step % P
+        m *= 2
+    n_inv = inv_mod(n % P, P)
+    return batch_to_affine([jac_mul(p_, n_inv) for p_ in a])
 
 
 class ParamsKZG:

@@ -747,6 +747,35 @@ def _static_table_new(cls, ctx: Context, values: np.ndarray, srs_g1: np.ndarray)
 StaticTable.new = classmethod(_static_table_new)
 
 
+def _static_table_new_fk(cls, ctx: Context, values: np.ndarray, srs_g1: np.ndarray) -> "StaticTable":
+    """Same table as `StaticTable.new` (bit-identical cached quotients), built FK-style in O(N log N) group operations."""
+    self = cls.__new__(cls)
+    v, g = _fr(values), _g1(srs_g1)
+    assert v.shape[0] == g.shape[0]
+    self.ctx, self.size = ctx, v.shape[0]
+    h = C.c_void_p()
+    ctx._chk(ctx.lib.cq_static_table_new_fk(ctx.h, self.size, v.ctypes.data, g.ctypes.data, C.byref(h)))
+    self.h = h
+    ctx._children.add(self)
+    return self
+
+
+StaticTable.new_fk = classmethod(_static_table_new_fk)
+
+
+def _params_downsize(self, k: int) -> "ParamsKZG":
+    """`ParamsKZG::downsize(k)` (kzg/commitment.rs:480-492), as a new object."""
+    out = ParamsKZG.__new__(ParamsKZG)
+    h = C.c_void_p()
+    self.ctx._chk(self.ctx.lib.cq_params_downsize(self.h, k, C.byref(h)))
+    out.ctx, out.k, out.n, out.h = self.ctx, k, 1 << k, h
+    self.ctx._children.add(out)
+    return out
+
+
+ParamsKZG.downsize = _params_downsize
+
+
 def _params_read_raw(cls, ctx: Context, data: bytes, checked: bool = True) -> "ParamsKZG":
     """`ParamsKZG::read_custom(reader, RawBytes | RawBytesUnchecked)` (kzg/commitment.rs:383-459)."""
     self = cls.__new__(cls)

@@ -4,6 +4,7 @@
 #include <vector>
 #include "cq.hpp"
 #include "ctx.hpp"
+#include "g1fft.hpp"
 #include "plonk.hpp"
 #include "prover.hpp"
 #include "setup.hpp"
@@ -832,6 +833,28 @@ int cq_static_table_new(cq_ctx* c, size_t size, const uint64_t* values, const ui
   hipFree(quot);
   domain_destroy(dom);
   return CQ_OK;
+}
+
+int cq_static_table_new_fk(cq_ctx* c, size_t size, const uint64_t* values, const uint64_t* srs_g1, cq_static_table** out) {
+  if (!c || !values || !srs_g1 || !out || !is_pow2(size) || size < 2 || size > (1u << 22)) return CQ_ERR_ARG;
+  CQ_HIP(c, hipSetDevice(c->device));
+  int rc = table_alloc(c, size, values, out);
+  if (rc != CQ_OK) return rc;
+  cq_static_table* t = *out;
+  cq_domain* dom = nullptr;
+  if ((rc = domain_create(c, 2, log2u(size), &dom)) != CQ_OK) return rc;
+  G1Affine* srs = nullptr;
+  Fr* coeffs = nullptr;
+  if (hipMalloc(&srs, size * sizeof(G1Affine)) != hipSuccess || hipMalloc(&coeffs, size * sizeof(Fr)) != hipSuccess)
+    return c->fail(CQ_ERR_HIP, "hipMalloc(static_table_new_fk)");
+  CQ_HIP(c, hipMemcpyAsync(srs, srs_g1, size * sizeof(G1Affine), hipMemcpyHostToDevice, c->stream));
+  rc = domain_lagrange_to_coeff(dom, t->values, coeffs, 1, size, size);  // :99-105
+  if (rc == CQ_OK) rc = fk_table_quotients(c, coeffs, srs, log2u(size), t->qs);
+  hipStreamSynchronize(c->stream);
+  hipFree(srs);
+  hipFree(coeffs);
+  domain_destroy(dom);
+  return rc;
 }
 
 // ---- harness RNGs ----------------------------------------------------------------------------------------

@@ -5,6 +5,7 @@
 #include <vector>
 #include "ctx.hpp"
 #include "msm.hpp"
+#include "g1fft.hpp"
 #include "setup.hpp"
 #include "cq.hpp"
 
@@ -336,6 +337,37 @@ int cq_params_read_raw(cq_ctx* c, const uint8_t* buf, size_t len, int checked, c
     if ((rc2 = msm_register_tables(c, p->g_lagrange, p->n)) != CQ_OK) return rc2;
   }
   *out = p;
+  return CQ_OK;
+}
+
+int cq_g_to_lagrange_dev(cq_ctx* c, const uint64_t* g_dev, uint32_t k, uint64_t* g_lagrange_dev) {
+  if (!c || !g_dev || !g_lagrange_dev || k > 26) return CQ_ERR_ARG;
+  CQ_HIP(c, hipSetDevice(c->device));
+  return g1_to_lagrange(c, (const G1Affine*)g_dev, k, (G1Affine*)g_lagrange_dev);
+}
+
+// ParamsKZG::downsize (kzg/commitment.rs:480-492)
+int cq_params_downsize(cq_params* p, uint32_t k, cq_params** out) {
+  if (!p || !out || k > p->k) return CQ_ERR_ARG;  // `assert!(k <= self.k)`
+  cq_ctx* c = p->ctx;
+  CQ_HIP(c, hipSetDevice(c->device));
+  cq_params* q = new cq_params();
+  q->ctx = c;
+  q->k = k;
+  q->n = (size_t)1 << k;
+  const size_t bytes = q->n * sizeof(G1Affine);
+  if (hipMalloc(&q->g, bytes) != hipSuccess || hipMalloc(&q->g_lagrange, bytes) != hipSuccess) {
+    delete q;
+    return c->fail(CQ_ERR_HIP, "hipMalloc(params)");
+  }
+  CQ_HIP(c, hipMemcpyAsync(q->g, p->g, bytes, hipMemcpyDeviceToDevice, c->stream));
+  int rc = g1_to_lagrange(c, q->g, k, q->g_lagrange);
+  if (rc != CQ_OK) return rc;
+  if (c->msm_precompute) {
+    if ((rc = msm_register_tables(c, q->g, q->n)) != CQ_OK) return rc;
+    if ((rc = msm_register_tables(c, q->g_lagrange, q->n)) != CQ_OK) return rc;
+  }
+  *out = q;
   return CQ_OK;
 }
 

@@ -62,3 +62,15 @@ def test_sha_table_kats():
     t = ST.create_decomposition_table("test", 10)
     assert len(t) == 1024 and (0, 0, 0, 0) in t
     assert (0b10_1010_1010, 0b1010, 0b10, 0b10) in t and (0b11_1011_0110, 0b1011, 0b01, 0b10) in t
+
+
+def test_g_to_lagrange_matches_closed_form():
+    """arithmetic.rs:277-301: the inverse FFT over G1 of [s^i]_1 is the Lagrange-basis SRS; the closed form used for
+    setup (kzg/commitment.rs:241-251) must give the same points (the reference's own identity
+    commit(lagrange_to_coeff(a)) == commit_lagrange(a), kzg/commitment.rs:570-593, rests on it)."""
+    from oracle import kzg
+
+    s = B.fr_random(B.Xoshiro256ss(5))
+    for k in (0, 1, 4):
+        p = kzg.ParamsKZG(k, s)
+        assert kzg.g_to_lagrange(p.g, k) == p.g_lagrange

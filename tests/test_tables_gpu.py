@@ -97,3 +97,28 @@ def test_params_raw_roundtrip_and_validation(ctx):
     ParamsKZG.read_raw(ctx, bytes(bad), checked=False)  # RawBytesUnchecked performs no checks
     with pytest.raises(CqError):
         ParamsKZG.read_raw(ctx, raw[:100], checked=False)
+
+
+@pytest.mark.parametrize("N", [2, 16, 256, 4096])
+def test_static_table_fk_equals_reference_construction(ctx, N):
+    """FK-style preprocessing (one size-2N convolution and one DFT over G1) gives the same cached quotients as
+    `StaticTableValues::new` (static_lookup.rs:78-126), checked against the closed form with the toxic waste and,
+    for small N, against the O(N^2) construction run on the GPU."""
+    from sha2_on_cq_halo2_amd import ParamsKZG, StaticTable
+
+    s = B.fr_random(B.Xoshiro256ss(31 + N))
+    sm = B.to_mont_limbs([s])[0]
+    rng = B.Xoshiro256ss(N)
+    values = []
+    while len(values) < N:  # unique values
+        v = B.fr_random(rng) if N > 16 else rng.next_u64() % 1000
+        if v not in values:
+            values.append(v)
+    vm = B.to_mont_limbs(values)
+    k = max(N.bit_length() - 1, 1)
+    srs = ParamsKZG.setup_from_toxic_waste(ctx, k, sm).download()[0][:N]
+    fk = StaticTable.new_fk(ctx, vm, srs).download_qs()
+    closed = StaticTable.setup_from_toxic_waste(ctx, vm, sm).download_qs()
+    assert np.array_equal(fk, closed)
+    if N <= 256:
+        assert np.array_equal(fk, StaticTable.new(ctx, vm, srs).download_qs())
