@@ -95,8 +95,41 @@ def _eq(J1, J2):
     return jac_to_affine(J1) == jac_to_affine(J2)
 
 
-def _gwc_check(tr, proof, queries, s):
-    """gwc/verifier.rs:48-128, unbatched: per point z, s*W - z*W == sum_j v^j (C_j - e_j G)."""
+def _jac_neg(J):
+    return (J[0], (-J[1]) % Q_MOD, J[2])
+
+
+class _FinalChecks:
+    """The verifier's closing equations, each of the form  prod_i e(P_i, [k_i]_2) == 1.
+
+    pairing=False (default): the toxic waste is known in tests, so the equation is checked in G1 as
+    sum_i k_i P_i == O -- sound for test SRSs and fast.  pairing=True: the real thing, with the optimal ate pairing
+    of oracle/pairing.py and the G2 elements a setup would publish ([1]_2, [s]_2, [T(s)]_2, [Z_V(s)]_2,
+    [s^bound]_2; kzg/commitment.rs:253-256, static_lookup.rs:150-160)."""
+
+    def __init__(self, pairing: bool):
+        self.pairing = pairing
+        self._g2 = {}
+
+    def holds(self, pairs) -> bool:
+        if not self.pairing:
+            acc = JAC_ID
+            for J, k in pairs:
+                acc = jac_add(acc, jac_mul(J, k % P))
+            return jac_to_affine(acc) is None
+        from . import pairing as PR
+
+        lst = []
+        for J, k in pairs:
+            k %= P
+            if k not in self._g2:
+                self._g2[k] = PR.g2_mul(k)
+            lst.append((jac_to_affine(J), self._g2[k]))
+        return PR.pairing_product_is_one(lst)
+
+
+def _gwc_check(tr, proof, queries, s, fc):
+    """gwc/verifier.rs:48-128, unbatched: per point z,  e(W, [s]_2) = e(z W + sum_j v^j (C_j - e_j G), [1]_2)."""
     v = tr.squeeze()
     groups = []
     for q in queries:
@@ -118,12 +151,13 @@ def _gwc_check(tr, proof, queries, s):
             term = jac_add(q[1], _smul(G1_GEN, (-q[2]) % P))
             rhs = jac_add(rhs, jac_mul(term, pv))
             pv = pv * v % P
-        ok &= _eq(_smul(w, (s - z) % P), rhs)
+        ok &= fc.holds([(to_jac(w), s), (_jac_neg(jac_add(_smul(w, z), rhs)), 1)])
     return ok
 
 
 def verify_proof(proof: bytes, circuit, vk_repr: int, s: int, tables: dict, table_size: int,
-                 srs_g1_len: int, instances=(), fixed_commitments=(), perm_commitments=(), opener="gwc") -> bool:
+                 srs_g1_len: int, instances=(), fixed_commitments=(), perm_commitments=(), opener="gwc",
+                 pairing: bool = False) -> bool:
     """Returns True iff every verifier equation holds.
 
     tables: id -> list of table values (given order); the committed table polynomial
@@ -131,6 +165,7 @@ def verify_proof(proof: bytes, circuit, vk_repr: int, s: int, tables: dict, tabl
     srs_g1_len: the `srs_g1_len` handed to `StaticTableValues::commit` (static_lookup.rs:149).
     instances: the public inputs per instance column; fixed_commitments / perm_commitments: the
     verifying key's `fixed_commitments` and `permutation.commitments` (affine points).
+    pairing: check the closing equations with real pairings (slow; see _FinalChecks) instead of in G1.
     """
     cs = circuit
     dom = EvaluationDomain(cs.degree(), cs.k)
@@ -284,6 +319,7 @@ def verify_proof(proof: bytes, circuit, vk_repr: int, s: int, tables: dict, tabl
     queries.append((x, to_jac(random_cm), random_eval, ("random",)))
 
     ok = True
+    fc = _FinalChecks(pairing)
     if opener == "shplonk":  # shplonk/verifier.rs:54-148
         y_ = tr.squeeze()
         v_ = tr.squeeze()
@@ -300,9 +336,9 @@ def verify_proof(proof: bytes, circuit, vk_repr: int, s: int, tables: dict, tabl
             rhs = jac_add(rhs, jac_mul(by_key[key], sc_))
         rhs = jac_add(rhs, _smul(G1_GEN, (-r_outer) % P))
         rhs = jac_add(rhs, _smul(h1, (-z_0) % P))
-        ok &= _eq(_smul(h2, (s - u_) % P), rhs)  # e(h2,[s]) = e(rhs + u*h2,[1])
+        ok &= fc.holds([(to_jac(h2), s), (_jac_neg(jac_add(rhs, _smul(h2, u_))), 1)])  # e(h2,[s]) = e(rhs + u*h2,[1])
     else:
-        ok &= _gwc_check(tr, proof, queries, s)
+        ok &= _gwc_check(tr, proof, queries, s, fc)
         if ok is None:
             return False
     # CQ pairings (static_lookup/verifier.rs:138-177), each equation separately
@@ -319,11 +355,9 @@ def verify_proof(proof: bytes, circuit, vk_repr: int, s: int, tables: dict, tabl
             ts = (ts * theta + tv) % P
         zv = (pow(s, table_size, P) - 1) % P
         # e(a,[T]) = e(qa,[Zv]) e(m - beta a,[1])
-        lhs = _smul(a, ts)
-        rhs = jac_add(_smul(qa, zv), jac_add(to_jac(m_cm), _smul(a, (-beta) % P)))
-        ok &= _eq(lhs, rhs)
+        ok &= fc.holds([(to_jac(a), ts), (_jac_neg(to_jac(qa)), zv), (_jac_neg(jac_add(to_jac(m_cm), _smul(a, (-beta) % P))), 1)])
         # e(b0,[s^(L-1-(n-2))]) = e(p,[1])
-        ok &= _eq(_smul(b0, pow(s, srs_g1_len - 1 - (n - 2), P)), to_jac(p_))
+        ok &= fc.holds([(to_jac(b0), pow(s, srs_g1_len - 1 - (n - 2), P)), (_jac_neg(to_jac(p_)), 1)])
         # e(a - [a(0)],[1]) = e(a0,[s])
-        ok &= _eq(jac_add(to_jac(a), _smul(G1_GEN, (-a_at_zero) % P)), _smul(a0, s))
+        ok &= fc.holds([(jac_add(to_jac(a), _smul(G1_GEN, (-a_at_zero) % P)), 1), (_jac_neg(to_jac(a0)), s)])
     return bool(ok)
