@@ -17,6 +17,7 @@ ARCH = "gfx950"
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value",
          "-fno-gpu-rdc", "-I", os.path.join(HERE, "..", "include")]
+FLAGS += os.environ.get("CQ_EXTRA_HIPCC_FLAGS", "").split()  # tuning sweeps only (e.g. -DCQ_MSM_S1=24)
 
 
 def sources():
@@ -52,7 +53,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         if r.returncode != 0:
             raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + r.stdout + r.stderr)
 
-    with ThreadPoolExecutor(max_workers=min(4, max(1, len(jobs)))) as ex:
+    with ThreadPoolExecutor(max_workers=min(int(os.environ.get('CQ_BUILD_JOBS', '4')), max(1, len(jobs)))) as ex:
         list(ex.map(run, jobs))
     if jobs or not os.path.exists(LIB):
         run([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs)

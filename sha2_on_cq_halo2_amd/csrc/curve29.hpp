@@ -85,7 +85,7 @@ static __device__ __forceinline__ XYZZ29 xyzz29_dbl_affine(const Affine29& a) {
   Fq29 m = x2 + x2 + x2;                       // < 6, limbs < 3 * 2^29
   m.normalise();
   const Fq29 x3 = Fq29::sub<4>(m.sqr(), s + s);                   // 36; s + s < 4  ->  x3 < 6
-  const Fq29 y3 = Fq29::sub<2>(m * Fq29::sub<8>(s, x3), w * a.y);  // (s - x3) < 10, 6 * 10 = 60; w * y: 4  ->  y3 < 4
+  const Fq29 y3 = Fq29::mul2(m, Fq29::sub<8>(s, x3), w, Fq29::neg<2>(a.y));  // m (s - x3) - w y: 6 * 10 + 2 * 2 = 64  ->  y3 < 2
   return {x3, y3, v, w};
 }
 
@@ -99,7 +99,7 @@ static __device__ __forceinline__ XYZZ29 xyzz29_dbl(const XYZZ29& p) {
   Fq29 m = x2 + x2 + x2;                       // < 6
   m.normalise();
   const Fq29 x3 = Fq29::sub<4>(m.sqr(), s + s);                   // x3 < 6
-  const Fq29 y3 = Fq29::sub<2>(m * Fq29::sub<8>(s, x3), w * p.y);  // 60; 2 * 4 = 8  ->  y3 < 4
+  const Fq29 y3 = Fq29::mul2(m, Fq29::sub<8>(s, x3), w, Fq29::neg<4>(p.y));  // 6 * 10 + 2 * 4 = 68  ->  y3 < 2
   return {x3, y3, v * p.zz, w * p.zzz};
 }
 
@@ -123,7 +123,7 @@ static __device__ __forceinline__ void xyzz29_add_affine(XYZZ29& acc, const Affi
   const Fq29 ppp = p * pp;                     // 20
   const Fq29 q = acc.x * pp;                   // 16
   const Fq29 x3 = Fq29::sub<6, 31>(r.sqr(), ppp + q + q);               // 36; subtrahend < 6, limbs < 3 * 2^29  ->  x3 < 8
-  const Fq29 y3 = Fq29::sub<2>(r * Fq29::sub<8>(q, x3), acc.y * ppp);   // 6 * 10 = 60; 4 * 2 = 8  ->  y3 < 4
+  const Fq29 y3 = Fq29::mul2(r, Fq29::sub<8>(q, x3), Fq29::neg<4>(acc.y), ppp);  // r (q - x3) - y1 ppp, one reduction: 6 * 10 + 4 * 2 = 68  ->  y3 < 2
   acc.x = x3;
   acc.y = y3;
   acc.zz = acc.zz * pp;                        // 4
@@ -152,7 +152,7 @@ static __device__ __forceinline__ void xyzz29_add(XYZZ29& acc, const XYZZ29& b) 
   const Fq29 ppp = p * pp;                     // 8
   const Fq29 q = u1 * pp;                      // 4
   const Fq29 x3 = Fq29::sub<6, 31>(r.sqr(), ppp + q + q);              // x3 < 8
-  const Fq29 y3 = Fq29::sub<2>(r * Fq29::sub<8>(q, x3), s1 * ppp);     // 4 * 10 = 40; 4  ->  y3 < 4
+  const Fq29 y3 = Fq29::mul2(r, Fq29::sub<8>(q, x3), Fq29::neg<2>(s1), ppp);  // 4 * 10 + 2 * 2 = 44  ->  y3 < 2
   acc.x = x3;
   acc.y = y3;
   acc.zz = acc.zz * b.zz * pp;                 // 4, 4

@@ -154,6 +154,30 @@ struct Fp29 {
     r.a[8] = (uint32_t)c[17];
     return r;
   }
+  // x y + z w with ONE reduction (81 multiplies fewer than two products and an addition).  All four operands
+  // normalised (limbs < 2^29: 18 * 2^58 + 9 * 2^58 + carries < 2^63); bound: Kx Ky + Kz Kw <= 128  ->  result < 2 p.
+  static __device__ __forceinline__ Fp29 mul2(const Fp29& x, const Fp29& y, const Fp29& z, const Fp29& w) {
+    uint64_t c[18];
+    CQ_UNROLL for (int k = 0; k < 18; k++) c[k] = 0;
+    CQ_UNROLL for (int i = 0; i < 9; i++) {
+      CQ_UNROLL for (int j = 0; j < 9; j++) c[i + j] += (uint64_t)x.a[i] * y.a[j];
+    }
+    CQ_UNROLL for (int i = 0; i < 9; i++) {
+      CQ_UNROLL for (int j = 0; j < 9; j++) c[i + j] += (uint64_t)z.a[i] * w.a[j];
+    }
+    CQ_UNROLL for (int i = 0; i < 9; i++) {
+      const uint32_t m = ((uint32_t)c[i] * NINV) & M29;
+      CQ_UNROLL for (int j = 0; j < 9; j++) c[i + j] += (uint64_t)m * pl(j);
+      c[i + 1] += c[i] >> 29;
+    }
+    Fp29 r;
+    CQ_UNROLL for (int k = 0; k < 8; k++) {
+      r.a[k] = (uint32_t)c[9 + k] & M29;
+      c[10 + k] += c[9 + k] >> 29;
+    }
+    r.a[8] = (uint32_t)c[17];
+    return r;
+  }
   __device__ __forceinline__ Fp29 operator*(const Fp29& o) const { return mul(*this, o); }
   __device__ __forceinline__ Fp29 sqr() const { return mul(*this, *this); }
 

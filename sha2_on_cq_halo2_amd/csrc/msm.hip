@@ -346,8 +346,11 @@ __global__ __launch_bounds__(MSM_ACC_THREADS) void msm_accumulate_kernel(
   const G1Affine* __restrict__ pts = bases[msm];
   const size_t table_stride = pre ? (size_t)table_strides[msm] : 0;
   const uint32_t r = j - off1[g];
-  const uint32_t lo = off0[g] + r * MSM_S1;
-  const uint32_t hi = min(off0[g] + cnt[g], lo + MSM_S1);
+  // the bucket's cnt entries are cut into t = ceil(cnt / MSM_S1) sub-lists of EQUAL length (+-1): a wave runs as
+  // long as its longest lane, so 40 entries are better served as 20 + 20 than as 32 + 8
+  const uint32_t t = t1[g], n_g = cnt[g];
+  const uint32_t lo = off0[g] + (uint32_t)(((uint64_t)n_g * r) / t);
+  const uint32_t hi = off0[g] + (uint32_t)(((uint64_t)n_g * (r + 1)) / t);
   XYZZ29 acc = XYZZ29::identity();
   // Software pipeline: the table point of entry e+1 (a dependent, essentially random 64-byte gather) and the
   // index of entry e+2 are requested before the ~10 products of entry e are computed.
@@ -385,7 +388,7 @@ __global__ __launch_bounds__(MSM_ACC_THREADS) void msm_accumulate_kernel(
     if (neg && !p.is_identity()) p.y = Fq29::neg<2>(p.y);
     xyzz29_add_affine(acc, p);
   }
-  store_xyzz29(t1[g] == 1 ? buckets + g : partial + j, acc);
+  store_xyzz29(t == 1 ? buckets + g : partial + j, acc);
 }
 
 // level k >= 2, long sub-lists: one WAVE per sub-list of <= MSM_S2 partial sums of level k-1
@@ -487,9 +490,9 @@ int msm_precompute_tables(cq_ctx* ctx, const G1Affine* bases, uint32_t n, uint32
 // Every dependent EC addition costs a wave ~5 us whatever the number of busy lanes, so the reduction is shaped
 // for depth, not work.  Buckets are read as a rows x cols matrix (b = cols * hi + lo + 1, cols = min(M, 128)):
 //     sum_b b B_b  =  cols * sum_hi hi R_hi  +  sum_lo (lo + 1) C_lo,     R = row sums, C = column sums.
-// Kernel 1: one WAVE per row / column sum (<= 2 buckets per lane, then a 6-level shuffle tree): rows + cols waves
-// per bucket set, all independent.  Kernel 2: per bucket set two waves, one per weighted sum of <= 128 terms
-// (pair sums, suffix scan by shuffles, one tree), joined through LDS.  ~7 + ~24 dependent operations instead of
+// Kernel 1: 16 lanes per row / column sum (<= 8 buckets per lane serially, then a 4-level shuffle tree), four lines
+// per wave, all independent.  Kernel 2: per bucket set two waves, one per weighted sum of <= 128 terms
+// (pair sums, suffix scan by shuffles, one tree), joined through LDS.  ~11 + ~24 dependent operations instead of
 // the ~46 of a lane-serial running sum over 1024-bucket groups.
 static __device__ __forceinline__ XYZZ29 wave_sum(XYZZ29 v) {
 #pragma unroll 1
@@ -500,19 +503,29 @@ static __device__ __forceinline__ XYZZ29 wave_sum(XYZZ29 v) {
   return v;  // lane 0 holds the sum
 }
 
+// A wave serves RC_LINES rows (or columns): RC_SEG lanes per line, each summing cols / RC_SEG consecutive buckets of
+// it serially (every lane busy), then a log2(RC_SEG)-level shuffle tree.  With one wave per line and a 6-level tree
+// only a quarter of the lane-operations were useful and the kernel was VALU-throughput bound at batch 16.
+constexpr uint32_t RC_SEG = 16, RC_LINES = 64 / RC_SEG;
 __global__ __launch_bounds__(64) void msm_rowcol_kernel(const XYZZ* __restrict__ buckets, uint32_t M, uint32_t rows, uint32_t cols,
                                                         XYZZ* __restrict__ sums /*[sets][rows + cols]*/) {
-  const uint32_t q = blockIdx.x, set = blockIdx.y, lane = threadIdx.x;
+  const uint32_t set = blockIdx.y, lane = threadIdx.x;
+  const uint32_t q = blockIdx.x * RC_LINES + lane / RC_SEG, seg = lane % RC_SEG;  // line: row q or column q - rows
   const XYZZ* Bk = buckets + (size_t)set * M;
   XYZZ29 acc = XYZZ29::identity();
   if (q < rows) {  // R_q = sum_lo B[q][lo]
-    for (uint32_t lo = lane; lo < cols; lo += 64) xyzz29_add(acc, load_xyzz29(Bk + (size_t)q * cols + lo));
-  } else {         // C_lo = sum_hi B[hi][lo]
-    const uint32_t lo = q - rows;
-    for (uint32_t hi = lane; hi < rows; hi += 64) xyzz29_add(acc, load_xyzz29(Bk + (size_t)hi * cols + lo));
+    const uint32_t per = (cols + RC_SEG - 1) / RC_SEG;
+    for (uint32_t lo = seg * per; lo < min(cols, (seg + 1) * per); lo++) xyzz29_add(acc, load_xyzz29(Bk + (size_t)q * cols + lo));
+  } else if (q < rows + cols) {  // C_lo = sum_hi B[hi][lo]
+    const uint32_t lo = q - rows, per = (rows + RC_SEG - 1) / RC_SEG;
+    for (uint32_t hi = seg * per; hi < min(rows, (seg + 1) * per); hi++) xyzz29_add(acc, load_xyzz29(Bk + (size_t)hi * cols + lo));
   }
-  acc = wave_sum(acc);
-  if (lane == 0) store_xyzz29(sums + (size_t)set * (rows + cols) + q, acc);
+#pragma unroll 1
+  for (int delta = RC_SEG / 2; delta >= 1; delta >>= 1) {
+    XYZZ29 o = xyzz29_shfl_down(acc, delta);  // lanes seg + delta >= RC_SEG read the next line's lanes: not used
+    if (seg + delta < RC_SEG) xyzz29_add(acc, o);
+  }
+  if (seg == 0 && q < rows + cols) store_xyzz29(sums + (size_t)set * (rows + cols) + q, acc);
 }
 
 // sum_{j < count} (j + first_weight) X_j over one wave, count <= 128; result in lane 0
@@ -672,7 +685,7 @@ int msm_run(cq_ctx* ctx, const Fr* const* scalars_host_ptrs, const G1Affine* con
     msm_combine_kernel<<<(uint32_t)((L.tmax[k] + 3) / 4), 256, 0, s>>>(part[(k - 1) & 1], t_prev, off_prev, t_cur, off_cur, Bt,
                                                                        part[k & 1], buckets);
   }
-  msm_rowcol_kernel<<<dim3(L.rows + L.cols, batch * L.Wb), 64, 0, s>>>(buckets, M, L.rows, L.cols, pairs);
+  msm_rowcol_kernel<<<dim3((L.rows + L.cols + RC_LINES - 1) / RC_LINES, batch * L.Wb), 64, 0, s>>>(buckets, M, L.rows, L.cols, pairs);
   msm_weighted_kernel<<<batch * L.Wb, 128, 0, s>>>(pairs, L.rows, L.cols, window_sums_dev);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }

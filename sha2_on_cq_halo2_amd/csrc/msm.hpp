@@ -11,12 +11,12 @@ namespace cq {
 constexpr uint32_t MSM_ACC_THREADS = 128;
 
 #ifndef CQ_MSM_S1
-#define CQ_MSM_S1 32
+#define CQ_MSM_S1 24
 #endif
 constexpr uint32_t MSM_S1 = CQ_MSM_S1;  // max point indices summed by one lane (level 1)
 constexpr uint32_t MSM_S2 = 256;        // max partial sums summed by one wave (levels >= 2)
 constexpr uint32_t MSM_SHORT = 64;       // level >= 2 lists up to this long are summed by one lane
-constexpr uint32_t MSM_MAX_BATCH = 16;  // MSMs per launch
+constexpr uint32_t MSM_MAX_BATCH = 32;  // MSMs per launch
 
 struct MsmPtrs {
   const void* p[MSM_MAX_BATCH];
