@@ -51,6 +51,7 @@ void cq_ctx_destroy(cq_ctx* c) {
   if (!c) return;
   hipSetDevice(c->device);
   hipStreamSynchronize(c->stream);
+  if (c->aux_stream) hipStreamSynchronize(c->aux_stream);
   c->ntt_cache.clear();
   for (int i = 0; i < cq_ctx::NSCRATCH; i++)
     if (c->scratch[i]) hipFree(c->scratch[i]);
@@ -59,6 +60,9 @@ void cq_ctx_destroy(cq_ctx* c) {
   if (c->prof_entries) hipHostFree(c->prof_entries);
   if (c->copy_done) hipEventDestroy(c->copy_done);
   if (c->copy_stream) hipStreamDestroy(c->copy_stream);
+  if (c->msm_tail_event) hipEventDestroy(c->msm_tail_event);
+  if (c->aux_done) hipEventDestroy(c->aux_done);
+  if (c->aux_stream) hipStreamDestroy(c->aux_stream);
   if (c->fb_table) hipFree(c->fb_table);
   for (auto& t : c->msm_tables) hipFree(t.table);
   if (c->own_stream) hipStreamDestroy(c->stream);

@@ -14,7 +14,7 @@ struct cq_ctx {
   bool own_stream = false;
   std::string err;
   std::vector<std::unique_ptr<cq::NttTables>> ntt_cache;
-  static constexpr int NSCRATCH = 8;
+  static constexpr int NSCRATCH = 10;
   void* scratch[NSCRATCH] = {};
   size_t scratch_bytes[NSCRATCH] = {};
   void* pinned = nullptr;  // small pinned host staging buffer
@@ -110,6 +110,27 @@ struct cq_ctx {
     if (e != hipSuccess) return hip_fail(e, "hipStreamCreate(copy)");
     e = hipEventCreateWithFlags(&copy_done, hipEventDisableTiming);
     if (e != hipSuccess) return hip_fail(e, "hipEventCreate(copy)");
+    return CQ_OK;
+  }
+  // Second compute stream (lowest priority).  An MSM ends in latency-bound kernels (partial-sum combines, row /
+  // column sums, weighted sums) that leave most of the GPU idle; the prover uses that time for transforms whose
+  // inputs are already fixed (prover.hip, AuxFork).  msm_run records `msm_tail_event` right after its accumulate
+  // kernel; work on `aux_stream` starts there; `aux_done` orders the main stream after it.  While the prover has
+  // `stream` pointed at the side stream, NTTs take their scratch from `ntt_scratch_slot` (a slot of their own).
+  hipStream_t aux_stream = nullptr;
+  hipEvent_t msm_tail_event = nullptr, aux_done = nullptr;
+  uint64_t msm_tail_seq = 0;
+  bool aux_pending = false;
+  int ntt_scratch_slot = 0;
+  int ensure_aux_stream() {
+    if (aux_stream) return CQ_OK;
+    int least = 0, greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+    hipError_t e = hipStreamCreateWithPriority(&aux_stream, hipStreamNonBlocking, least);
+    if (e != hipSuccess) return hip_fail(e, "hipStreamCreate(aux)");
+    e = hipEventCreateWithFlags(&msm_tail_event, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&aux_done, hipEventDisableTiming);
+    if (e != hipSuccess) return hip_fail(e, "hipEventCreate(aux)");
     return CQ_OK;
   }
   void* pinned_msm = nullptr;  // MSM results (kept apart from `pinned`, which stages RNG words)

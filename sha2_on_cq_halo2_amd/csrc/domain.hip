@@ -64,7 +64,7 @@ static int run(cq_ctx* c, uint32_t log_n, const Fr& omega, const Fr* in, Fr* out
   if (!tb) return rc;
   const size_t n = (size_t)1 << log_n;
   void* scr;
-  if ((rc = c->ensure_scratch(0, (size_t)2 * io.batch * n * sizeof(Fr), &scr)) != CQ_OK) return rc;
+  if ((rc = c->ensure_scratch(c->ntt_scratch_slot, (size_t)2 * io.batch * n * sizeof(Fr), &scr)) != CQ_OK) return rc;
   io.prof = c;
   if (ntt_run(*tb, in, out, (Fr*)scr, io, c->stream) != 0) return c->fail(CQ_ERR_HIP, "ntt launch failed");
   return CQ_OK;

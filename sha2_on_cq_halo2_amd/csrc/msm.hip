@@ -9,27 +9,29 @@
 // (msm, window, bucket) triple is one entry of a flat bucket array, so the batch only adds
 // parallelism.  GPU pipeline, all on one stream:
 //   1. digits    : scalar -> canonical (one Montgomery reduction) -> SIGNED c-bit digits (halves the bucket
-//                  count) and the histogram.  Table mode: per-block LDS histogram of 8192 scalars, one device
-//                  atomic per non-empty bucket per block (device-scope atomics on the small counter array are
-//                  the throughput limit otherwise); plain mode: one atomic per entry, issued back to back.
-//                  The value an atomic returns is the entry's rank inside its bucket.
-//   2. plan      : exclusive scans of the histogram (reduce / spine / apply): where each bucket's
-//                  index list starts, and how many bounded sub-lists it is cut into per level.
-//   3. scatter   : entries dropped at list start + rank; sign kept in bit 31, window in bits 26..30.
+//                  count).  An entry = (point, window, sign) of a non-zero digit; its bucket = |digit| - 1.
+//   2. sort      : counting sort of the entries by bucket.  Table mode: two passes through LDS (partition = bucket
+//                  >> 7, then bucket), every global write a run of consecutive entries -- see "Precomputed-table
+//                  mode" below.  Plain mode: one device atomic per entry (issued back to back) whose return value
+//                  is the entry's rank, then a scatter to list start + rank.
+//   3. plan      : exclusive scans of the histogram (reduce / spine / apply): where each bucket's index list
+//                  starts, and how many bounded sub-lists it is cut into per level.
 //   4. accumulate: level 1 -- one lane per sub-list of <= MSM_S1 entries gathers affine points (64 B each, from
 //                  the per-window tables or the caller's array) into an XYZZ accumulator (8M+2S per mixed add,
 //                  no inversion) on the lazy 9x29-bit field (curve29.hpp); the next point's gather is in flight
-//                  while the current addition runs.  Levels >= 2: one LANE per short list of partial sums, one
-//                  WAVE per long one (strided lane sums + 6-step shuffle tree).  A bucket is written as soon
+//                  while the current addition runs.  Levels >= 2: one to four LANES per short list of partial sums
+//                  (indexed by bucket), one WAVE per long one (strided lane sums + 6-step shuffle tree).  A bucket is written as soon
 //                  as one lane/wave owns all of it.  Bounding the per-lane work keeps the kernel balanced for
 //                  skewed digit distributions (0/1 selector columns, SHA limb columns) where a lane-per-bucket
 //                  kernel would serialise on one huge bucket.  256-bit modular integer work: VALU-bound, MFMA
 //                  does not apply.
-//   5. reduce    : sum_b b*B_b per bucket set, shaped for depth: buckets as a rows x cols matrix, one wave per
+//   5. reduce    : sum_b b*B_b per bucket set, shaped for depth: buckets as a rows x cols matrix, 16 lanes per
 //                  row / column sum, then two weighted wave sums (the reference does this serially,
 //                  arithmetic.rs:95-99).
 //   6. host      : table mode returns one Jacobian point per MSM; plain mode W window sums per MSM, folded by a
 //                  Horner over windows (c doublings each) on the host.
+#include <algorithm>
+#include <cstdlib>
 #include "msm.hpp"
 #include "curve29.hpp"
 #include "ctx.hpp"
@@ -141,68 +143,227 @@ __global__ __launch_bounds__(256) void msm_digits_kernel(const Fr* const* __rest
   }
 }
 
-// Precomputed-table mode (one bucket set of M <= 2^14 counters per MSM): the histogram of a chunk of scalars is
-// built in LDS first, so the device-scope atomics -- the throughput limit of the kernel above, every one of them
-// lands on the same few hundred cache lines -- drop from one per (scalar, window) to one per non-empty bucket per
-// block.  Pass 1 counts in LDS; each non-empty bucket then reserves its range with ONE global atomic and the LDS
-// counter becomes that range's cursor; pass 2 hands out the ranks from the cursors.
-constexpr uint32_t DIGITS_LDS_THREADS = 1024;
+// Precomputed-table mode (one bucket set of M = 2^14 buckets per MSM): a two-pass (MSD) counting sort.
+//
+// A single-pass sort drops every 4-byte entry at a random place of its MSM's list array; the L2 evicts those as
+// 32-byte partial writes (measured: 32 B of write traffic per entry, 1.3 TB/s, twice that only while a whole launch
+// fits the 256 MB memory-side cache), and the per-entry rank array costs another 8 B.  Here every pass writes runs:
+//   a. part_hist    : per chunk of 2048 scalars, LDS histogram of the entries' PARTITION (bucket >> 7: 128
+//                     partitions of 128 buckets per MSM); one device atomic per (chunk, partition).
+//   b. part_scan    : exclusive scan of the partition sizes (<= 32 x 128 values, one block).
+//   c. part_scatter : same chunks; each reserves its range in every partition with one device atomic and writes
+//                     (payload, bucket) pairs there -- 128 open runs of ~270 entries per workgroup, which the
+//                     L2 merges into full lines.
+//   d. bucket_count : per partition, LDS histogram of its 128 buckets -> the global bucket counts (the plan's input).
+//   e. bucket_place : after the plan: per tile of 4096 entries of a partition, LDS histogram, one device atomic
+//                     per non-empty bucket to reserve the tile's run inside the bucket's list, entries written
+//                     there (runs of ~32 entries).  PART_SPLIT workgroups share a partition tile by tile.
+#ifndef CQ_PART_CHUNK_THREADS
+#define CQ_PART_CHUNK_THREADS 256
+#endif
+constexpr uint32_t DIGITS_LDS_THREADS = CQ_PART_CHUNK_THREADS;
 constexpr uint32_t DIGITS_LDS_PER_LANE = 8;
 constexpr uint32_t DIGITS_LDS_CHUNK = DIGITS_LDS_THREADS * DIGITS_LDS_PER_LANE;
 constexpr uint32_t DIGITS_LDS_MAX_M = 1u << 14;
-__global__ __launch_bounds__(DIGITS_LDS_THREADS) void msm_digits_lds_kernel(const Fr* const* __restrict__ scalars,
-                                                                            const uint64_t* __restrict__ lens, uint32_t nmax,
-                                                                            uint32_t c, uint32_t nwin, uint32_t* __restrict__ ranks,
-                                                                            uint32_t* __restrict__ counts) {
-  __shared__ uint32_t hist[DIGITS_LDS_MAX_M];
+constexpr uint32_t PART_BITS = 7, PART_BUCKETS = 1u << PART_BITS;  // buckets per partition
+constexpr uint32_t PART_MAX = DIGITS_LDS_MAX_M >> PART_BITS;          // partitions per MSM
+constexpr uint32_t PART_THREADS = 256, PART_PER_LANE = 16, PART_TILE = PART_THREADS * PART_PER_LANE;
+constexpr uint32_t PART_SPLIT = 8;  // workgroups per partition in the bucket passes
+static_assert(PART_MAX == 128 && PART_BUCKETS == 128 && PART_MAX <= DIGITS_LDS_THREADS && PART_BUCKETS <= PART_THREADS, "one thread per histogram bin; wave0_scan128");
+
+__global__ __launch_bounds__(DIGITS_LDS_THREADS) void msm_part_hist_kernel(const Fr* const* __restrict__ scalars,
+                                                                           const uint64_t* __restrict__ lens, uint32_t c, uint32_t nwin,
+                                                                           uint32_t npart, uint32_t* __restrict__ psize) {
+  __shared__ uint32_t hist[PART_MAX];
   const uint32_t m = blockIdx.y, t = threadIdx.x;
-  const uint32_t M = 1u << (c - 1);
   const uint32_t len = (uint32_t)lens[m];
   const uint32_t base = blockIdx.x * DIGITS_LDS_CHUNK;
   if (base >= len) return;  // block-uniform
-  for (uint32_t b = t; b < M; b += DIGITS_LDS_THREADS) hist[b] = 0;
-  U256 v[DIGITS_LDS_PER_LANE];
-#pragma unroll
+  if (t < npart) hist[t] = 0;
+  __syncthreads();
   for (uint32_t k = 0; k < DIGITS_LDS_PER_LANE; k++) {
     const uint32_t i = base + k * DIGITS_LDS_THREADS + t;
-    if (i < len) v[k] = scalars[m][i].to_canonical();
-    else for (int q = 0; q < 8; q++) v[k].l[q] = 0;  // zero scalar: no non-zero digit
-  }
-  __syncthreads();
-#pragma unroll
-  for (uint32_t k = 0; k < DIGITS_LDS_PER_LANE; k++) {
+    if (i >= len) continue;
+    const U256 v = scalars[m][i].to_canonical();
     uint32_t carry = 0, neg;
     for (uint32_t w = 0; w < nwin; w++) {
-      const uint32_t d = signed_digit(v[k], w, c, carry, neg);
-      if (d) atomicAdd(&hist[d - 1], 1u);
+      const uint32_t d = signed_digit(v, w, c, carry, neg);
+      if (d) atomicAdd(&hist[(d - 1) >> PART_BITS], 1u);
     }
   }
   __syncthreads();
-  uint32_t* cnt = counts + (size_t)m * M;
-  for (uint32_t b = t; b < M; b += DIGITS_LDS_THREADS) {
-    const uint32_t h = hist[b];
-    if (h) hist[b] = atomicAdd(&cnt[b], h);
-  }
+  if (t < npart && hist[t]) atomicAdd(&psize[m * npart + t], hist[t]);
+}
+
+// exclusive scan of P <= 4096 values in one block: poff[0..P], poff[P] = total
+__global__ __launch_bounds__(1024) void msm_part_scan_kernel(const uint32_t* __restrict__ psize, uint32_t P, uint32_t* __restrict__ poff) {
+  __shared__ uint32_t part[1024];
+  const uint32_t per = (P + 1023) / 1024;
+  const uint32_t lo = min(threadIdx.x * per, P), hi = min(lo + per, P);
+  uint32_t s = 0;
+  for (uint32_t j = lo; j < hi; j++) s += psize[j];
+  part[threadIdx.x] = s;
   __syncthreads();
+  for (uint32_t off = 1; off < 1024; off <<= 1) {
+    const uint32_t v = threadIdx.x >= off ? part[threadIdx.x - off] : 0;
+    __syncthreads();
+    part[threadIdx.x] += v;
+    __syncthreads();
+  }
+  uint32_t run = part[threadIdx.x] - s;
+  for (uint32_t j = lo; j < hi; j++) {
+    poff[j] = run;
+    run += psize[j];
+  }
+  if (threadIdx.x == 1023) poff[P] = part[1023];
+}
+
+// exclusive scan of the PART_MAX (= 128) histogram bins by the first wave: lane l owns bins 2l and 2l + 1
+static __device__ __forceinline__ void wave0_scan128(const uint32_t* __restrict__ hist, uint32_t* __restrict__ start) {
+  const uint32_t l = threadIdx.x;
+  if (l >= 64) return;
+  const uint32_t a = hist[2 * l], b = hist[2 * l + 1];
+  uint32_t incl = a + b;
 #pragma unroll
-  for (uint32_t k = 0; k < DIGITS_LDS_PER_LANE; k++) {
-    const uint32_t i = base + k * DIGITS_LDS_THREADS + t;
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t o = __shfl_up(incl, d, 64);
+    if ((int)l >= d) incl += o;
+  }
+  start[2 * l] = incl - (a + b);
+  start[2 * l + 1] = incl - b;
+}
+
+// One scalar per lane; the chunk's entries are sorted by partition in LDS first, so that the write-out is a linear
+// copy of runs (~34 entries = 272 B per partition) instead of one uncoalesced 8-byte store per entry (which kept the
+// per-CU memory pipeline, not HBM, busy for 0.5 ms on a 21-MSM launch).
+constexpr uint32_t PSC_THREADS = 256, PSC_MAX_WIN = 17;
+__global__ __launch_bounds__(PSC_THREADS) void msm_part_scatter_kernel(const Fr* const* __restrict__ scalars,
+                                                                       const uint64_t* __restrict__ lens, uint32_t c, uint32_t nwin,
+                                                                       uint32_t npart, const uint32_t* __restrict__ poff,
+                                                                       uint32_t* __restrict__ pcursor, uint2* __restrict__ part_buf) {
+  __shared__ uint2 stage[PSC_THREADS * PSC_MAX_WIN];
+  __shared__ uint32_t hist[PART_MAX], lstart[PART_MAX], gbase[PART_MAX];
+  const uint32_t m = blockIdx.y, t = threadIdx.x;
+  const uint32_t len = (uint32_t)lens[m];
+  const uint32_t i = blockIdx.x * PSC_THREADS + t;
+  if (blockIdx.x * PSC_THREADS >= len) return;  // block-uniform
+  if (t < PART_MAX) hist[t] = 0;
+  U256 v;
+  if (i < len) v = scalars[m][i].to_canonical();
+  else for (int q = 0; q < 8; q++) v.l[q] = 0;  // zero scalar: no non-zero digit
+  __syncthreads();
+  {
     uint32_t carry = 0, neg;
     for (uint32_t w = 0; w < nwin; w++) {
-      const uint32_t d = signed_digit(v[k], w, c, carry, neg);
-      if (d) ranks[((size_t)m * nwin + w) * nmax + i] = atomicAdd(&hist[d - 1], 1u);
+      const uint32_t d = signed_digit(v, w, c, carry, neg);
+      if (d) atomicAdd(&hist[(d - 1) >> PART_BITS], 1u);
     }
+  }
+  __syncthreads();
+  wave0_scan128(hist, lstart);
+  if (t < npart) {
+    const uint32_t h = hist[t];
+    gbase[t] = h ? poff[m * npart + t] + atomicAdd(&pcursor[m * npart + t], h) : 0u;
+  }
+  __syncthreads();
+  const uint32_t total = lstart[PART_MAX - 1] + hist[PART_MAX - 1];
+  __syncthreads();
+  if (t < PART_MAX) hist[t] = 0;
+  __syncthreads();
+  {
+    uint32_t carry = 0, neg;
+    for (uint32_t w = 0; w < nwin; w++) {
+      const uint32_t d = signed_digit(v, w, c, carry, neg);
+      if (!d) continue;
+      const uint32_t pt = (d - 1) >> PART_BITS;
+      // entry: point index (26 bits) | window << 26 | sign << 31, and the bucket inside the MSM
+      stage[lstart[pt] + atomicAdd(&hist[pt], 1u)] = make_uint2(i | (w << 26) | (neg << 31), d - 1);
+    }
+  }
+  __syncthreads();
+  for (uint32_t j = t; j < total; j += PSC_THREADS) {
+    const uint2 e = stage[j];
+    const uint32_t pt = e.y >> PART_BITS;
+    part_buf[gbase[pt] + (j - lstart[pt])] = e;
+  }
+}
+
+// partition pid = msm * npart + p owns the flat buckets [pid << PART_BITS, (pid + 1) << PART_BITS)
+__global__ __launch_bounds__(PART_THREADS) void msm_bucket_count_kernel(const uint2* __restrict__ part_buf, const uint32_t* __restrict__ poff,
+                                                                        uint32_t* __restrict__ counts) {
+  __shared__ uint32_t hist[PART_BUCKETS];
+  const uint32_t pid = blockIdx.x, t = threadIdx.x;
+  const uint32_t lo = poff[pid], hi = poff[pid + 1];
+  if (lo + blockIdx.y * PART_THREADS >= hi) return;  // block-uniform
+  if (t < PART_BUCKETS) hist[t] = 0;
+  __syncthreads();
+  for (uint32_t e = lo + blockIdx.y * PART_THREADS + t; e < hi; e += PART_SPLIT * PART_THREADS)
+    atomicAdd(&hist[part_buf[e].y & (PART_BUCKETS - 1)], 1u);
+  __syncthreads();
+  if (t < PART_BUCKETS && hist[t]) atomicAdd(&counts[(pid << PART_BITS) + t], hist[t]);
+}
+
+// Same idea one level down: a tile's entries are sorted by bucket in LDS, then copied out run by run (~32 entries =
+// one 128-byte line per bucket and tile).
+__global__ __launch_bounds__(PART_THREADS) void msm_bucket_place_kernel(const uint2* __restrict__ part_buf, const uint32_t* __restrict__ poff,
+                                                                        const uint32_t* __restrict__ off0, uint32_t* __restrict__ cursor,
+                                                                        uint32_t* __restrict__ sorted) {
+  __shared__ uint32_t hist[PART_BUCKETS], lstart[PART_BUCKETS], base[PART_BUCKETS];
+  __shared__ uint32_t spay[PART_TILE];
+  __shared__ uint8_t sbkt[PART_TILE];
+  const uint32_t pid = blockIdx.x, t = threadIdx.x;
+  const uint32_t lo = poff[pid], hi = poff[pid + 1];
+  const uint32_t ntiles = (hi - lo + PART_TILE - 1) / PART_TILE;
+  for (uint32_t tile = blockIdx.y; tile < ntiles; tile += PART_SPLIT) {  // block-uniform trip count
+    const uint32_t tlo = lo + tile * PART_TILE, thi = min(hi, tlo + PART_TILE);
+    if (t < PART_BUCKETS) hist[t] = 0;
+    __syncthreads();
+    uint2 ent[PART_PER_LANE];
+#pragma unroll
+    for (uint32_t k = 0; k < PART_PER_LANE; k++) {
+      const uint32_t e = tlo + k * PART_THREADS + t;
+      if (e < thi) {
+        ent[k] = part_buf[e];
+        atomicAdd(&hist[ent[k].y & (PART_BUCKETS - 1)], 1u);
+      }
+    }
+    __syncthreads();
+    wave0_scan128(hist, lstart);
+    if (t < PART_BUCKETS) {
+      const uint32_t h = hist[t], g = (pid << PART_BITS) + t;
+      base[t] = h ? off0[g] + atomicAdd(&cursor[g], h) : 0u;
+    }
+    __syncthreads();
+    if (t < PART_BUCKETS) hist[t] = 0;
+    __syncthreads();
+#pragma unroll
+    for (uint32_t k = 0; k < PART_PER_LANE; k++) {
+      const uint32_t e = tlo + k * PART_THREADS + t;
+      if (e < thi) {
+        const uint32_t b = ent[k].y & (PART_BUCKETS - 1);
+        const uint32_t lp = lstart[b] + atomicAdd(&hist[b], 1u);
+        spay[lp] = ent[k].x;
+        sbkt[lp] = (uint8_t)b;
+      }
+    }
+    __syncthreads();
+    for (uint32_t j = t; j < thi - tlo; j += PART_THREADS) {
+      const uint32_t b = sbkt[j];
+      sorted[base[b] + (j - lstart[b])] = spay[j];
+    }
+    __syncthreads();
   }
 }
 
 // ---- 2. plan: exclusive scans over the flat bucket array -----------------------------------------
 // Sequence 0 is the histogram itself (-> list start of every bucket); sequence k >= 1 is the
-// number of level-k sub-lists of every bucket: t1 = ceil(cnt/S1), t_k = ceil(t_{k-1}/S2) while
-// t_{k-1} > 1, else 0 (the bucket was finished at level k-1).
+// number of level-k sub-lists of every bucket: t1 = ceil(cnt/S1); t_k = ceil(t_{k-1}/S2) while t_{k-1} > MSM_SHORT,
+// else 0: a bucket with 2..MSM_SHORT partial sums is finished by msm_combine_short_kernel, which is indexed by
+// bucket and needs no slot; one with a single partial sum was written to its bucket by the level before.
 static __device__ __forceinline__ uint32_t level_value(uint32_t cnt, uint32_t lv) {
   if (lv == 0) return cnt;
   uint32_t t = (cnt + MSM_S1 - 1) / MSM_S1;
-  for (uint32_t k = 2; k <= lv; k++) t = t <= 1 ? 0 : (t + MSM_S2 - 1) / MSM_S2;
+  for (uint32_t k = 2; k <= lv; k++) t = t <= MSM_SHORT ? 0 : (t + MSM_S2 - 1) / MSM_S2;
   return t;
 }
 
@@ -391,8 +552,9 @@ __global__ __launch_bounds__(MSM_ACC_THREADS) void msm_accumulate_kernel(
   store_xyzz29(t == 1 ? buckets + g : partial + j, acc);
 }
 
-// level k >= 2, long sub-lists: one WAVE per sub-list of <= MSM_S2 partial sums of level k-1
-// (buckets whose level k-1 count is <= MSM_SHORT are left to msm_combine_short_kernel)
+// level k >= 2, long lists (more than MSM_SHORT partial sums of level k-1 -- 0/1 columns, sparse top windows): one
+// WAVE per sub-list of <= MSM_S2 of them.  Only these lists have slots at level k, so off_cur[Bt] is small (usually
+// zero) and almost every wave of the grid leaves at the first test.
 __global__ __launch_bounds__(256) void msm_combine_kernel(
     const XYZZ* __restrict__ prev, const uint32_t* __restrict__ t_prev, const uint32_t* __restrict__ off_prev,
     const uint32_t* __restrict__ t_cur, const uint32_t* __restrict__ off_cur, uint32_t Bt, XYZZ* __restrict__ partial,
@@ -402,7 +564,6 @@ __global__ __launch_bounds__(256) void msm_combine_kernel(
   if (j >= off_cur[Bt]) return;
   const uint32_t g = owner_of(off_cur, Bt, j);
   const uint32_t tp = t_prev[g];
-  if (tp <= MSM_SHORT) return;
   const uint32_t r = j - off_cur[g];
   const uint32_t lo = off_prev[g] + r * MSM_S2;
   const uint32_t hi = min(off_prev[g] + tp, lo + MSM_S2);
@@ -416,32 +577,30 @@ __global__ __launch_bounds__(256) void msm_combine_kernel(
   if (lane == 0) store_xyzz29(t_cur[g] == 1 ? buckets + g : partial + j, acc);
 }
 
-// level k >= 2, short sub-lists (<= MSM_SHORT partial sums, always the whole bucket): FOUR lanes each -- the
-// additions of one list are dependent, so a quad sums strided quarters and folds them with two shuffles
-// (depth tp/4 + 2 instead of tp)
-constexpr uint32_t COMBINE_QUAD = 4;
+// level k >= 2, short lists (2..MSM_SHORT partial sums, always the whole bucket): Q lanes per BUCKET.  The additions
+// of one list are dependent, so with few buckets (a launch of one or two MSMs is latency-bound) a quad sums strided
+// quarters and folds them with two shuffles (depth tp/4 + 2 instead of tp); a launch with hundreds of thousands of
+// buckets is throughput-bound and uses one lane per bucket (no idle shuffle levels).  Indexed by bucket: no search,
+// and a bucket that is empty, already final (one partial sum) or long costs one load.
+template <uint32_t Q>
 __global__ __launch_bounds__(MSM_ACC_THREADS) void msm_combine_short_kernel(
-    const XYZZ* __restrict__ prev, const uint32_t* __restrict__ t_prev, const uint32_t* __restrict__ off_prev,
-    const uint32_t* __restrict__ off_cur, uint32_t Bt, XYZZ* __restrict__ buckets) {
+    const XYZZ* __restrict__ prev, const uint32_t* __restrict__ t_prev, const uint32_t* __restrict__ off_prev, uint32_t Bt,
+    XYZZ* __restrict__ buckets) {
   const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x;
-  const uint32_t j = gt / COMBINE_QUAD, sub = gt % COMBINE_QUAD;
-  const bool live = j < off_cur[Bt];
-  uint32_t g = 0, tp = 0, lo = 0;
-  if (live) {
-    g = owner_of(off_cur, Bt, j);
-    tp = t_prev[g];
-    lo = off_prev[g];
-  }
-  const bool mine = live && tp <= MSM_SHORT;
+  const uint32_t g = gt / Q, sub = gt % Q;
+  const uint32_t tp = g < Bt ? t_prev[g] : 0;
+  const bool mine = tp >= 2 && tp <= MSM_SHORT;
+  if (!__any(mine)) return;  // wave-uniform
+  const uint32_t lo = mine ? off_prev[g] : 0;
   XYZZ29 acc = XYZZ29::identity();
   if (mine)
-    for (uint32_t e = sub; e < tp; e += COMBINE_QUAD) xyzz29_add(acc, load_xyzz29(prev + lo + e));
+    for (uint32_t e = sub; e < tp; e += Q) xyzz29_add(acc, load_xyzz29(prev + lo + e));
 #pragma unroll 1
-  for (int delta = COMBINE_QUAD / 2; delta >= 1; delta >>= 1) {
+  for (int delta = Q / 2; delta >= 1; delta >>= 1) {
     XYZZ29 o = xyzz29_shfl_down(acc, delta);  // all lanes take part in the shuffle
-    if (mine && sub + delta < COMBINE_QUAD) xyzz29_add(acc, o);
+    if (mine && sub + delta < Q) xyzz29_add(acc, o);
   }
-  if (mine && sub == 0) store_xyzz29(buckets + g, acc);  // tp <= MSM_SHORT <= MSM_S2  =>  t_cur[g] == 1
+  if (mine && sub == 0) store_xyzz29(buckets + g, acc);
 }
 
 // ---- precomputed window tables (one-off setup) -----------------------------------------------------------
@@ -601,21 +760,25 @@ MsmLayout::MsmLayout(uint32_t n_, uint32_t c_, uint32_t batch_, bool pre_) : n(n
   const uint64_t E = (uint64_t)batch * W * n;  // upper bound on (point,digit) entries
   size_t o = 0;
   off_ptrs = o;    o = up(o + (size_t)4 * batch * sizeof(void*));
-  off_ranks = o;   o = up(o + (size_t)E * sizeof(uint32_t));
+  // table mode: (payload, bucket) pairs of the partition pass; plain mode: one rank per entry
+  part_sort = pre && M <= DIGITS_LDS_MAX_M && M >= PART_BUCKETS && W <= PSC_MAX_WIN;
+  npart = part_sort ? M >> PART_BITS : 0;
+  off_ranks = o;   o = up(o + (size_t)E * (part_sort ? sizeof(uint2) : sizeof(uint32_t)));
+  off_poff = o;    o = up(o + ((size_t)batch * npart + 1) * sizeof(uint32_t));
   off_counts = o;  o = up(o + (size_t)Bt * sizeof(uint32_t));
+  off_cursor = o;  o = up(o + (part_sort ? (size_t)Bt : 0) * sizeof(uint32_t));        // per-bucket fill cursors
+  off_psize = o;   o = up(o + (size_t)2 * batch * npart * sizeof(uint32_t));          // partition sizes, cursors
   off_buckets = o; o = up(o + (size_t)Bt * sizeof(XYZZ));  // counts..buckets zeroed by one memset
   zero_end = o;
   off_blocksums = o; o = up(o + (size_t)nseq * nblk * sizeof(uint32_t));
   off_off = o;     o = up(o + (size_t)nseq * (Bt + 1) * sizeof(uint32_t));
   off_tk = o;      o = up(o + (size_t)levels * Bt * sizeof(uint32_t));
   off_sorted = o;  o = up(o + (size_t)E * sizeof(uint32_t));
-  // partial sums: level k has at most ceil(items_{k-1}/S) + Bt sub-lists
-  uint64_t cap = (E + MSM_S1 - 1) / MSM_S1;
+  // partial sums: level 1 has at most ceil(E/S1) + Bt sub-lists; level k >= 2 only serves lists of more than
+  // MSM_SHORT items, so at most items/S2 + items/SHORT + 1 sub-lists
   for (uint32_t k = 0; k < 8; k++) tmax[k] = 0;
-  for (uint32_t k = 0; k < levels; k++) {
-    tmax[k] = cap + Bt;
-    cap = (tmax[k] + MSM_S2 - 1) / MSM_S2;
-  }
+  tmax[0] = (E + MSM_S1 - 1) / MSM_S1 + Bt;
+  for (uint32_t k = 1; k < levels; k++) tmax[k] = tmax[k - 1] / MSM_S2 + tmax[k - 1] / MSM_SHORT + 1;
   off_part[0] = o;
   o = up(o + (size_t)tmax[0] * sizeof(XYZZ));
   off_part[1] = o;
@@ -658,30 +821,52 @@ int msm_run(cq_ctx* ctx, const Fr* const* scalars_host_ptrs, const G1Affine* con
   const uint64_t* d_lens = (const uint64_t*)((const void**)d_scalars + 3 * batch);
   // counts and buckets (identity = all zero) are adjacent: one memset
   if (hipMemsetAsync(counts, 0, L.zero_end - L.off_counts, s) != hipSuccess) return -1;
-  if (pre && M <= DIGITS_LDS_MAX_M)
-    msm_digits_lds_kernel<<<dim3((n + DIGITS_LDS_CHUNK - 1) / DIGITS_LDS_CHUNK, batch), DIGITS_LDS_THREADS, 0, s>>>(d_scalars, d_lens, n, c, W,
-                                                                                                                  ranks, counts);
-  else
-    msm_digits_kernel<<<dim3((n + 255) / 256, batch), 256, 0, s>>>(d_scalars, d_lens, n, c, W, pre ? 1u : 0u, ranks, counts);
-  msm_scan_reduce_kernel<<<L.nblk, 256, 0, s>>>(counts, Bt, L.nseq, blocksums);
-  msm_scan_spine_kernel<<<1, 1024, 0, s>>>(blocksums, L.nblk, L.nseq);
-  msm_scan_apply_kernel<<<L.nblk, 256, 0, s>>>(counts, Bt, L.nseq, blocksums, off, tk);
   const uint32_t* off0 = off;
-  msm_scatter_kernel<<<dim3((n + 255) / 256, batch), 256, 0, s>>>(d_scalars, d_lens, n, c, W, pre ? 1u : 0u, ranks, off0, sorted);
+  if (L.part_sort) {
+    const uint32_t P = batch * L.npart;
+    uint2* part_buf = (uint2*)(ws + L.off_ranks);
+    uint32_t* poff = (uint32_t*)(ws + L.off_poff);
+    uint32_t* cursor = (uint32_t*)(ws + L.off_cursor);
+    uint32_t* psize = (uint32_t*)(ws + L.off_psize);
+    uint32_t* pcursor = psize + P;
+    const dim3 chunks((n + DIGITS_LDS_CHUNK - 1) / DIGITS_LDS_CHUNK, batch);
+    msm_part_hist_kernel<<<chunks, DIGITS_LDS_THREADS, 0, s>>>(d_scalars, d_lens, c, W, L.npart, psize);
+    msm_part_scan_kernel<<<1, 1024, 0, s>>>(psize, P, poff);
+    msm_part_scatter_kernel<<<dim3((n + PSC_THREADS - 1) / PSC_THREADS, batch), PSC_THREADS, 0, s>>>(d_scalars, d_lens, c, W, L.npart, poff, pcursor,
+                                                                                                     part_buf);
+    msm_bucket_count_kernel<<<dim3(P, PART_SPLIT), PART_THREADS, 0, s>>>(part_buf, poff, counts);
+    msm_scan_reduce_kernel<<<L.nblk, 256, 0, s>>>(counts, Bt, L.nseq, blocksums);
+    msm_scan_spine_kernel<<<1, 1024, 0, s>>>(blocksums, L.nblk, L.nseq);
+    msm_scan_apply_kernel<<<L.nblk, 256, 0, s>>>(counts, Bt, L.nseq, blocksums, off, tk);
+    msm_bucket_place_kernel<<<dim3(P, PART_SPLIT), PART_THREADS, 0, s>>>(part_buf, poff, off0, cursor, sorted);
+  } else {
+    msm_digits_kernel<<<dim3((n + 255) / 256, batch), 256, 0, s>>>(d_scalars, d_lens, n, c, W, pre ? 1u : 0u, ranks, counts);
+    msm_scan_reduce_kernel<<<L.nblk, 256, 0, s>>>(counts, Bt, L.nseq, blocksums);
+    msm_scan_spine_kernel<<<1, 1024, 0, s>>>(blocksums, L.nblk, L.nseq);
+    msm_scan_apply_kernel<<<L.nblk, 256, 0, s>>>(counts, Bt, L.nseq, blocksums, off, tk);
+    msm_scatter_kernel<<<dim3((n + 255) / 256, batch), 256, 0, s>>>(d_scalars, d_lens, n, c, W, pre ? 1u : 0u, ranks, off0, sorted);
+  }
   if (ctx->prof_on && ctx->prof_entries && ctx->prof_entries_n < cq_ctx::PROF_COUNTERS)
     (void)hipMemcpyAsync(ctx->prof_entries + ctx->prof_entries_n++, off0 + Bt, sizeof(uint32_t), hipMemcpyDeviceToHost, s);
   hipEvent_t pe = ctx->prof_begin(CQ_PROF_MSM_ACCUMULATE);
   msm_accumulate_kernel<<<(uint32_t)((L.tmax[0] + MSM_ACC_THREADS - 1) / MSM_ACC_THREADS), MSM_ACC_THREADS, 0, s>>>(
       d_bases, L.B, pre ? 1u : 0u, d_strides, sorted, counts, off0, tk, off + (size_t)(Bt + 1), Bt, part[0], buckets);
   ctx->prof_end(pe);
+  if (ctx->msm_tail_event) {  // from here on the launch is latency-bound: side-stream work may start (ctx.hpp)
+    (void)hipEventRecord(ctx->msm_tail_event, s);
+    ctx->msm_tail_seq++;
+  }
   for (uint32_t k = 1; k < L.levels; k++) {
     const uint32_t* t_prev = tk + (size_t)(k - 1) * Bt;
     const uint32_t* off_prev = off + (size_t)k * (Bt + 1);
     const uint32_t* t_cur = tk + (size_t)k * Bt;
     const uint32_t* off_cur = off + (size_t)(k + 1) * (Bt + 1);
     // ping-pong: level k+1 reads part[(k-1)&1], writes part[k&1]; one wave per sub-list
-    msm_combine_short_kernel<<<(uint32_t)((L.tmax[k] * COMBINE_QUAD + MSM_ACC_THREADS - 1) / MSM_ACC_THREADS), MSM_ACC_THREADS, 0, s>>>(
-        part[(k - 1) & 1], t_prev, off_prev, off_cur, Bt, buckets);
+    const uint32_t q = Bt <= (1u << 15) ? 4u : Bt <= (1u << 17) ? 2u : 1u;  // lanes per bucket, see the kernel
+    const uint32_t cs_blocks = (uint32_t)(((uint64_t)Bt * q + MSM_ACC_THREADS - 1) / MSM_ACC_THREADS);
+    if (q == 4) msm_combine_short_kernel<4><<<cs_blocks, MSM_ACC_THREADS, 0, s>>>(part[(k - 1) & 1], t_prev, off_prev, Bt, buckets);
+    else if (q == 2) msm_combine_short_kernel<2><<<cs_blocks, MSM_ACC_THREADS, 0, s>>>(part[(k - 1) & 1], t_prev, off_prev, Bt, buckets);
+    else msm_combine_short_kernel<1><<<cs_blocks, MSM_ACC_THREADS, 0, s>>>(part[(k - 1) & 1], t_prev, off_prev, Bt, buckets);
     msm_combine_kernel<<<(uint32_t)((L.tmax[k] + 3) / 4), 256, 0, s>>>(part[(k - 1) & 1], t_prev, off_prev, t_cur, off_cur, Bt,
                                                                        part[k & 1], buckets);
   }

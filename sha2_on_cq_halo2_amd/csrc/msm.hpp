@@ -27,10 +27,10 @@ struct MsmStrides {
 
 // Workspace carve-up for `batch` MSMs of n terms each with c-bit signed windows.
 struct MsmLayout {
-  uint32_t n, c, batch, W, Wb, M, B, Bt, levels, nseq, nblk, rows, cols;
-  bool pre;
+  uint32_t n, c, batch, W, Wb, M, B, Bt, levels, nseq, nblk, rows, cols, npart;
+  bool pre, part_sort;
   uint64_t tmax[8];
-  size_t off_ptrs, off_ranks, off_counts, off_buckets, zero_end, off_blocksums, off_off, off_tk,
+  size_t off_ptrs, off_ranks, off_poff, off_counts, off_cursor, off_psize, off_buckets, zero_end, off_blocksums, off_off, off_tk,
       off_sorted, off_part[2], off_pairs, total;
   MsmLayout(uint32_t n_, uint32_t c_, uint32_t batch_, bool pre_ = false);
 };

@@ -196,6 +196,53 @@ struct Commit {
   }
 };
 
+// Work for the side stream (ctx.hpp): between begin() and end() every library call that enqueues on `c->stream`
+// lands on the low-priority stream instead, ordered after the accumulate kernel of the MSM launch queued last (all
+// earlier kernels of the main stream are complete by then, and what remains of the MSM only touches its own
+// workspace).  join_aux() makes the main stream wait for it.  The destructor restores the context on an error path.
+struct AuxFork {
+  cq_ctx* c;
+  hipStream_t main = nullptr;
+  int saved_slot = 0;
+  bool active = false;
+  explicit AuxFork(cq_ctx* c_) : c(c_) {}
+  // `seq_before`: c->msm_tail_seq sampled before the MSMs were queued
+  int begin(uint64_t seq_before) {
+    if (c->msm_tail_seq == seq_before) CQ_HIP(c, hipEventRecord(c->msm_tail_event, c->stream));  // no launch: plain ordering
+    CQ_HIP(c, hipStreamWaitEvent(c->aux_stream, c->msm_tail_event, 0));
+    main = c->stream;
+    saved_slot = c->ntt_scratch_slot;
+    c->stream = c->aux_stream;
+    c->ntt_scratch_slot = 8;
+    active = true;
+    return CQ_OK;
+  }
+  int end() {
+    if (!active) return CQ_OK;
+    restore();
+    c->aux_pending = true;
+    CQ_HIP(c, hipEventRecord(c->aux_done, c->aux_stream));
+    return CQ_OK;
+  }
+  void restore() {
+    c->stream = main;
+    c->ntt_scratch_slot = saved_slot;
+    active = false;
+  }
+  ~AuxFork() {
+    if (active) {
+      restore();
+      hipStreamSynchronize(c->aux_stream);
+    }
+  }
+};
+static int join_aux(cq_ctx* c) {
+  if (!c->aux_pending) return CQ_OK;
+  c->aux_pending = false;
+  CQ_HIP(c, hipStreamWaitEvent(c->stream, c->aux_done, 0));
+  return CQ_OK;
+}
+
 int commit_batch_v(const cq_pk* pk, const std::vector<const Fr*>& scalars, const std::vector<const G1Affine*>& bases,
                    const std::vector<size_t>& lens, std::vector<G1Affine>& out) {
   Commit cm;
@@ -426,6 +473,17 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, const uint64_
   uint64_t* rng_dev = B.rng_dev;
   uint32_t *m_counts = B.m_counts, *err_dev = B.err_dev;
 
+  // side stream: drain whatever an aborted proof may have left there; its NTTs must find their twiddle tables built
+  CQ_TRY(c->ensure_aux_stream());
+  if (c->aux_pending) {
+    CQ_HIP(c, hipStreamSynchronize(c->aux_stream));
+    c->aux_pending = false;
+  }
+  {
+    int trc = CQ_OK;
+    if (!c->tables_for(dom->k, dom->omega_inv, &trc) || !c->tables_for(dom->extended_k, dom->extended_omega, &trc)) return trc;
+  }
+
   // prover.rs:85 -- vk.hash_into(transcript)
   tr.common_scalar(pk->vk_repr);
 
@@ -586,6 +644,7 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, const uint64_
   }
 
   // ---- CQ round 1 (static_lookup/prover.rs:51-183) ------------------------------------------------
+  bool adv_is_coeff = false;
   if (L) CQ_HIP(c, hipMemsetAsync(m_counts, 0, (L * N + 16) * sizeof(uint32_t), s));
   size_t input_slot = 0;
   for (size_t l = 0; l < L; l++) {
@@ -656,7 +715,26 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, const uint64_
     for (size_t l = 0; l < L; l++) { sc.push_back(m_fr + l * N); bs.push_back(pk->table_cfg->g1_lagrange); ln.push_back(N); }
     std::vector<G1Affine> cm;
     Commit r1;
+    const uint64_t seq = c->msm_tail_seq;
     CQ_TRY(r1.begin(pk, sc, bs, ln));
+    {
+      // under the launch's tail: f -> coefficients (:326-334) and onto the extended coset (evaluation.rs:533-548 reads
+      // it), the instance cosets -- none of them depends on beta / gamma
+      AuxFork fork(c);
+      CQ_TRY(fork.begin(seq));
+      if (L) {
+        CQ_TRY(domain_lagrange_to_coeff(dom, f_lag, f_coeff, (uint32_t)L, n, n));
+        CQ_TRY(domain_coeff_to_extended(dom, f_coeff, cosets + L * ext, (uint32_t)L, n, ext));
+      }
+      if (general && I) CQ_TRY(domain_coeff_to_extended(dom, B.inst_coeff, B.inst_cosets, (uint32_t)I, n, ext));
+      if (A && S == 0) {
+        // advice -> coefficients (prover.rs:587-603), in place: without a permutation argument nothing reads the
+        // Lagrange values after round 1, and the round-2 inversions leave room for it
+        CQ_TRY(domain_lagrange_to_coeff(dom, adv, adv, (uint32_t)A, n, n));
+        adv_is_coeff = true;
+      }
+      CQ_TRY(fork.end());
+    }
     CQ_TRY(finish_random_poly());  // host draws overlap the MSM kernels just queued
     CQ_TRY(r1.end(cm));
     for (size_t q = 0; q < 2 * PL; q++)
@@ -770,10 +848,7 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, const uint64_
       CQ_TRY(cq_a_values(c, den + l * N, m_counts + l * N, (uint32_t)N, tp, a_val + l * N, a_scaled + woff * N));
       woff += w;
     }
-    if (L) {
-      CQ_TRY(domain_lagrange_to_coeff(dom, bpoly, bpoly, (uint32_t)L, n, n));
-      CQ_TRY(domain_lagrange_to_coeff(dom, f_lag, f_coeff, (uint32_t)L, n, n));  // :326-334
-    }
+    if (L) CQ_TRY(domain_lagrange_to_coeff(dom, bpoly, bpoly, (uint32_t)L, n, n));  // f: under round 1's launch
     // commitments, one batch of launches: the permutation products (permutation/prover.rs:177, written first),
     // then a, a0 (dense over the table SRS), q_a (over [qs_0|qs_1|...]), p, b0 (n-1 terms of b[1..]) and the
     // vanishing argument's random polynomial (vanishing/prover.rs:58)
@@ -795,7 +870,21 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, const uint64_
         woff += w;
       }
       sc.push_back(random_poly); bs.push_back(pk->params->g); ln.push_back(n);
-      CQ_TRY(commit_batch_v(pk, sc, bs, ln, r2));
+      Commit r2cm;
+      const uint64_t seq = c->msm_tail_seq;
+      CQ_TRY(r2cm.begin(pk, sc, bs, ln));
+      {
+        // under the launch's tail, none of it depending on y: advice -> coefficients (prover.rs:587-603, in place: the
+        // Lagrange values were last read by the permutation / lookup products above) and onto the extended coset
+        // (evaluation.rs:317-335), b onto the extended coset
+        AuxFork fork(c);
+        CQ_TRY(fork.begin(seq));
+        if (A && !adv_is_coeff) CQ_TRY(domain_lagrange_to_coeff(dom, adv, adv, (uint32_t)A, n, n));
+        if (L) CQ_TRY(domain_coeff_to_extended(dom, bpoly, cosets, (uint32_t)L, n, ext));
+        if (general && A) CQ_TRY(domain_coeff_to_extended(dom, adv, B.adv_cosets, (uint32_t)A, n, ext));
+        CQ_TRY(fork.end());
+      }
+      CQ_TRY(r2cm.end(r2));
     }
     for (size_t st = 0; st < S; st++)
       if (!tr.write_point(r2[st])) return c->fail(CQ_ERR_TRANSCRIPT, "permutation product commitment is the identity");
@@ -828,15 +917,15 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, const uint64_
   if (!tr.write_point(random_cm)) return c->fail(CQ_ERR_TRANSCRIPT, "random poly commitment is the identity");
   const Fr y = tr.squeeze();  // prover.rs:584
 
-  // advice polys: lagrange_to_coeff (:587-603), in place
-  if (A) CQ_TRY(domain_lagrange_to_coeff(dom, adv, adv, (uint32_t)A, n, n));
+  // advice polys (lagrange_to_coeff, :587-603) and the cosets of advice / instance / b / f were computed on the side
+  // stream under the round-1 and round-2 launches
+  CQ_TRY(join_aux(c));
 
   // ---- evaluate_h (evaluation.rs:285-551) + divide by the vanishing polynomial ------------------------
   {
     if (general) {
       // advice / instance cosets (:317-335), permutation product cosets (permutation/prover.rs:182)
-      if (A) CQ_TRY(domain_coeff_to_extended(dom, adv, B.adv_cosets, (uint32_t)A, n, ext));
-      if (I) CQ_TRY(domain_coeff_to_extended(dom, B.inst_coeff, B.inst_cosets, (uint32_t)I, n, ext));
+      if (I && !(L || PL)) CQ_TRY(domain_coeff_to_extended(dom, B.inst_coeff, B.inst_cosets, (uint32_t)I, n, ext));  // no round 1
       if (S) CQ_TRY(domain_coeff_to_extended(dom, B.z, B.z_cosets, (uint32_t)S, n, ext));
       const uint32_t rot_scale = 1u << (dom->extended_k - dom->k);
       if (pk->num_gate_polys) {  // custom gates (:348-365)
@@ -920,10 +1009,6 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, const uint64_
       la.ext = (uint32_t)ext;
       la.rot_scale = rot_scale;
       CQ_TRY(lookup_h_terms(c, la, h_ext));
-    }
-    if (L) {
-      CQ_TRY(domain_coeff_to_extended(dom, bpoly, cosets, (uint32_t)L, n, ext));
-      CQ_TRY(domain_coeff_to_extended(dom, f_coeff, cosets + L * ext, (uint32_t)L, n, ext));
     }
     // CQ terms (:533-548), then the division by X^n - 1 (vanishing/prover.rs:84, domain.rs:319-338)
     CqQuotientArgs qa;
