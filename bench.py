@@ -170,6 +170,8 @@ def main():
             "traffic": None,
             "launches": int(ntt_calls),
             "melem_per_s": ntt_elems / (ntt_ms / 1e3) / 1e6 if ntt_ms > 0 else 0.0,
+            "note": "most NTT passes of a proof run on the library's side stream underneath the MSM tail kernels, so these "
+                    "event-bracketed pass times include the kernels they share the GPU with (stand-alone: 5.6-5.9 Gelem/s)",
         }
         if world == 1 and not args.no_plonk_variant:
             out["plonk_variant"] = plonk_variant(ctx, wl, max(2, min(args.steps, 5)))

@@ -115,7 +115,8 @@ def test_msm_skewed_scalars_multilevel(ctx, kind):
     _check(ctx, sc, pts)
 
 
-@pytest.mark.parametrize("n,kind", [(700, "uniform"), (5000, "uniform"), (5000, "bits"), (40000, "uniform")])
+@pytest.mark.parametrize("n,kind", [(700, "uniform"), (5000, "uniform"), (5000, "bits"), (40000, "uniform"),
+                                    (70000, "bits"), (70000, "const"), (33000, "limb12")])
 def test_msm_precomputed_tables_same_result(ctx, n, kind):
     """Fixed-base mode (per-window tables, one bucket set) returns the same point as the plain
     pipeline and as the oracle; also on a prefix of the registered array."""
@@ -124,8 +125,12 @@ def test_msm_precomputed_tables_same_result(ctx, n, kind):
     pts = B.points_to_mont_limbs(random_points(min(n, 2048), 91))
     pts = np.tile(pts, ((n + 2047) // 2048, 1))[:n]
     rng = B.Xoshiro256ss(92)
-    if kind == "bits":
+    if kind == "bits":  # one bucket (and one partition of the table-mode sort) takes every entry: many tiles, long lists
         sc = B.to_mont_limbs([rng.next_u64() & 1 for _ in range(n)])
+    elif kind == "const":  # 17 buckets with n entries each
+        sc = np.tile(B.to_mont_limbs([B.fr_random(rng)]), (n, 1))
+    elif kind == "limb12":
+        sc = np.tile(B.to_mont_limbs([rng.next_u64() & 0xFFF for _ in range(1000)]), (n // 1000, 1))
     else:
         rs = np.random.RandomState(n)
         sc = rs.randint(0, 2**63, size=(n, 4), dtype=np.int64).astype(np.uint64)
