@@ -62,8 +62,9 @@ int msm_multi_begin(cq_ctx* c, const Fr* const* scalars, const G1Affine* const* 
     MsmLayout L(nmax, cb, batch, pre);
     ln.W = L.W;
     ln.Wb = L.Wb;
+    ln.cols = L.cols;
     ln.slot = slots;
-    slots += (size_t)batch * L.Wb;
+    slots += (size_t)2 * batch * L.Wb;  // a (V, U) pair per bucket set
     pend.launches.push_back(ln);
     done += batch;
   }
@@ -107,7 +108,7 @@ int msm_multi_end(cq_ctx* c, MsmPending& pend, uint64_t* out_jac) {
         continue;
       }
       const G1Jac* res = (const G1Jac*)pend.host + ln.slot;
-      G1Jac r = ln.pre ? res[j] : msm_fold_windows(res + (size_t)j * ln.W, ln.W, ln.c);
+      G1Jac r = ln.pre ? msm_set_value(res + (size_t)2 * j, ln.cols) : msm_fold_windows(res + (size_t)2 * j * ln.W, ln.W, ln.c, ln.cols);
       r.x.to_limbs64(o);
       r.y.to_limbs64(o + 4);
       r.z.to_limbs64(o + 8);

@@ -358,6 +358,80 @@ struct Fp {
     e[0] -= 2;  // low limb of both moduli is >= 2
     return pow(e);
   }
+  // The same inverse by the binary extended Euclid on the 8 x 32-bit integers: ~750 data-dependent steps of shifts
+  // and additions instead of ~380 dependent modular products -- about 3x shorter as a chain.  It diverges across
+  // lanes, so it is for the places where ONE lane inverts (the total of a batch inversion).  With y = (aR)^-1 as an
+  // integer, mont_mul(y, R^3) = a^-1 R.
+  CQ_HD Fp inv_euclid() const {
+    if (is_zero()) return zero();
+    uint32_t u[8], w[8], x1[8], x2[8];
+    CQ_UNROLL for (int i = 0; i < 8; i++) {
+      u[i] = v.l[i];
+      w[i] = P::MOD[i];
+      x1[i] = i == 0 ? 1u : 0u;
+      x2[i] = 0;
+    }
+    auto is_one = [](const uint32_t* a) {
+      uint32_t o = a[0] ^ 1u;
+      CQ_UNROLL for (int i = 1; i < 8; i++) o |= a[i];
+      return o == 0;
+    };
+    auto halve = [](uint32_t* a, uint32_t* x) {  // a even: a /= 2, x = x / 2 mod p
+      CQ_UNROLL for (int i = 0; i < 7; i++) a[i] = (a[i] >> 1) | (a[i + 1] << 31);
+      a[7] >>= 1;
+      uint32_t top = 0;
+      if (x[0] & 1u) {  // x + p < 2p < 2^255
+        uint64_t c = 0;
+        CQ_UNROLL for (int i = 0; i < 8; i++) {
+          c += (uint64_t)x[i] + P::MOD[i];
+          x[i] = (uint32_t)c;
+          c >>= 32;
+        }
+        top = (uint32_t)c;
+      }
+      CQ_UNROLL for (int i = 0; i < 7; i++) x[i] = (x[i] >> 1) | (x[i + 1] << 31);
+      x[7] = (x[7] >> 1) | (top << 31);
+    };
+    auto geq = [](const uint32_t* a, const uint32_t* b) {
+      for (int i = 7; i >= 0; i--)
+        if (a[i] != b[i]) return a[i] > b[i];
+      return true;
+    };
+    auto sub_into = [](uint32_t* a, const uint32_t* b) -> uint32_t {  // a -= b, returns the borrow
+      uint64_t br = 0;
+      CQ_UNROLL for (int i = 0; i < 8; i++) {
+        const uint64_t d = (uint64_t)a[i] - b[i] - br;
+        a[i] = (uint32_t)d;
+        br = (d >> 32) & 1;
+      }
+      return (uint32_t)br;
+    };
+    auto sub_mod = [&](uint32_t* x, const uint32_t* y) {  // x = x - y mod p, x, y < p
+      if (sub_into(x, y)) {
+        uint64_t c = 0;
+        CQ_UNROLL for (int i = 0; i < 8; i++) {
+          c += (uint64_t)x[i] + P::MOD[i];
+          x[i] = (uint32_t)c;
+          c >>= 32;
+        }
+      }
+    };
+    while (!is_one(u) && !is_one(w)) {
+      while (!(u[0] & 1u)) halve(u, x1);
+      while (!(w[0] & 1u)) halve(w, x2);
+      if (geq(u, w)) {
+        sub_into(u, w);
+        sub_mod(x1, x2);
+      } else {
+        sub_into(w, u);
+        sub_mod(x2, x1);
+      }
+    }
+    Fp y;
+    const uint32_t* r = is_one(u) ? x1 : x2;
+    CQ_UNROLL for (int i = 0; i < 8; i++) y.v.l[i] = r[i];
+    return y * r3();
+  }
 };
 
 using Fr = Fp<FrP>;

@@ -646,13 +646,13 @@ int msm_precompute_tables(cq_ctx* ctx, const G1Affine* bases, uint32_t n, uint32
 }
 
 // ---- 5. reduction: sum_{b=1..M} b * B_b per bucket set ---------------------------------------------------
-// Every dependent EC addition costs a wave ~5 us whatever the number of busy lanes, so the reduction is shaped
+// Every dependent EC addition costs a lone wave ~9 us whatever the number of busy lanes, so the reduction is shaped
 // for depth, not work.  Buckets are read as a rows x cols matrix (b = cols * hi + lo + 1, cols = min(M, 128)):
 //     sum_b b B_b  =  cols * sum_hi hi R_hi  +  sum_lo (lo + 1) C_lo,     R = row sums, C = column sums.
 // Kernel 1: 16 lanes per row / column sum (<= 8 buckets per lane serially, then a 4-level shuffle tree), four lines
 // per wave, all independent.  Kernel 2: per bucket set two waves, one per weighted sum of <= 128 terms
-// (pair sums, suffix scan by shuffles, one tree), joined through LDS.  ~11 + ~24 dependent operations instead of
-// the ~46 of a lane-serial running sum over 1024-bucket groups.
+// (pair sums, suffix scan by shuffles, one tree); the host applies "cols *" and joins the two.  ~11 + ~16 dependent
+// operations instead of the ~46 of a lane-serial running sum over 1024-bucket groups.
 static __device__ __forceinline__ XYZZ29 wave_sum(XYZZ29 v) {
 #pragma unroll 1
   for (int delta = 32; delta >= 1; delta >>= 1) {
@@ -708,24 +708,15 @@ static __device__ __forceinline__ XYZZ29 wave_weighted_sum(const XYZZ* __restric
   return wave_sum(v);
 }
 
+// Two waves per bucket set, one per weighted sum.  The set's value is cols * V + U with V = sum_hi hi R_hi and
+// U = sum_lo (lo + 1) C_lo; the log2(cols) doublings and the last addition are left to the host (a single wave needs
+// ~9 us per dependent EC operation here, the CPU a fraction of a microsecond): out[2 set] = V, out[2 set + 1] = U.
 __global__ __launch_bounds__(128) void msm_weighted_kernel(const XYZZ* __restrict__ sums, uint32_t rows, uint32_t cols,
-                                                           G1Jac* __restrict__ window_sums) {
-  __shared__ XYZZ29 other;
+                                                           G1Jac* __restrict__ out) {
   const uint32_t set = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const XYZZ* S = sums + (size_t)set * (rows + cols);
-  XYZZ29 v;
-  if (wave == 0) {
-    v = wave_weighted_sum(S, rows, 0);                      // sum_hi hi R_hi
-    for (uint32_t l = cols; l > 1; l >>= 1) v = xyzz29_dbl(v);  // * cols (a power of two)
-  } else {
-    v = wave_weighted_sum(S + rows, cols, 1);               // sum_lo (lo + 1) C_lo
-    if (lane == 0) other = v;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    xyzz29_add(v, other);
-    window_sums[set] = xyzz29_to_jac(v);
-  }
+  const XYZZ29 v = wave == 0 ? wave_weighted_sum(S, rows, 0) : wave_weighted_sum(S + rows, cols, 1);
+  if (lane == 0) out[2 * set + wave] = xyzz29_to_jac(v);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -875,11 +866,17 @@ int msm_run(cq_ctx* ctx, const Fr* const* scalars_host_ptrs, const G1Affine* con
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
-G1Jac msm_fold_windows(const G1Jac* window_sums, uint32_t W, uint32_t c) {
+G1Jac msm_set_value(const G1Jac* pair, uint32_t cols) {
+  G1Jac v = pair[0];
+  for (uint32_t l = cols; l > 1; l >>= 1) v = jac_dbl(v);
+  return jac_add(v, pair[1]);
+}
+
+G1Jac msm_fold_windows(const G1Jac* pairs, uint32_t W, uint32_t c, uint32_t cols) {
   G1Jac acc = G1Jac::identity();
   for (int w = (int)W - 1; w >= 0; w--) {
     for (uint32_t j = 0; j < c; j++) acc = jac_dbl(acc);
-    acc = jac_add(acc, window_sums[w]);
+    acc = jac_add(acc, msm_set_value(pairs + 2 * w, cols));
   }
   return acc;
 }

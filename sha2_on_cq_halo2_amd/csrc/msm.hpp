@@ -37,15 +37,17 @@ struct MsmLayout {
 
 uint32_t msm_window_bits(uint32_t n);
 // Enqueues the whole pipeline on ctx->stream.
-// `scalars` / `bases`: HOST arrays of `batch` device pointers; window_sums_dev receives batch*W points.
+// `scalars` / `bases`: HOST arrays of `batch` device pointers; window_sums_dev receives a PAIR of points (V, U) per
+// bucket set -- the set's value is cols * V + U (msm_set_value; cols = MsmLayout::cols) -- batch*W pairs.
 // `pre`: every bases[j] points to a precomputed table [W][table_stride] with table[w][i] = 2^(c*w)*base[i]
-// (msm_precompute_tables); then window_sums_dev receives ONE point per MSM (the result itself).
+// (msm_precompute_tables); then there is ONE bucket set, i.e. one pair, per MSM.
 // lens[j] <= n: per-MSM lengths (one launch may mix lengths; n is the maximum)
 int msm_run(cq_ctx* ctx, const Fr* const* scalars, const G1Affine* const* bases, const size_t* lens, uint32_t n, uint32_t c,
             uint32_t batch, bool pre, const size_t* table_strides, void* workspace, G1Jac* window_sums_dev);
 int msm_precompute_tables(cq_ctx* ctx, const G1Affine* bases, uint32_t n, uint32_t c, G1Affine* table);
-// Host: sum_w 2^(c*w) * window_sums[w].
-G1Jac msm_fold_windows(const G1Jac* window_sums, uint32_t W, uint32_t c);
+// Host: value of one bucket set from its pair; sum_w 2^(c*w) * (value of set w) over W consecutive pairs.
+G1Jac msm_set_value(const G1Jac* pair, uint32_t cols);
+G1Jac msm_fold_windows(const G1Jac* pairs, uint32_t W, uint32_t c, uint32_t cols);
 
 }  // namespace cq
 
@@ -61,7 +63,7 @@ int cq_msm_multi_v(cq_ctx* c, const cq::Fr* const* scalars, const cq::G1Affine* 
 struct MsmPending {
   struct Launch {
     size_t first = 0, slot = 0;
-    uint32_t batch = 0, c = 0, nmax = 0, W = 0, Wb = 0;
+    uint32_t batch = 0, c = 0, nmax = 0, W = 0, Wb = 0, cols = 0;
     bool pre = false, empty = false;
   };
   std::vector<Launch> launches;

@@ -91,7 +91,8 @@ __global__ __launch_bounds__(256) void kate_fill_kernel(const Fr* __restrict__ a
 }
 
 // ---- ff::BatchInvert (Montgomery's trick), zeros stay zero -----------------------------------------
-// A Fermat inversion is ~380 dependent products, so it is shared by a whole workgroup: 256 lanes x BI_PER_LANE
+// An inversion is a long dependent chain on one lane (binary extended Euclid, ~750 limb steps; Fermat's ~380
+// dependent products took 0.4 ms), so it is shared by a whole workgroup: 256 lanes x BI_PER_LANE
 // strided (coalesced) elements.  Each lane keeps its elements in registers, parks the running prefix products in
 // the output array, the lane totals are scanned in LDS (prefix and suffix), lane 0 inverts the block total, and
 // every lane unwinds its own elements: ~5 products per element + one inversion per 4096 elements.
@@ -149,7 +150,7 @@ __global__ __launch_bounds__(256) void batch_invert_kernel(Fr* __restrict__ a, u
   __syncthreads();
   const Fr after = t < 255 ? bi_get(lo, hi, t + 1) : Fr::one();
   __syncthreads();
-  if (t == 0) bi_put(lo, hi, 0, total.inv());
+  if (t == 0) bi_put(lo, hi, 0, total.inv_euclid());
   __syncthreads();
   const Fr total_inv = bi_get(lo, hi, 0);
   // inverse of (everything up to and including this lane) = total^-1 * (product of the later lanes)
