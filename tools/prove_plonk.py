@@ -1,0 +1,16 @@
+"""Times the general-PLONK variant of the SHA-shaped circuit (gate, selector, copy constraints; bench.py's
+`plonk_variant` leg) -- for rocprofv3 kernel traces.   python3 tools/prove_plonk.py [k] [gwc|shplonk]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from sha2_on_cq_halo2_amd import Context
+from sha2_on_cq_halo2_amd.sha_circuit import ShaCqWorkload, ShaPlonkWorkload
+
+k = int(sys.argv[1]) if len(sys.argv) > 1 else 18
+opener = sys.argv[2] if len(sys.argv) > 2 else "gwc"
+ctx = Context(0)
+wl = ShaCqWorkload(ctx, k)
+pw = ShaPlonkWorkload(ctx, k, seed=0x5348413243515F, share=wl)
+pw.pk.set_opener(opener)
+for i in range(4):
+    t = time.time(); proof = pw.prove(seed=2 + i); dt = time.time() - t
+    print("plonk variant k=%d %s: %.1f ms  proof %d bytes" % (k, opener, dt * 1e3, len(proof)), flush=True)
