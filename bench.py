@@ -146,6 +146,7 @@ def main():
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
             "traffic": pmc_traffic("msm_accumulate_kernel") if k == 18 else None,
+            "valu_issue_utilisation_pmc": pmc_valu_issue() if k == 18 else None,
             "launches": int(acc_calls),
             "avg_launch_ms": acc_ms / max(acc_calls, 1),
             "msm_kernel_mscalar_per_s": units / acc_s / 1e6 if acc_s > 0 else 0.0,
@@ -237,6 +238,19 @@ def pmc_traffic(kernel):
     try:
         with open(path) as f:
             return json.load(f)["cq::" + kernel]["hbm_bytes_per_launch_raw"]
+    except Exception:
+        return None
+
+
+def pmc_valu_issue():
+    """VALU issue utilisation of the accumulate launch that holds most of a proof's additions (SQ_INSTS_VALU x 4
+    cycles / (1024 SIMDs x GPU cycles)), from the committed rocprofv3 --pmc pass over the same k=18 proof
+    (profiles/README.md); None if the summary is missing."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_sq_accumulate_k18.json")
+    try:
+        with open(path) as f:
+            rows = json.load(f)["kernels"]["msm_accumulate_kernel"]
+        return max(rows, key=lambda r: r["valu_wave_instructions"])["valu_issue_utilisation"]
     except Exception:
         return None
 

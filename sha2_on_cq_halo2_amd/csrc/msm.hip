@@ -31,7 +31,6 @@
 //   6. host      : table mode returns one Jacobian point per MSM; plain mode W window sums per MSM, folded by a
 //                  Horner over windows (c doublings each) on the host.
 #include <algorithm>
-#include <cstdlib>
 #include "msm.hpp"
 #include "curve29.hpp"
 #include "ctx.hpp"
