@@ -359,9 +359,9 @@ __global__ __launch_bounds__(PART_THREADS) void msm_bucket_place_kernel(const ui
 // number of level-k sub-lists of every bucket: t1 = ceil(cnt/S1); t_k = ceil(t_{k-1}/S2) while t_{k-1} > MSM_SHORT,
 // else 0: a bucket with 2..MSM_SHORT partial sums is finished by msm_combine_short_kernel, which is indexed by
 // bucket and needs no slot; one with a single partial sum was written to its bucket by the level before.
-static __device__ __forceinline__ uint32_t level_value(uint32_t cnt, uint32_t lv) {
+static __device__ __forceinline__ uint32_t level_value(uint32_t cnt, uint32_t lv, uint32_t s1) {
   if (lv == 0) return cnt;
-  uint32_t t = (cnt + MSM_S1 - 1) / MSM_S1;
+  uint32_t t = (cnt + s1 - 1) / s1;
   for (uint32_t k = 2; k <= lv; k++) t = t <= MSM_SHORT ? 0 : (t + MSM_S2 - 1) / MSM_S2;
   return t;
 }
@@ -390,7 +390,7 @@ static __device__ __forceinline__ uint32_t block_excl_scan256(uint32_t v, uint32
 
 constexpr uint32_t SCAN_TILE = 2048;  // elements per block (8 per thread)
 
-__global__ __launch_bounds__(256) void msm_scan_reduce_kernel(const uint32_t* __restrict__ cnt, uint32_t Bt, uint32_t nseq,
+__global__ __launch_bounds__(256) void msm_scan_reduce_kernel(const uint32_t* __restrict__ cnt, uint32_t Bt, uint32_t nseq, uint32_t s1,
                                                               uint32_t* __restrict__ blocksums /*[nseq][nblk]*/) {
   __shared__ uint32_t sh[4];
   const uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * 8;
@@ -398,7 +398,7 @@ __global__ __launch_bounds__(256) void msm_scan_reduce_kernel(const uint32_t* __
   for (int k = 0; k < 8; k++) c8[k] = (base + k < Bt) ? cnt[base + k] : 0;
   for (uint32_t lv = 0; lv < nseq; lv++) {
     uint32_t s = 0;
-    for (int k = 0; k < 8; k++) s += level_value(c8[k], lv);
+    for (int k = 0; k < 8; k++) s += level_value(c8[k], lv, s1);
     uint32_t tot;
     block_excl_scan256(s, sh, tot);
     if (threadIdx.x == 0) blocksums[(size_t)lv * gridDim.x + blockIdx.x] = tot;
@@ -431,7 +431,7 @@ __global__ __launch_bounds__(1024) void msm_scan_spine_kernel(uint32_t* __restri
   }
 }
 
-__global__ __launch_bounds__(256) void msm_scan_apply_kernel(const uint32_t* __restrict__ cnt, uint32_t Bt, uint32_t nseq,
+__global__ __launch_bounds__(256) void msm_scan_apply_kernel(const uint32_t* __restrict__ cnt, uint32_t Bt, uint32_t nseq, uint32_t s1,
                                                              const uint32_t* __restrict__ blocksums,
                                                              uint32_t* __restrict__ off /*[nseq][Bt+1]*/,
                                                              uint32_t* __restrict__ tk /*[nseq-1][Bt]*/) {
@@ -443,7 +443,7 @@ __global__ __launch_bounds__(256) void msm_scan_apply_kernel(const uint32_t* __r
     uint32_t v8[8];
     uint32_t s = 0;
     for (int k = 0; k < 8; k++) {
-      v8[k] = level_value(c8[k], lv);
+      v8[k] = level_value(c8[k], lv, s1);
       s += v8[k];
     }
     uint32_t tot;
@@ -506,7 +506,7 @@ __global__ __launch_bounds__(MSM_ACC_THREADS) void msm_accumulate_kernel(
   const G1Affine* __restrict__ pts = bases[msm];
   const size_t table_stride = pre ? (size_t)table_strides[msm] : 0;
   const uint32_t r = j - off1[g];
-  // the bucket's cnt entries are cut into t = ceil(cnt / MSM_S1) sub-lists of EQUAL length (+-1): a wave runs as
+  // the bucket's cnt entries are cut into t = ceil(cnt / s1) sub-lists of EQUAL length (+-1): a wave runs as
   // long as its longest lane, so 40 entries are better served as 20 + 20 than as 32 + 8
   const uint32_t t = t1[g], n_g = cnt[g];
   const uint32_t lo = off0[g] + (uint32_t)(((uint64_t)n_g * r) / t);
@@ -811,6 +811,12 @@ int msm_run(cq_ctx* ctx, const Fr* const* scalars_host_ptrs, const G1Affine* con
   const uint64_t* d_lens = (const uint64_t*)((const void**)d_scalars + 3 * batch);
   // counts and buckets (identity = all zero) are adjacent: one memset
   if (hipMemsetAsync(counts, 0, L.zero_end - L.off_counts, s) != hipSuccess) return -1;
+  // Sub-list length of the accumulate level.  Short lists keep a small launch (two MSMs: 32 K buckets) parallel and
+  // balanced; a launch with tens of millions of entries has lanes to spare, and longer lists halve the partial sums
+  // its combine level has to add up.  (The workspace is sized for MSM_S1, the smaller of the two.)
+  uint64_t entries_max = 0;
+  for (uint32_t i = 0; i < batch; i++) entries_max += (uint64_t)lens[i] * W;
+  const uint32_t s1 = entries_max >= MSM_S1_BIG_ENTRIES ? MSM_S1_BIG : MSM_S1;
   const uint32_t* off0 = off;
   if (L.part_sort) {
     const uint32_t P = batch * L.npart;
@@ -825,15 +831,15 @@ int msm_run(cq_ctx* ctx, const Fr* const* scalars_host_ptrs, const G1Affine* con
     msm_part_scatter_kernel<<<dim3((n + PSC_THREADS - 1) / PSC_THREADS, batch), PSC_THREADS, 0, s>>>(d_scalars, d_lens, c, W, L.npart, poff, pcursor,
                                                                                                      part_buf);
     msm_bucket_count_kernel<<<dim3(P, PART_SPLIT), PART_THREADS, 0, s>>>(part_buf, poff, counts);
-    msm_scan_reduce_kernel<<<L.nblk, 256, 0, s>>>(counts, Bt, L.nseq, blocksums);
+    msm_scan_reduce_kernel<<<L.nblk, 256, 0, s>>>(counts, Bt, L.nseq, s1, blocksums);
     msm_scan_spine_kernel<<<1, 1024, 0, s>>>(blocksums, L.nblk, L.nseq);
-    msm_scan_apply_kernel<<<L.nblk, 256, 0, s>>>(counts, Bt, L.nseq, blocksums, off, tk);
+    msm_scan_apply_kernel<<<L.nblk, 256, 0, s>>>(counts, Bt, L.nseq, s1, blocksums, off, tk);
     msm_bucket_place_kernel<<<dim3(P, PART_SPLIT), PART_THREADS, 0, s>>>(part_buf, poff, off0, cursor, sorted);
   } else {
     msm_digits_kernel<<<dim3((n + 255) / 256, batch), 256, 0, s>>>(d_scalars, d_lens, n, c, W, pre ? 1u : 0u, ranks, counts);
-    msm_scan_reduce_kernel<<<L.nblk, 256, 0, s>>>(counts, Bt, L.nseq, blocksums);
+    msm_scan_reduce_kernel<<<L.nblk, 256, 0, s>>>(counts, Bt, L.nseq, s1, blocksums);
     msm_scan_spine_kernel<<<1, 1024, 0, s>>>(blocksums, L.nblk, L.nseq);
-    msm_scan_apply_kernel<<<L.nblk, 256, 0, s>>>(counts, Bt, L.nseq, blocksums, off, tk);
+    msm_scan_apply_kernel<<<L.nblk, 256, 0, s>>>(counts, Bt, L.nseq, s1, blocksums, off, tk);
     msm_scatter_kernel<<<dim3((n + 255) / 256, batch), 256, 0, s>>>(d_scalars, d_lens, n, c, W, pre ? 1u : 0u, ranks, off0, sorted);
   }
   if (ctx->prof_on && ctx->prof_entries && ctx->prof_entries_n < cq_ctx::PROF_COUNTERS)

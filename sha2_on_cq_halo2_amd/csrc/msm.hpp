@@ -14,6 +14,15 @@ constexpr uint32_t MSM_ACC_THREADS = 128;
 #define CQ_MSM_S1 24
 #endif
 constexpr uint32_t MSM_S1 = CQ_MSM_S1;  // max point indices summed by one lane (level 1)
+#ifndef CQ_MSM_S1_BIG
+#define CQ_MSM_S1_BIG 32
+#endif
+#ifndef CQ_MSM_S1_BIG_ENTRIES
+#define CQ_MSM_S1_BIG_ENTRIES 24000000ull
+#endif
+constexpr uint32_t MSM_S1_BIG = CQ_MSM_S1_BIG;  // ... in launches of at least MSM_S1_BIG_ENTRIES (scalar, window) pairs
+constexpr uint64_t MSM_S1_BIG_ENTRIES = CQ_MSM_S1_BIG_ENTRIES;
+static_assert(MSM_S1_BIG >= MSM_S1, "the workspace is sized for MSM_S1");
 constexpr uint32_t MSM_S2 = 256;        // max partial sums summed by one wave (levels >= 2)
 constexpr uint32_t MSM_SHORT = 64;       // level >= 2 lists up to this long are summed by one lane
 constexpr uint32_t MSM_MAX_BATCH = 32;  // MSMs per launch
