@@ -720,7 +720,7 @@ __global__ __launch_bounds__(128) void msm_weighted_kernel(const XYZZ* __restric
 
 // -------------------------------------------------------------------------------------------------
 uint32_t msm_window_bits(uint32_t n) {
-  // Measured on MI355X (tools/msm_sweep.py, uniform scalars).  15 is also the width whose top
+  // Measured on MI355X (tests/perf/msm_sweep.py, uniform scalars).  15 is also the width whose top
   // window (bits 240..254) is well filled; widths that leave 1-7 bits for the top window pile
   // n/2^bits entries on a handful of buckets.  (The reference uses ceil(ln n), arithmetic.rs:16-22.)
   if (n >= (1u << 15)) return 15;

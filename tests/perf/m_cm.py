@@ -1,5 +1,6 @@
+import os
 import sys, numpy as np
-sys.path.insert(0, '.')
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
 from oracle import bn254 as B, kzg, poly as OP
 from sha2_on_cq_halo2_amd import Context, ParamsKZG
 ctx = Context(0)

@@ -1,5 +1,6 @@
+import os
 import time, sys, numpy as np
-sys.path.insert(0, '.')
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
 from sha2_on_cq_halo2_amd import Context
 from oracle import bn254 as B
 from tests.util import random_points

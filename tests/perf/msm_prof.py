@@ -1,5 +1,5 @@
 import time, sys, numpy as np, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from sha2_on_cq_halo2_amd import Context
 from oracle import bn254 as B
 from tests.util import random_points

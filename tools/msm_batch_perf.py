@@ -5,13 +5,13 @@ import sys, time, os
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from sha2_on_cq_halo2_amd import Context, ParamsKZG
-from oracle import bn254 as B
+from sha2_on_cq_halo2_amd.api import fr_to_mont
 
 k = int(sys.argv[1]) if len(sys.argv) > 1 else 18
 batches = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [2, 8, 21]
 n = 1 << k
 ctx = Context(0)
-s = B.to_mont_limbs([B.fr_random(B.Xoshiro256ss(1))])[0]
+s = fr_to_mont(0x1234567890ABCDEF1234567890ABCDEF)
 params = ParamsKZG.setup_from_toxic_waste(ctx, k, s)
 rs = np.random.RandomState(1)
 bufs = []
