@@ -159,8 +159,12 @@ def main():
             "note": "VALU-bound integer kernel (no MFMA applies), so the HBM fraction is small by construction; "
                     "valu_frac = Montgomery products executed / measured chip peak (cq_bench_modmul_dev), see DESIGN.md",
         }
+        # NTT: measured stand-alone (8 columns of 2^k, lagrange_to_coeff -- the advice transform of the proof), because
+        # inside a proof most passes run on the side stream underneath the MSM tail kernels and their event-bracketed
+        # times include the kernels they share the GPU with (kept as `in_proof`).
+        sa_elems, sa_ms, sa_calls = ntt_standalone(ctx, k)
+        ntt_ach = NTT_BYTES_PER_ELEM * sa_elems / (sa_ms / 1e3) / 1e9 if sa_ms > 0 else 0.0
         ntt_elems = wl.ntt_elems_per_proof() * args.steps
-        ntt_ach = NTT_BYTES_PER_ELEM * ntt_elems / (ntt_ms / 1e3) / 1e9 if ntt_ms > 0 else 0.0
         out["roofline_ntt"] = {
             "kernel": "ntt_pass_kernel (all passes of a transform)",
             "bound": "hbm",
@@ -168,11 +172,12 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": ntt_ach / HBM_PEAK_GBS,
-            "traffic": None,
-            "launches": int(ntt_calls),
-            "melem_per_s": ntt_elems / (ntt_ms / 1e3) / 1e6 if ntt_ms > 0 else 0.0,
-            "note": "most NTT passes of a proof run on the library's side stream underneath the MSM tail kernels, so these "
-                    "event-bracketed pass times include the kernels they share the GPU with (stand-alone: 5.6-5.9 Gelem/s)",
+            "traffic": pmc_traffic("ntt_pass_kernel") if k == 18 else None,
+            "launches": int(sa_calls),
+            "melem_per_s": sa_elems / (sa_ms / 1e3) / 1e6 if sa_ms > 0 else 0.0,
+            "sample": f"10 x lagrange_to_coeff of 8 columns of 2^{k} (3 passes each), nothing else on the GPU",
+            "in_proof": {"launches": int(ntt_calls), "melem_per_s": ntt_elems / (ntt_ms / 1e3) / 1e6 if ntt_ms > 0 else 0.0,
+                         "note": "overlapped with MSM tail kernels (side stream): pass times include the co-running kernels"},
         }
         if world == 1 and not args.no_plonk_variant:
             out["plonk_variant"] = plonk_variant(ctx, wl, max(2, min(args.steps, 5)))
@@ -240,6 +245,32 @@ def pmc_traffic(kernel):
             return json.load(f)["cq::" + kernel]["hbm_bytes_per_launch_raw"]
     except Exception:
         return None
+
+
+def ntt_standalone(ctx, k, batch=8, reps=10):
+    """(elements, summed pass time in ms, pass launches) of `reps` batched lagrange_to_coeff transforms, timed by the
+    library's HIP events around every ntt_pass_kernel launch."""
+    import numpy as np
+
+    from sha2_on_cq_halo2_amd.api import PROF_NTT_PASS, EvaluationDomain
+
+    dom = EvaluationDomain(ctx, 3, k)
+    n = 1 << k
+    rs = np.random.RandomState(7)
+    a = rs.randint(0, 2**63, size=(batch * n, 4), dtype=np.int64).astype(np.uint64)
+    a[:, 3] &= np.uint64((1 << 60) - 1)
+    src, dst = ctx.to_device(a), ctx.alloc(batch * n * 32)
+    ctx._chk(ctx.lib.cq_lagrange_to_coeff_dev(dom.h, src.ptr, dst.ptr, batch))
+    ctx.sync()
+    ctx.profile_enable(True)
+    ctx.profile_read(PROF_NTT_PASS)
+    for _ in range(reps):
+        ctx._chk(ctx.lib.cq_lagrange_to_coeff_dev(dom.h, src.ptr, dst.ptr, batch))
+    ctx.sync()
+    ms, calls = ctx.profile_read(PROF_NTT_PASS)
+    ctx.profile_enable(False)
+    dom.close()
+    return batch * n * reps, ms, calls
 
 
 def pmc_valu_issue():

@@ -18,7 +18,7 @@ constexpr uint32_t MSM_S1 = CQ_MSM_S1;  // max point indices summed by one lane 
 #define CQ_MSM_S1_BIG 32
 #endif
 #ifndef CQ_MSM_S1_BIG_ENTRIES
-#define CQ_MSM_S1_BIG_ENTRIES 24000000ull
+#define CQ_MSM_S1_BIG_ENTRIES 64000000ull
 #endif
 constexpr uint32_t MSM_S1_BIG = CQ_MSM_S1_BIG;  // ... in launches of at least MSM_S1_BIG_ENTRIES (scalar, window) pairs
 constexpr uint64_t MSM_S1_BIG_ENTRIES = CQ_MSM_S1_BIG_ENTRIES;
