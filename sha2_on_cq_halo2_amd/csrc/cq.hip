@@ -69,38 +69,61 @@ static __device__ __forceinline__ uint32_t table_find(const Fr* __restrict__ val
 }
 
 // ---- round 1 (static_lookup/prover.rs:132-161): row -> table index, multiplicities --------------------
-__global__ __launch_bounds__(256) void cq_round1_kernel(CqRound1Args a, uint32_t u, uint32_t* __restrict__ m_counts,
-                                                        uint32_t* __restrict__ err) {
-  const uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;
-  const bool live = row < u;
-  uint32_t idx = EMPTY;
-  bool bad = false;
-  for (uint32_t j = 0; live && !bad && j < a.width; j++) {
-    const Fr v = ld(a.cols[j] + row);
-    const uint32_t ix = table_find(a.values[j], a.slots[j], a.nslots[j], v);
-    if (ix == EMPTY) {
-      atomicExch(err, 1u);  // "{:?} not in table" (:141)
-      bad = true;
-    } else if (j && ix != idx) {
-      atomicExch(err, 2u);  // "Vector lookup must be on the same table row" (:148)
-      bad = true;
+// Same-address device atomics serialise in L2 (~15 ns each): the padded rows of a sparse witness all hit one table
+// entry, and one atomic per wave still meant ~3000 of them on that entry (45 of the kernel's 52 us).  Every lane
+// therefore looks up R1_ROWS rows (strided, so loads stay coalesced), folds equal neighbours into a running (index, count) pair, and what
+// is left at the end is aggregated across the wave before it touches L2.
+constexpr uint32_t R1_ROWS = 4;
+__global__ __launch_bounds__(256) void cq_round1_kernel(CqRound1Batch batch, uint32_t u, uint32_t* __restrict__ err) {
+  const CqRound1Args& a = batch.a[blockIdx.y];
+  uint32_t* __restrict__ m_counts = batch.m_counts[blockIdx.y];
+  uint32_t found[R1_ROWS];
+#pragma unroll
+  for (uint32_t r = 0; r < R1_ROWS; r++) {  // independent probe chains, in flight together
+    const uint32_t row = (blockIdx.x * R1_ROWS + r) * blockDim.x + threadIdx.x;
+    uint32_t idx = EMPTY;
+    bool bad = row >= u;
+    for (uint32_t j = 0; !bad && j < a.width; j++) {
+      const Fr v = ld(a.cols[j] + row);
+      const uint32_t ix = table_find(a.values[j], a.slots[j], a.nslots[j], v);
+      if (ix == EMPTY) {
+        atomicExch(err, 1u);  // "{:?} not in table" (:141)
+        bad = true;
+      } else if (j && ix != idx) {
+        atomicExch(err, 2u);  // "Vector lookup must be on the same table row" (:148)
+        bad = true;
+      }
+      idx = ix;
     }
-    idx = ix;
+    found[r] = bad ? EMPTY : idx;
   }
-  // multiplicities: padded rows all hit the same entry, so aggregate equal indices within the wave
-  // before touching L2 (same-address atomics serialise)
-  bool pending = live && !bad;
+  uint32_t held = EMPTY, held_cnt = 0;
+#pragma unroll
+  for (uint32_t r = 0; r < R1_ROWS; r++) {
+    if (found[r] == EMPTY) continue;
+    if (found[r] == held) {
+      held_cnt++;
+    } else {
+      if (held_cnt) atomicAdd(&m_counts[held], held_cnt);
+      held = found[r];
+      held_cnt = 1;
+    }
+  }
+  // aggregate equal indices within the wave (all lanes reach this point)
+  bool pending = held_cnt != 0;
 #pragma unroll 1
   for (int round = 0; round < 4 && __ballot(pending); round++) {
     const unsigned long long pend = __ballot(pending);
     const int leader = __ffsll((long long)pend) - 1;
-    const uint32_t lidx = __shfl(idx, leader, 64);
-    const bool mine = pending && idx == lidx;
-    const unsigned long long grp = __ballot(mine);
-    if ((int)(threadIdx.x & 63) == leader) atomicAdd(&m_counts[lidx], (uint32_t)__popcll(grp));
+    const uint32_t lidx = __shfl(held, leader, 64);
+    const bool mine = pending && held == lidx;
+    uint32_t c = mine ? held_cnt : 0u;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d, 64);
+    if ((int)(threadIdx.x & 63) == leader) atomicAdd(&m_counts[lidx], c);
     if (mine) pending = false;
   }
-  if (pending) atomicAdd(&m_counts[idx], 1u);
+  if (pending) atomicAdd(&m_counts[held], held_cnt);
 }
 
 // ---- round 2 (static_lookup/prover.rs:245-257), dense over the table -----------------------------------
@@ -207,8 +230,8 @@ int cq_table_build_index(cq_ctx* c, const Fr* values, uint32_t N, uint32_t** slo
   return CQ_OK;
 }
 
-int cq_round1(cq_ctx* c, const CqRound1Args& a, uint32_t u, uint32_t* m_counts, uint32_t* err_dev) {
-  if (u) cq_round1_kernel<<<blocks_for(u), 256, 0, c->stream>>>(a, u, m_counts, err_dev);
+int cq_round1(cq_ctx* c, const CqRound1Batch& b, uint32_t u, uint32_t* err_dev) {
+  if (u && b.count) cq_round1_kernel<<<dim3((u + 256 * R1_ROWS - 1) / (256 * R1_ROWS), b.count), 256, 0, c->stream>>>(b, u, err_dev);
   return hipGetLastError() == hipSuccess ? CQ_OK : c->fail(CQ_ERR_HIP, "cq_round1 launch failed");
 }
 

@@ -20,6 +20,14 @@ struct CqRound1Args {
   uint32_t nslots[CQ_MAX_WIDTH];
   uint32_t width;
 };
+// several lookups of one proof in a single launch (blockIdx.y = lookup): the kernel is bound by the latency of its
+// dependent probes, so independent lookups overlap instead of queueing
+constexpr uint32_t CQ_ROUND1_BATCH = 8;
+struct CqRound1Batch {
+  CqRound1Args a[CQ_ROUND1_BATCH];
+  uint32_t* m_counts[CQ_ROUND1_BATCH];
+  uint32_t count;
+};
 struct CqThetaPowers {
   Fr pow[CQ_MAX_WIDTH];  // theta^(width-1-j)
   uint32_t width;
@@ -29,7 +37,7 @@ struct ShaCols {
 };
 
 int cq_table_build_index(cq_ctx* c, const Fr* values, uint32_t N, uint32_t** slots_out, uint32_t* nslots_out);
-int cq_round1(cq_ctx* c, const CqRound1Args& a, uint32_t u, uint32_t* m_counts, uint32_t* err_dev);
+int cq_round1(cq_ctx* c, const CqRound1Batch& b, uint32_t u, uint32_t* err_dev);
 int cq_a_denominators(cq_ctx* c, const Fr* t, const uint32_t* m, uint32_t N, const Fr& beta, Fr* den);
 int cq_a_values(cq_ctx* c, const Fr* den_inv, const uint32_t* m, uint32_t N, const CqThetaPowers& tp, Fr* a, Fr* a_scaled);
 int cq_m_to_fr(cq_ctx* c, const uint32_t* m, uint32_t N, Fr* out);

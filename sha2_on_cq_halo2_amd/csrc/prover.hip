@@ -647,6 +647,8 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, const uint64_
   bool adv_is_coeff = false;
   if (L) CQ_HIP(c, hipMemsetAsync(m_counts, 0, (L * N + 16) * sizeof(uint32_t), s));
   size_t input_slot = 0;
+  CqRound1Batch r1b;
+  r1b.count = 0;
   for (size_t l = 0; l < L; l++) {
     const cq_lookup_desc& lk = pk->lookups[l];
     const uint32_t w = (uint32_t)lk.cols.size();
@@ -685,7 +687,7 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, const uint64_
       p = p * theta;
     }
     CQ_TRY(poly_lincomb(c, la, (uint32_t)n, f_lag + l * n));
-    CqRound1Args ra;
+    CqRound1Args& ra = r1b.a[r1b.count];
     ra.width = w;
     for (uint32_t j = 0; j < w; j++) {
       ra.cols[j] = input[j];
@@ -693,10 +695,14 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, const uint64_
       ra.slots[j] = lk.tables[j]->slots;
       ra.nslots[j] = lk.tables[j]->nslots;
     }
-    CQ_TRY(cq_round1(c, ra, u, m_counts + l * N, err_dev));
-    CQ_TRY(cq_m_to_fr(c, m_counts + l * N, (uint32_t)N, m_fr + l * N));
+    r1b.m_counts[r1b.count++] = m_counts + l * N;
+    if (r1b.count == CQ_ROUND1_BATCH || l + 1 == L) {  // the lookups of a proof share launches
+      CQ_TRY(cq_round1(c, r1b, u, err_dev));
+      r1b.count = 0;
+    }
   }
   if (L) {
+    CQ_TRY(cq_m_to_fr(c, m_counts, (uint32_t)(L * N), m_fr));  // the L vectors are adjacent
     uint32_t herr = 0;
     CQ_HIP(c, hipMemcpyAsync(&herr, err_dev, 4, hipMemcpyDeviceToHost, s));
     CQ_HIP(c, hipStreamSynchronize(s));
