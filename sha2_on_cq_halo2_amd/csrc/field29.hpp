@@ -25,6 +25,7 @@ struct Consts29 {
   uint32_t one[9];      // R' mod p      (the field's 1)
   uint32_t to256[9];    // 2^256 mod p   : mul(x, to256) turns x R' into x R
   uint32_t from256[9];  // 2^266 mod p   : mul(y, from256) turns y = x R into x R'
+  uint32_t c271[9];     // 2^271 mod p   : mul(z R, c271) = z 2^266, the constant that converts AND scales by z (ntt.hip)
 };
 struct Limbs29 {
   uint32_t l[9];
@@ -71,6 +72,7 @@ constexpr Consts29 make_consts29() {
   pow2_mod_p29<P>(261, c.one);
   pow2_mod_p29<P>(256, c.to256);
   pow2_mod_p29<P>(266, c.from256);
+  pow2_mod_p29<P>(271, c.c271);
   return c;
 }
 template <class P>
@@ -249,5 +251,6 @@ struct Fp29 {
 };
 
 using Fq29 = Fp29<FqP>;
+using Fr29 = Fp29<FrP>;
 
 }  // namespace cq

@@ -30,42 +30,81 @@ __global__ void fr_powers_kernel(Fr* out, Fr base, uint64_t step, uint32_t count
   out[j] = base.pow_u64((uint64_t)j * step);
 }
 
-static __device__ __forceinline__ Fr lds_load(const uint4* lo, const uint4* hi, uint32_t i) {
-  Fr r;
-  uint4 a = lo[i], b = hi[i];
-  r.v.l[0] = a.x; r.v.l[1] = a.y; r.v.l[2] = a.z; r.v.l[3] = a.w;
-  r.v.l[4] = b.x; r.v.l[5] = b.y; r.v.l[6] = b.z; r.v.l[7] = b.w;
+// ---- arithmetic of the passes ------------------------------------------------------------------------------------
+// The butterflies run on the lazy 9 x 29-bit field type (field29.hpp: Montgomery form with R' = 2^261, values in
+// [0, K p), no packing / conditional subtraction between operations) -- a product is 226 instructions instead of the
+// ~330 of the canonical 8 x u32 type, and the additions need no compare-and-subtract.  Bounds: every table constant
+// is canonical (< p, K = 1); an element entering level r of the in-LDS FFT is below B_r p with B_0 = 2, and a level
+// doubles the bound (s = u + v, d = u - v + B_r p, the latter below 2 p again when it is multiplied by a root), so
+// B_r = 2^(r+1) <= 64 and every product has Ka * Kb <= 128 * 1.  Each element passes through exactly one more
+// product per pass, at the STORE: times the next pass's twiddle (or 1) between passes -- so the scratch holds values
+// below 2 p, packed -- and times the output factor in the last pass, where the constant is the factor's R = 2^256
+// limbs, which turns R' form into the caller's R form in the same product.  The first pass converts on load the
+// same way (times 2^266, or z 2^266 for the coset shift).  Results are the same field elements as before, stored
+// canonically.
+static __device__ __forceinline__ Fr29 lds_load29(const uint32_t* sm, uint32_t E, uint32_t i) {
+  Fr29 r;
+  CQ_UNROLL for (int l = 0; l < 9; l++) r.a[l] = sm[l * E + i];
   return r;
 }
-static __device__ __forceinline__ void lds_store(uint4* lo, uint4* hi, uint32_t i, const Fr& r) {
-  lo[i] = make_uint4(r.v.l[0], r.v.l[1], r.v.l[2], r.v.l[3]);
-  hi[i] = make_uint4(r.v.l[4], r.v.l[5], r.v.l[6], r.v.l[7]);
+static __device__ __forceinline__ void lds_store29(uint32_t* sm, uint32_t E, uint32_t i, const Fr29& r) {
+  CQ_UNROLL for (int l = 0; l < 9; l++) sm[l * E + i] = r.a[l];
 }
-static __device__ __forceinline__ Fr g_load(const Fr* p) {
+static __device__ __forceinline__ Fr29 g_load29(const Fr* p) {  // 8 x u32 -> limbs (no arithmetic)
   const uint4* q = reinterpret_cast<const uint4*>(p);
-  uint4 a = q[0], b = q[1];
-  Fr r;
-  r.v.l[0] = a.x; r.v.l[1] = a.y; r.v.l[2] = a.z; r.v.l[3] = a.w;
-  r.v.l[4] = b.x; r.v.l[5] = b.y; r.v.l[6] = b.z; r.v.l[7] = b.w;
+  const uint4 a = q[0], b = q[1];
+  const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+  return Fr29::unpack(w);
+}
+static __device__ __forceinline__ void g_store29(Fr* p, const Fr29& x, bool canonical) {  // x < 2 p, normalised
+  uint32_t w[8];
+  x.pack(w);
+  if (canonical) Fr::cond_sub_p(w, 0);
+  uint4* q = reinterpret_cast<uint4*>(p);
+  q[0] = make_uint4(w[0], w[1], w[2], w[3]);
+  q[1] = make_uint4(w[4], w[5], w[6], w[7]);
+}
+static __device__ __forceinline__ Fr29 const29(const uint32_t* c) {
+  Fr29 r;
+  CQ_UNROLL for (int l = 0; l < 9; l++) r.a[l] = c[l];
   return r;
 }
-static __device__ __forceinline__ void g_store(Fr* p, const Fr& r) {
-  uint4* q = reinterpret_cast<uint4*>(p);
-  q[0] = make_uint4(r.v.l[0], r.v.l[1], r.v.l[2], r.v.l[3]);
-  q[1] = make_uint4(r.v.l[4], r.v.l[5], r.v.l[6], r.v.l[7]);
+// value < 2 p -> the canonical representative (< p)
+static __device__ __forceinline__ Fr29 canon29(const Fr29& x) {
+  uint32_t w[8];
+  x.pack(w);
+  Fr::cond_sub_p(w, 0);
+  return Fr29::unpack(w);
+}
+// u - v + K p for v < K p, K = 2^(rnd+1)
+static __device__ __forceinline__ Fr29 sub_level(const Fr29& u, const Fr29& v, uint32_t rnd) {
+  switch (rnd) {
+    case 0: return Fr29::sub<2>(u, v);
+    case 1: return Fr29::sub<4>(u, v);
+    case 2: return Fr29::sub<8>(u, v);
+    case 3: return Fr29::sub<16>(u, v);
+    case 4: return Fr29::sub<32>(u, v);
+    default: return Fr29::sub<64>(u, v);
+  }
 }
 
+// one-off: table of R = 2^256 Montgomery values -> canonical R' = 2^261 values, in place
+__global__ void ntt_table_to29_kernel(Fr* t, uint32_t count) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= count) return;
+  g_store29(t + j, Fr29::mul(g_load29(t + j), const29(CONSTS29<FrP>.from256)), true);
+}
+
+static_assert(NTT_MAX_DEG <= 6, "sub_level: B_r = 2^(r+1) <= 64");
 static __device__ __forceinline__ uint32_t bitrev(uint32_t x, uint32_t bits) {
   return bits ? (__brev(x) >> (32 - bits)) : 0;
 }
 
 __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(NttPassArgs a) {
-  extern __shared__ uint4 smem[];
+  extern __shared__ uint32_t smem29[];
   const uint32_t D = 1u << a.deg;
   const uint32_t T = 1u << a.log_t;
   const uint32_t E = D * T;
-  uint4* lo = smem;
-  uint4* hi = smem + E;
   const uint32_t n = 1u << a.log_n;
   const uint32_t t = n >> a.deg;
   const uint32_t p = 1u << a.lgp;
@@ -74,39 +113,35 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(NttPassArgs a) {
   const Fr* in = a.in + (size_t)batch * a.in_stride;
   Fr* out = a.out + (size_t)batch * a.out_stride;
   const uint32_t index0 = tile * T;
+  const bool first = a.lgp == 0, last = a.next_deg == 0;
 
-  // ---- load tile: element (row i, col c) <- in[index0 + c + i*t] * twiddle ----
+  // ---- load tile: element (row i, col c) <- in[index0 + c + i*t] ----
+  // first pass: R form -> R' form (times 2^266), with the coset factor zeta^(g mod 3) folded into the constant;
+  // later passes: the previous pass already applied this pass's twiddle and left R' values below 2 p
+  Fr29 cload[3];
+  if (first) {
+    cload[0] = const29(CONSTS29<FrP>.from256);
+    if (a.flags & NTT_IN_COSET) {
+      const Fr29 k271 = const29(CONSTS29<FrP>.c271);
+      cload[1] = Fr29::mul(Fr29::unpack(a.in_coset[0].v.l), k271);  // z 2^266, < 2 p
+      cload[2] = Fr29::mul(Fr29::unpack(a.in_coset[1].v.l), k271);
+    } else {
+      cload[1] = cload[2] = cload[0];
+    }
+  }
   for (uint32_t e = threadIdx.x; e < E; e += NTT_THREADS) {
     const uint32_t c = e & (T - 1);
     const uint32_t i = e >> a.log_t;
-    const uint32_t index = index0 + c;
-    const uint32_t g = index + i * t;
-    Fr x;
+    const uint32_t g = index0 + c + i * t;
+    Fr29 x = Fr29::zero();
     if (g < a.in_len) {
-      x = g_load(in + g);
-      if (a.flags & NTT_IN_COSET) {
-        const uint32_t m = g % 3;
-        if (m) x = x * a.in_coset[m - 1];
+      x = g_load29(in + g);
+      if (first) {
+        const uint32_t m = (a.flags & NTT_IN_COSET) ? g % 3 : 0;
+        x = Fr29::mul(x, m == 0 ? cload[0] : (m == 1 ? cload[1] : cload[2]));  // 1 * 2
       }
-      if (a.lgp) {
-        const uint32_t k = index & (p - 1);
-        // exponent of w_n: (n >> lgp >> deg) * k * i  < n
-        const uint32_t ex = ((n >> a.lgp) >> a.deg) * k * i;
-        if (ex) {
-          if (a.tw_full) {
-            x = x * g_load(a.tw_full + ex);
-          } else {
-            Fr w = g_load(a.tw_lo + (ex & ((1u << a.tw_l) - 1)));
-            const uint32_t h = ex >> a.tw_l;
-            if (h) w = w * g_load(a.tw_hi + h);
-            x = x * w;
-          }
-        }
-      }
-    } else {
-      x = Fr::zero();
     }
-    lds_store(lo, hi, i * T + c, x);
+    lds_store29(smem29, E, i * T + c, x);
   }
   __syncthreads();
 
@@ -120,29 +155,64 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(NttPassArgs a) {
       const uint32_t di = b & (bit - 1);
       const uint32_t i0 = (b << 1) - di;
       const uint32_t i1 = i0 + bit;
-      Fr u = lds_load(lo, hi, i0 * T + c);
-      Fr v = lds_load(lo, hi, i1 * T + c);
-      Fr s = u + v;
-      Fr d = u - v;
-      if (di) d = d * g_load(a.pq + ((size_t)(di << rnd) << a.pq_shift));
-      lds_store(lo, hi, i0 * T + c, s);
-      lds_store(lo, hi, i1 * T + c, d);
+      const Fr29 u = lds_load29(smem29, E, i0 * T + c);
+      const Fr29 v = lds_load29(smem29, E, i1 * T + c);
+      Fr29 s = u + v;  // < 2 B_r p
+      s.normalise();
+      Fr29 d = sub_level(u, v, rnd);  // < 2 B_r p
+      if (di) d = Fr29::mul(d, g_load29(a.pq + ((size_t)(di << rnd) << a.pq_shift)));  // 2 B_r * 1 <= 128
+      lds_store29(smem29, E, i0 * T + c, s);
+      lds_store29(smem29, E, i1 * T + c, d);
     }
     __syncthreads();
   }
 
-  // ---- store: output digit i' (bit-reversed LDS row) -> out[((index-k)<<deg) + k + i'*p] ----
+  // ---- store: output digit i' (bit-reversed LDS row) -> out[((index-k)<<deg) + k + i'*p], through one product ----
+  Fr29 cstore[3];
+  if (last) {
+    // R' -> R with the output factor: the constant is the factor's own R = 2^256 limbs (1 -> R mod p)
+    if (a.flags & NTT_OUT_MUL) {
+      cstore[0] = Fr29::unpack(a.out_mul[0].v.l);
+      if (a.flags & NTT_OUT_COSET) {
+        cstore[1] = Fr29::unpack(a.out_mul[1].v.l);
+        cstore[2] = Fr29::unpack(a.out_mul[2].v.l);
+      } else {
+        cstore[1] = cstore[2] = cstore[0];
+      }
+    } else {
+      cstore[0] = cstore[1] = cstore[2] = Fr29::unpack(Fr::one().v.l);
+    }
+  }
+  const uint32_t lgp2 = a.lgp + a.deg;          // the next pass: p' = 2^lgp2, t' = n >> next_deg
+  const uint32_t log_t2 = a.log_n - a.next_deg;
   for (uint32_t e = threadIdx.x; e < E; e += NTT_THREADS) {
     const uint32_t c = e & (T - 1);
     const uint32_t i = e >> a.log_t;
     const uint32_t index = index0 + c;
     const uint32_t k = index & (p - 1);
     const uint32_t g = ((index - k) << a.deg) + k + i * p;
-    if (g < a.out_len) {
-      Fr x = lds_load(lo, hi, bitrev(i, a.deg) * T + c);
-      if (a.flags & NTT_OUT_MUL) x = x * a.out_mul[(a.flags & NTT_OUT_COSET) ? (g % 3) : 0];
-      g_store(out + g, x);
+    if (g >= a.out_len) continue;
+    const Fr29 x = lds_load29(smem29, E, bitrev(i, a.deg) * T + c);  // < 128 p
+    if (last) {
+      const uint32_t m = (a.flags & NTT_OUT_COSET) ? g % 3 : 0;
+      g_store29(out + g, Fr29::mul(x, m == 0 ? cstore[0] : (m == 1 ? cstore[1] : cstore[2])), true);
+      continue;
     }
+    // twiddle of the next pass for the element it will read at g: row i2 = g / t', index2 = g mod t',
+    // exponent (n >> lgp2 >> next_deg) * (index2 mod 2^lgp2) * i2  < n
+    const uint32_t i2 = g >> log_t2, index2 = g & ((1u << log_t2) - 1);
+    const uint32_t ex = ((n >> lgp2) >> a.next_deg) * (index2 & ((1u << lgp2) - 1)) * i2;
+    Fr29 w;
+    if (!ex) {
+      w = const29(CONSTS29<FrP>.one);
+    } else if (a.tw_full) {
+      w = g_load29(a.tw_full + ex);
+    } else {
+      w = g_load29(a.tw_lo + (ex & ((1u << a.tw_l) - 1)));
+      const uint32_t h = ex >> a.tw_l;
+      if (h) w = canon29(Fr29::mul(w, g_load29(a.tw_hi + h)));
+    }
+    g_store29(out + g, Fr29::mul(x, w), false);  // 128 * 1
   }
 }
 
@@ -175,6 +245,11 @@ int NttTables::build(uint32_t log_n_, const Fr& omega_, hipStream_t stream) {
     (void)hipGetLastError();
   // pq[j] = (w_n^(n / 2^pq_log))^j : roots for the largest in-LDS FFT
   fr_powers_kernel<<<(pq_cnt + 255) / 256, 256, 0, stream>>>(pq, omega, (uint64_t)1 << (log_n - pq_log), pq_cnt);
+  // the passes compute on the lazy 29-bit field: tables in its (canonical) R' = 2^261 form
+  ntt_table_to29_kernel<<<(lo_cnt + 255) / 256, 256, 0, stream>>>(tw_lo, lo_cnt);
+  ntt_table_to29_kernel<<<(hi_cnt + 255) / 256, 256, 0, stream>>>(tw_hi, hi_cnt);
+  if (tw_full) ntt_table_to29_kernel<<<((1u << log_n) + 255) / 256, 256, 0, stream>>>(tw_full, 1u << log_n);
+  ntt_table_to29_kernel<<<(pq_cnt + 255) / 256, 256, 0, stream>>>(pq, pq_cnt);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
@@ -209,6 +284,7 @@ int ntt_run(const NttTables& tb, const Fr* in, Fr* out, Fr* scratch, const NttIo
     a.log_n = log_n;
     a.lgp = lgp;
     a.deg = degs[ps];
+    a.next_deg = last ? 0 : degs[ps + 1];
     const uint32_t t = n >> degs[ps];
     uint32_t log_t = 0;
     while ((1u << (log_t + 1)) <= t && ((1u << (log_t + 1)) << degs[ps]) <= NTT_TILE_ELEMS) log_t++;
@@ -244,7 +320,7 @@ int ntt_run(const NttTables& tb, const Fr* in, Fr* out, Fr* scratch, const NttIo
     }
     const uint32_t T = 1u << log_t;
     dim3 grid(t / T, io.batch);
-    const size_t lds = (size_t)(T << degs[ps]) * 32;
+    const size_t lds = (size_t)(T << degs[ps]) * 36;  // nine 32-bit limb planes
     hipEvent_t pe = io.prof ? io.prof->prof_begin(CQ_PROF_NTT_PASS) : nullptr;
     ntt_pass_kernel<<<grid, NTT_THREADS, lds, stream>>>(a);
     if (io.prof) io.prof->prof_end(pe);

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "field.hpp"
+#include "field29.hpp"
 
 struct cq_ctx;
 
@@ -24,6 +25,8 @@ struct NttPassArgs {
   Fr* out;
   size_t in_stride, out_stride;  // batch strides, in elements
   uint32_t log_n, lgp, deg, log_t;
+  uint32_t next_deg;  // bits the NEXT pass resolves (0: this is the last pass); its twiddles are applied at this pass's store
+  // twiddle tables hold the kernels' own form: canonical values in Montgomery form with R' = 2^261, packed into 8 x u32
   const Fr* tw_lo;  // w^j, j < 2^tw_l
   const Fr* tw_hi;  // w^(j << tw_l)
   const Fr* tw_full;  // w^j, j < n (nullptr: compose tw_lo * tw_hi)
