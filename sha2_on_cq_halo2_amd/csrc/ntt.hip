@@ -3,17 +3,17 @@
 //
 // Algorithm (not the reference's bit-reverse + recursive butterflies): a Stockham auto-sort
 // decomposition.  log_n is split into passes of `deg` bits.  A pass with `lgp` bits already done
-// reads, for every "index" in [0, n>>deg), the 2^deg elements in[index + i*(n>>deg)], multiplies
-// element i by w^((n>>lgp>>deg) * k * i) with k = index mod 2^lgp, runs a 2^deg-point
-// decimation-in-frequency FFT in LDS, and writes output digit i' to
-// out[((index-k)<<deg) + k + i'*2^lgp].  After the last pass the data is in natural order, so
+// reads, for every "index" in [0, n>>deg), the 2^deg elements in[index + i*(n>>deg)], each carrying the
+// twiddle w^((n>>lgp>>deg) * k * i) with k = index mod 2^lgp (the PREVIOUS pass multiplied it in when it
+// stored the element, see "arithmetic of the passes"), runs a 2^deg-point decimation-in-frequency FFT
+// in LDS, and writes output digit i' to out[((index-k)<<deg) + k + i'*2^lgp].  After the last pass the data is in natural order, so
 // input and output orders match `best_fft` (natural in / natural out) with no separate
 // bit-reversal pass over HBM.
 //
 // HBM access: a workgroup owns a tile of T consecutive `index` values, so every global access is a
 // run of T consecutive 32-byte elements (T=16..32 -> 512 B..1 KiB runs), 16 B per lane.
-// LDS: the tile lives as two uint4 planes (low/high 16 bytes of each element) so that consecutive
-// elements fall in consecutive 16-byte slots -> conflict-free ds_read/write_b128.
+// LDS: the tile lives as nine planes of 32-bit limbs (field29.hpp), consecutive elements in consecutive words ->
+// conflict-free ds_read/write_b32.
 // The coset shift (zeta^(i mod 3), domain.rs:347-363), zero padding to the extended domain
 // (domain.rs:259), the 1/n scaling of the inverse transform (domain.rs:366-374) and the truncation
 // of `extended_to_coeff` (domain.rs:311-312) are fused into the first/last pass instead of being
