@@ -18,6 +18,7 @@
 // (domain.rs:259), the 1/n scaling of the inverse transform (domain.rs:366-374) and the truncation
 // of `extended_to_coeff` (domain.rs:311-312) are fused into the first/last pass instead of being
 // separate streaming passes.
+#include <cstdlib>
 #include "ntt.hpp"
 #include "ctx.hpp"
 
@@ -239,7 +240,8 @@ int NttTables::build(uint32_t log_n_, const Fr& omega_, hipStream_t stream) {
   fr_powers_kernel<<<(hi_cnt + 255) / 256, 256, 0, stream>>>(tw_hi, omega, (uint64_t)lo_cnt, hi_cnt);
   // full table (the kernels are bound by field products, not by HBM: a 32-byte load is cheaper than the product that
   // composes the two-level entry); skipped for very large domains and when memory is short
-  if (log_n >= 8 && log_n <= 24 && hipMalloc(&tw_full, sizeof(Fr) << log_n) == hipSuccess)
+  // (CQ_NTT_NO_FULL_TABLE: lets the tests exercise the two-level path that domains above 2^24 take)
+  if (log_n >= 8 && log_n <= 24 && !getenv("CQ_NTT_NO_FULL_TABLE") && hipMalloc(&tw_full, sizeof(Fr) << log_n) == hipSuccess)
     fr_powers_kernel<<<((1u << log_n) + 255) / 256, 256, 0, stream>>>(tw_full, omega, 1, 1u << log_n);
   else
     (void)hipGetLastError();

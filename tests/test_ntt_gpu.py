@@ -51,3 +51,23 @@ def test_best_fft_len_mismatch(ctx):
 
     with pytest.raises(CqError):
         ctx.best_fft(np.zeros((3, 4), dtype=np.uint64), np.zeros(4, dtype=np.uint64), 2)
+
+
+def test_best_fft_two_level_twiddles(monkeypatch):
+    """Domains above 2^24 have no full twiddle table: the inter-pass twiddle is composed from two small tables (and
+    brought back to the canonical range the products' bounds assume).  Forced here at a small size, on a context of
+    its own so that its twiddle cache is built under the switch; against the C oracle's best_fft."""
+    from oracle import cbind as OC
+    from sha2_on_cq_halo2_amd import Context
+
+    monkeypatch.setenv("CQ_NTT_NO_FULL_TABLE", "1")
+    c2 = Context(0)
+    try:
+        for log_n in (9, 13, 14):
+            rs = np.random.RandomState(log_n)
+            a = rs.randint(0, 2**63, size=(1 << log_n, 4), dtype=np.int64).astype(np.uint64)
+            a[:, 3] &= np.uint64((1 << 60) - 1)
+            w = B.to_mont_limbs([_omega(log_n)])[0]
+            assert np.array_equal(c2.best_fft(a, w, log_n), OC.best_fft(a, w, log_n))
+    finally:
+        c2.close()
