@@ -811,12 +811,14 @@ int msm_run(cq_ctx* ctx, const Fr* const* scalars_host_ptrs, const G1Affine* con
   const uint64_t* d_lens = (const uint64_t*)((const void**)d_scalars + 3 * batch);
   // counts and buckets (identity = all zero) are adjacent: one memset
   if (hipMemsetAsync(counts, 0, L.zero_end - L.off_counts, s) != hipSuccess) return -1;
-  // Sub-list length of the accumulate level.  Short lists keep a small launch (two MSMs: 32 K buckets) parallel and
-  // balanced; a launch with tens of millions of entries has lanes to spare, and longer lists halve the partial sums
-  // its combine level has to add up.  (The workspace is sized for MSM_S1, the smaller of the two.)
-  uint64_t entries_max = 0;
-  for (uint32_t i = 0; i < batch; i++) entries_max += (uint64_t)lens[i] * W;
-  const uint32_t s1 = entries_max >= MSM_S1_BIG_ENTRIES ? MSM_S1_BIG : MSM_S1;
+  // Sub-list length of the accumulate level, from the expected load of a bucket (entries of the launch's longest
+  // MSM / buckets).  Short lists keep a k = 18 launch (272 entries per bucket) parallel and balanced; with thousands
+  // of entries per bucket there are lanes to spare, and the partial sums per bucket must stay few: past MSM_SHORT of
+  // them a bucket falls to the wave-per-256 combine, which at k = 22 (4352 entries per bucket, 136 partial sums of
+  // 32) cost 17 ms of a 133 ms proof.  (The workspace is sized for MSM_S1, the smallest value.)
+  uint64_t load = 0;
+  for (uint32_t i = 0; i < batch; i++) load = std::max<uint64_t>(load, (uint64_t)lens[i] * W / (L.Wb * M));
+  const uint32_t s1 = load <= MSM_S1_BIG_LOAD ? MSM_S1 : std::max<uint32_t>(MSM_S1_BIG, (uint32_t)((load + MSM_PARTIALS_TARGET - 1) / MSM_PARTIALS_TARGET));
   const uint32_t* off0 = off;
   if (L.part_sort) {
     const uint32_t P = batch * L.npart;

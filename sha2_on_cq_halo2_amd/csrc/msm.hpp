@@ -17,11 +17,15 @@ constexpr uint32_t MSM_S1 = CQ_MSM_S1;  // max point indices summed by one lane 
 #ifndef CQ_MSM_S1_BIG
 #define CQ_MSM_S1_BIG 32
 #endif
-#ifndef CQ_MSM_S1_BIG_ENTRIES
-#define CQ_MSM_S1_BIG_ENTRIES 64000000ull
+#ifndef CQ_MSM_S1_BIG_LOAD
+#define CQ_MSM_S1_BIG_LOAD 512
 #endif
-constexpr uint32_t MSM_S1_BIG = CQ_MSM_S1_BIG;  // ... in launches of at least MSM_S1_BIG_ENTRIES (scalar, window) pairs
-constexpr uint64_t MSM_S1_BIG_ENTRIES = CQ_MSM_S1_BIG_ENTRIES;
+constexpr uint32_t MSM_S1_BIG = CQ_MSM_S1_BIG;  // ... at least this when a bucket expects more than MSM_S1_BIG_LOAD entries
+constexpr uint32_t MSM_S1_BIG_LOAD = CQ_MSM_S1_BIG_LOAD;
+#ifndef CQ_MSM_PARTIALS_TARGET
+#define CQ_MSM_PARTIALS_TARGET 48
+#endif
+constexpr uint32_t MSM_PARTIALS_TARGET = CQ_MSM_PARTIALS_TARGET;  // partial sums per bucket aimed at under heavy load (< MSM_SHORT)
 static_assert(MSM_S1_BIG >= MSM_S1, "the workspace is sized for MSM_S1");
 constexpr uint32_t MSM_S2 = 256;        // max partial sums summed by one wave (levels >= 2)
 constexpr uint32_t MSM_SHORT = 64;       // level >= 2 lists up to this long are summed by one lane
