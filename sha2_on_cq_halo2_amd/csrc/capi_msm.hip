@@ -53,8 +53,8 @@ int msm_multi_begin(cq_ctx* c, const Fr* const* scalars, const G1Affine* const* 
       batch++;
     }
     const uint32_t cb = pre ? t0->c : pick_c(c, nmax);
-    // keep the workspace below ~8 GiB
-    while (batch > 1 && MsmLayout(nmax, cb, batch, pre).total > ((size_t)8 << 30)) batch = (batch + 1) / 2;
+    // keep the workspace below ~32 GiB (of 288)
+    while (batch > 1 && MsmLayout(nmax, cb, batch, pre).total > ((size_t)32 << 30)) batch = (batch + 1) / 2;
     ln.batch = batch;
     ln.pre = pre;
     ln.c = cb;
