@@ -648,8 +648,8 @@ int msm_precompute_tables(cq_ctx* ctx, const G1Affine* bases, uint32_t n, uint32
 // Every dependent EC addition costs a lone wave ~9 us whatever the number of busy lanes, so the reduction is shaped
 // for depth, not work.  Buckets are read as a rows x cols matrix (b = cols * hi + lo + 1, cols = min(M, 128)):
 //     sum_b b B_b  =  cols * sum_hi hi R_hi  +  sum_lo (lo + 1) C_lo,     R = row sums, C = column sums.
-// Kernel 1: 16 lanes per row / column sum (<= 8 buckets per lane serially, then a 4-level shuffle tree), four lines
-// per wave, all independent.  Kernel 2: per bucket set two waves, one per weighted sum of <= 128 terms
+// Kernel 1: 16 or 64 lanes per row / column sum (a few buckets per lane serially, then a shuffle tree), all lines
+// independent.  Kernel 2: per bucket set two waves, one per weighted sum of <= 128 terms
 // (pair sums, suffix scan by shuffles, one tree); the host applies "cols *" and joins the two.  ~11 + ~16 dependent
 // operations instead of the ~46 of a lane-serial running sum over 1024-bucket groups.
 static __device__ __forceinline__ XYZZ29 wave_sum(XYZZ29 v) {
@@ -661,27 +661,30 @@ static __device__ __forceinline__ XYZZ29 wave_sum(XYZZ29 v) {
   return v;  // lane 0 holds the sum
 }
 
-// A wave serves RC_LINES rows (or columns): RC_SEG lanes per line, each summing cols / RC_SEG consecutive buckets of
-// it serially (every lane busy), then a log2(RC_SEG)-level shuffle tree.  With one wave per line and a 6-level tree
-// only a quarter of the lane-operations were useful and the kernel was VALU-throughput bound at batch 16.
-constexpr uint32_t RC_SEG = 16, RC_LINES = 64 / RC_SEG;
+// A wave serves 64 / SEG rows (or columns): SEG lanes per line, each summing cols / SEG consecutive buckets of it
+// serially, then a log2(SEG)-level shuffle tree.  SEG = 16 (depth 8 + 4, every lane busy in the serial part) when a
+// launch has many bucket sets -- with one wave per line and a 6-level tree only a quarter of the lane-operations were
+// useful and the kernel was VALU-throughput bound at batch 16; SEG = 64 (depth 2 + 6) for launches of a few sets,
+// which are latency-bound and leave most SIMDs idle anyway.
+template <uint32_t SEG>
 __global__ __launch_bounds__(64) void msm_rowcol_kernel(const XYZZ* __restrict__ buckets, uint32_t M, uint32_t rows, uint32_t cols,
                                                         XYZZ* __restrict__ sums /*[sets][rows + cols]*/) {
+  constexpr uint32_t LINES = 64 / SEG;
   const uint32_t set = blockIdx.y, lane = threadIdx.x;
-  const uint32_t q = blockIdx.x * RC_LINES + lane / RC_SEG, seg = lane % RC_SEG;  // line: row q or column q - rows
+  const uint32_t q = blockIdx.x * LINES + lane / SEG, seg = lane % SEG;  // line: row q or column q - rows
   const XYZZ* Bk = buckets + (size_t)set * M;
   XYZZ29 acc = XYZZ29::identity();
   if (q < rows) {  // R_q = sum_lo B[q][lo]
-    const uint32_t per = (cols + RC_SEG - 1) / RC_SEG;
+    const uint32_t per = (cols + SEG - 1) / SEG;
     for (uint32_t lo = seg * per; lo < min(cols, (seg + 1) * per); lo++) xyzz29_add(acc, load_xyzz29(Bk + (size_t)q * cols + lo));
   } else if (q < rows + cols) {  // C_lo = sum_hi B[hi][lo]
-    const uint32_t lo = q - rows, per = (rows + RC_SEG - 1) / RC_SEG;
+    const uint32_t lo = q - rows, per = (rows + SEG - 1) / SEG;
     for (uint32_t hi = seg * per; hi < min(rows, (seg + 1) * per); hi++) xyzz29_add(acc, load_xyzz29(Bk + (size_t)hi * cols + lo));
   }
 #pragma unroll 1
-  for (int delta = RC_SEG / 2; delta >= 1; delta >>= 1) {
-    XYZZ29 o = xyzz29_shfl_down(acc, delta);  // lanes seg + delta >= RC_SEG read the next line's lanes: not used
-    if (seg + delta < RC_SEG) xyzz29_add(acc, o);
+  for (int delta = SEG / 2; delta >= 1; delta >>= 1) {
+    XYZZ29 o = xyzz29_shfl_down(acc, delta);  // lanes seg + delta >= SEG read the next line's lanes: not used
+    if (seg + delta < SEG) xyzz29_add(acc, o);
   }
   if (seg == 0 && q < rows + cols) store_xyzz29(sums + (size_t)set * (rows + cols) + q, acc);
 }
@@ -868,7 +871,10 @@ int msm_run(cq_ctx* ctx, const Fr* const* scalars_host_ptrs, const G1Affine* con
     msm_combine_kernel<<<(uint32_t)((L.tmax[k] + 3) / 4), 256, 0, s>>>(part[(k - 1) & 1], t_prev, off_prev, t_cur, off_cur, Bt,
                                                                        part[k & 1], buckets);
   }
-  msm_rowcol_kernel<<<dim3((L.rows + L.cols + RC_LINES - 1) / RC_LINES, batch * L.Wb), 64, 0, s>>>(buckets, M, L.rows, L.cols, pairs);
+  if (batch * L.Wb <= 4)
+    msm_rowcol_kernel<64><<<dim3(L.rows + L.cols, batch * L.Wb), 64, 0, s>>>(buckets, M, L.rows, L.cols, pairs);
+  else
+    msm_rowcol_kernel<16><<<dim3((L.rows + L.cols + 3) / 4, batch * L.Wb), 64, 0, s>>>(buckets, M, L.rows, L.cols, pairs);
   msm_weighted_kernel<<<batch * L.Wb, 128, 0, s>>>(pairs, L.rows, L.cols, window_sums_dev);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
