@@ -172,15 +172,15 @@ static_assert(PART_MAX == 128 && PART_BUCKETS == 128 && PART_MAX <= DIGITS_LDS_T
 
 __global__ __launch_bounds__(DIGITS_LDS_THREADS) void msm_part_hist_kernel(const Fr* const* __restrict__ scalars,
                                                                            const uint64_t* __restrict__ lens, uint32_t c, uint32_t nwin,
-                                                                           uint32_t npart, uint32_t* __restrict__ psize) {
+                                                                           uint32_t npart, uint32_t per_lane, uint32_t* __restrict__ psize) {
   __shared__ uint32_t hist[PART_MAX];
   const uint32_t m = blockIdx.y, t = threadIdx.x;
   const uint32_t len = (uint32_t)lens[m];
-  const uint32_t base = blockIdx.x * DIGITS_LDS_CHUNK;
+  const uint32_t base = blockIdx.x * DIGITS_LDS_THREADS * per_lane;
   if (base >= len) return;  // block-uniform
   if (t < npart) hist[t] = 0;
   __syncthreads();
-  for (uint32_t k = 0; k < DIGITS_LDS_PER_LANE; k++) {
+  for (uint32_t k = 0; k < per_lane; k++) {
     const uint32_t i = base + k * DIGITS_LDS_THREADS + t;
     if (i >= len) continue;
     const U256 v = scalars[m][i].to_canonical();
@@ -830,8 +830,12 @@ int msm_run(cq_ctx* ctx, const Fr* const* scalars_host_ptrs, const G1Affine* con
     uint32_t* cursor = (uint32_t*)(ws + L.off_cursor);
     uint32_t* psize = (uint32_t*)(ws + L.off_psize);
     uint32_t* pcursor = psize + P;
-    const dim3 chunks((n + DIGITS_LDS_CHUNK - 1) / DIGITS_LDS_CHUNK, batch);
-    msm_part_hist_kernel<<<chunks, DIGITS_LDS_THREADS, 0, s>>>(d_scalars, d_lens, c, W, L.npart, psize);
+    // scalars per lane of the partition histogram: few in a small launch (more workgroups in flight: the kernel is
+    // latency-bound there), DIGITS_LDS_PER_LANE in a large one (fewer device atomics: 128 per workgroup)
+    const uint32_t per_lane = (uint64_t)n * batch <= (1u << 21) ? 2u : DIGITS_LDS_PER_LANE;
+    const uint32_t hist_chunk = DIGITS_LDS_THREADS * per_lane;
+    msm_part_hist_kernel<<<dim3((n + hist_chunk - 1) / hist_chunk, batch), DIGITS_LDS_THREADS, 0, s>>>(d_scalars, d_lens, c, W, L.npart,
+                                                                                                    per_lane, psize);
     msm_part_scan_kernel<<<1, 1024, 0, s>>>(psize, P, poff);
     msm_part_scatter_kernel<<<dim3((n + PSC_THREADS - 1) / PSC_THREADS, batch), PSC_THREADS, 0, s>>>(d_scalars, d_lens, c, W, L.npart, poff, pcursor,
                                                                                                      part_buf);
