@@ -552,9 +552,10 @@ def _lower_plonk(cs, fixed, mapping, keep: list, from_raw: bool = False) -> _CqP
     pl.num_perm_columns = len(cs.permutation_columns)
     pl.perm_column_kinds = u32([c.kind for c in cs.permutation_columns])
     pl.perm_column_indices = u32([c.index for c in cs.permutation_columns])
-    if mapping is not None:
+    if mapping is not None and len(cs.permutation_columns):  # (an Assembly over no columns has an empty mapping)
         m = np.ascontiguousarray(mapping, dtype=np.uint32)
-        assert m.shape == (len(cs.permutation_columns), m.shape[1], 2)
+        if m.ndim != 3 or m.shape[0] != len(cs.permutation_columns) or m.shape[2] != 2:
+            raise CqError(-1, "permutation mapping: expected [columns][rows][2]")
         keep.append(m)
         pl.perm_mapping = m.ctypes.data_as(C.POINTER(C.c_uint32))
     return pl

@@ -2,6 +2,8 @@
 the permutation argument over several product sets, optionally next to a static lookup).  Proof BYTES must
 equal the oracle's for the same key, witness, public inputs and RNG stream; larger proofs (several scan
 tiles, extended domain 4n) are checked with the acceptance verifier."""
+import os
+
 import numpy as np
 import pytest
 
@@ -196,7 +198,7 @@ def test_legacy_lookup_failure_is_an_error(ctx):
         CP.create_proof(fx["params"], fx["pk"], adv, B.Xoshiro256ss(1), instances=fx["instances"])
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("CQ_FUZZ_SEEDS", "12"))))  # CQ_FUZZ_SEEDS=100 for a long run
 def test_random_circuits_proof_bytes_match_oracle(ctx, seed):
     """Fuzz: random gates (random expression trees, rotations in [-2, 2]), random column mix, random copy
     constraints, optional legacy / static lookups, random witness (constraints NOT satisfied -- the prover never
