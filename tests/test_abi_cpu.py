@@ -59,3 +59,23 @@ def test_no_gpu_is_an_error_not_a_fallback():
         assert False, "Context() must fail without a GPU"
     except CqError as e:
         assert e.code == -3
+
+
+def test_product_and_tools_never_import_the_oracle():
+    """oracle/ is the checker: only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import it."""
+    import os
+    import re
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    offenders = []
+    for d in ("sha2_on_cq_halo2_amd", "tools"):
+        for base, _, files in os.walk(os.path.join(root, d)):
+            for f in files:
+                if f.endswith(".py") and re.search(r"^\s*(from|import)\s+oracle\b", open(os.path.join(base, f)).read(), re.M):
+                    offenders.append(os.path.join(base, f))
+    assert offenders == []
+    # bench.py: the only oracle import sits inside cpu_baseline()
+    src = open(os.path.join(root, "bench.py")).read()
+    for m in re.finditer(r"^\s*(from|import)\s+oracle\b", src, re.M):
+        head = src[:m.start()]
+        assert head.rfind("def cpu_baseline") > max(head.rfind("\ndef " + n) for n in ("main", "plonk_variant", "two_in_flight", "ntt_standalone"))
