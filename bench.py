@@ -243,16 +243,21 @@ def two_in_flight(ctx, wl, device, reps):
     for w in wls:
         w.prove(seed=1)
         w.prove(seed=2)
-    bar = threading.Barrier(3)
+    bar = threading.Barrier(3, timeout=300)  # a failing worker breaks the barrier instead of hanging the bench
+    errors = []
 
     def worker(w):
-        bar.wait()
-        for i in range(reps):
-            w.fill_witness()
-            w.prove(seed=50 + i)
-        bar.wait()
+        try:
+            bar.wait()
+            for i in range(reps):
+                w.fill_witness()
+                w.prove(seed=50 + i)
+            bar.wait()
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+            bar.abort()
 
-    ts = [threading.Thread(target=worker, args=(w,)) for w in wls]
+    ts = [threading.Thread(target=worker, args=(w,), daemon=True) for w in wls]
     for t in ts:
         t.start()
     bar.wait()
@@ -260,7 +265,9 @@ def two_in_flight(ctx, wl, device, reps):
     bar.wait()
     dt = time.perf_counter() - t0
     for t in ts:
-        t.join()
+        t.join(timeout=60)
+    if errors:
+        raise errors[0]
     for c in ctxs:
         c.close()
     return {"proofs": 2 * reps, "proofs_per_s": 2 * reps / dt, "mscalar_per_s": 2 * reps * wl.msm_scalars_per_proof() / dt / 1e6,
