@@ -38,13 +38,16 @@
 namespace cq {
 
 // ---- pointer tables (per-MSM scalar / base arrays), written from a by-value kernel argument ------
-__global__ void msm_set_ptrs_kernel(MsmPtrs sc, MsmPtrs bs, MsmStrides st, MsmStrides ln, const void** dst, uint32_t batch) {
+// `ln`: the length the SORT sees (0 for an MSM whose entry lists are another MSM's, see msm_run); `src`: the MSM whose
+// lists an MSM accumulates from (itself, unless it shares its scalars with an earlier one)
+__global__ void msm_set_ptrs_kernel(MsmPtrs sc, MsmPtrs bs, MsmStrides st, MsmStrides ln, MsmStrides src, const void** dst, uint32_t batch) {
   const uint32_t t = threadIdx.x;
   if (t < batch) {
     dst[t] = sc.p[t];
     dst[batch + t] = bs.p[t];
     ((uint64_t*)(dst + 2 * batch))[t] = st.s[t];
     ((uint64_t*)(dst + 3 * batch))[t] = ln.s[t];
+    ((uint64_t*)(dst + 4 * batch))[t] = src.s[t];
   }
 }
 
@@ -496,7 +499,8 @@ static __device__ __forceinline__ uint32_t owner_of(const uint32_t* __restrict__
 // level 1: lane j owns sub-list j of <= MSM_S1 point indices
 __global__ __launch_bounds__(MSM_ACC_THREADS) void msm_accumulate_kernel(
     const G1Affine* const* __restrict__ bases, uint32_t buckets_per_msm, uint32_t pre,
-    const uint64_t* __restrict__ table_strides, const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ off0,
+    const uint64_t* __restrict__ table_strides, const uint64_t* __restrict__ list_src, const uint32_t* __restrict__ sorted,
+    const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ off0,
     const uint32_t* __restrict__ t1, const uint32_t* __restrict__ off1, uint32_t Bt, XYZZ* __restrict__ partial,
     XYZZ* __restrict__ buckets) {
   const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -508,9 +512,11 @@ __global__ __launch_bounds__(MSM_ACC_THREADS) void msm_accumulate_kernel(
   const uint32_t r = j - off1[g];
   // the bucket's cnt entries are cut into t = ceil(cnt / s1) sub-lists of EQUAL length (+-1): a wave runs as
   // long as its longest lane, so 40 entries are better served as 20 + 20 than as 32 + 8
+  // an MSM over the same scalars as an earlier one of the launch (b0 and p of a CQ lookup) reads that one's lists
+  const uint32_t list0 = off0[(uint32_t)list_src[msm] * buckets_per_msm + (g - msm * buckets_per_msm)];
   const uint32_t t = t1[g], n_g = cnt[g];
-  const uint32_t lo = off0[g] + (uint32_t)(((uint64_t)n_g * r) / t);
-  const uint32_t hi = off0[g] + (uint32_t)(((uint64_t)n_g * (r + 1)) / t);
+  const uint32_t lo = list0 + (uint32_t)(((uint64_t)n_g * r) / t);
+  const uint32_t hi = list0 + (uint32_t)(((uint64_t)n_g * (r + 1)) / t);
   XYZZ29 acc = XYZZ29::identity();
   // Software pipeline: the table point of entry e+1 (a dependent, essentially random 64-byte gather) and the
   // index of entry e+2 are requested before the ~10 products of entry e are computed.
@@ -752,7 +758,7 @@ MsmLayout::MsmLayout(uint32_t n_, uint32_t c_, uint32_t batch_, bool pre_) : n(n
   auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
   const uint64_t E = (uint64_t)batch * W * n;  // upper bound on (point,digit) entries
   size_t o = 0;
-  off_ptrs = o;    o = up(o + (size_t)4 * batch * sizeof(void*));
+  off_ptrs = o;    o = up(o + (size_t)5 * batch * sizeof(void*));
   // table mode: (payload, bucket) pairs of the partition pass; plain mode: one rank per entry
   part_sort = pre && M <= DIGITS_LDS_MAX_M && M >= PART_BUCKETS && W <= PSC_MAX_WIN;
   npart = part_sort ? M >> PART_BITS : 0;
@@ -802,16 +808,32 @@ int msm_run(cq_ctx* ctx, const Fr* const* scalars_host_ptrs, const G1Affine* con
   const uint32_t M = L.M, W = L.W, Bt = L.Bt;
   if (batch == 0 || batch > MSM_MAX_BATCH) return -2;
   MsmPtrs sp, bp;
-  MsmStrides stv, lnv;
+  MsmStrides stv, lnv, srcv;
+  // MSMs of one launch over the SAME scalar vector (b0 and p of a CQ lookup: same coefficients, shifted bases) have
+  // the same entry lists: the later one is not sorted (the sort sees length 0), takes a copy of the bucket counts and
+  // accumulates from the earlier one's lists.
+  uint32_t alias[MSM_MAX_BATCH];
+  bool any_alias = false;
   for (uint32_t i = 0; i < MSM_MAX_BATCH; i++) {
     sp.p[i] = i < batch ? (const void*)scalars_host_ptrs[i] : nullptr;
     bp.p[i] = i < batch ? (const void*)bases_host_ptrs[i] : nullptr;
     stv.s[i] = (i < batch && pre) ? (uint64_t)table_strides[i] : 0;
     lnv.s[i] = i < batch ? (uint64_t)lens[i] : 0;
+    alias[i] = i;
+    if (i < batch && L.part_sort)
+      for (uint32_t j = 0; j < i; j++)
+        if (alias[j] == j && scalars_host_ptrs[j] == scalars_host_ptrs[i] && lens[j] == lens[i] && lens[i]) {
+          alias[i] = j;
+          lnv.s[i] = 0;
+          any_alias = true;
+          break;
+        }
+    srcv.s[i] = alias[i];
   }
-  msm_set_ptrs_kernel<<<1, 64, 0, s>>>(sp, bp, stv, lnv, (const void**)d_scalars, batch);
+  msm_set_ptrs_kernel<<<1, 64, 0, s>>>(sp, bp, stv, lnv, srcv, (const void**)d_scalars, batch);
   const uint64_t* d_strides = (const uint64_t*)((const void**)d_scalars + 2 * batch);
   const uint64_t* d_lens = (const uint64_t*)((const void**)d_scalars + 3 * batch);
+  const uint64_t* d_src = (const uint64_t*)((const void**)d_scalars + 4 * batch);
   // counts and buckets (identity = all zero) are adjacent: one memset
   if (hipMemsetAsync(counts, 0, L.zero_end - L.off_counts, s) != hipSuccess) return -1;
   // Sub-list length of the accumulate level, from the expected load of a bucket (entries of the launch's longest
@@ -840,6 +862,11 @@ int msm_run(cq_ctx* ctx, const Fr* const* scalars_host_ptrs, const G1Affine* con
     msm_part_scatter_kernel<<<dim3((n + PSC_THREADS - 1) / PSC_THREADS, batch), PSC_THREADS, 0, s>>>(d_scalars, d_lens, c, W, L.npart, poff, pcursor,
                                                                                                      part_buf);
     msm_bucket_count_kernel<<<dim3(P, PART_SPLIT), PART_THREADS, 0, s>>>(part_buf, poff, counts);
+    if (any_alias)
+      for (uint32_t i = 0; i < batch; i++)
+        if (alias[i] != i && hipMemcpyAsync(counts + (size_t)i * L.B, counts + (size_t)alias[i] * L.B, (size_t)L.B * sizeof(uint32_t),
+                                            hipMemcpyDeviceToDevice, s) != hipSuccess)
+          return -1;
     msm_scan_reduce_kernel<<<L.nblk, 256, 0, s>>>(counts, Bt, L.nseq, s1, blocksums);
     msm_scan_spine_kernel<<<1, 1024, 0, s>>>(blocksums, L.nblk, L.nseq);
     msm_scan_apply_kernel<<<L.nblk, 256, 0, s>>>(counts, Bt, L.nseq, s1, blocksums, off, tk);
@@ -855,7 +882,7 @@ int msm_run(cq_ctx* ctx, const Fr* const* scalars_host_ptrs, const G1Affine* con
     (void)hipMemcpyAsync(ctx->prof_entries + ctx->prof_entries_n++, off0 + Bt, sizeof(uint32_t), hipMemcpyDeviceToHost, s);
   hipEvent_t pe = ctx->prof_begin(CQ_PROF_MSM_ACCUMULATE);
   msm_accumulate_kernel<<<(uint32_t)((L.tmax[0] + MSM_ACC_THREADS - 1) / MSM_ACC_THREADS), MSM_ACC_THREADS, 0, s>>>(
-      d_bases, L.B, pre ? 1u : 0u, d_strides, sorted, counts, off0, tk, off + (size_t)(Bt + 1), Bt, part[0], buckets);
+      d_bases, L.B, pre ? 1u : 0u, d_strides, d_src, sorted, counts, off0, tk, off + (size_t)(Bt + 1), Bt, part[0], buckets);
   ctx->prof_end(pe);
   if (ctx->msm_tail_event) {  // from here on the launch is latency-bound: side-stream work may start (ctx.hpp)
     (void)hipEventRecord(ctx->msm_tail_event, s);

@@ -144,3 +144,26 @@ def test_msm_precomputed_tables_same_result(ctx, n, kind):
     assert np.array_equal(pre, exp)
     m = n - 7
     assert np.array_equal(OC.g1_to_affine(ctx.best_multiexp_dev(dsc, dpts, m)), OC.g1_to_affine(OC.best_multiexp(sc[:m], pts[:m])))
+
+
+def test_msm_batch_with_repeated_scalar_vector(ctx):
+    """MSMs of one launch over the same scalar vector share their sorted entry lists (b0 and p of a CQ lookup): the
+    later one is not sorted again.  [s0, s1, s0] in one launch, table mode, against the C oracle."""
+    from oracle import cbind as OC
+
+    n = 40000
+    pts = B.points_to_mont_limbs(random_points(2048, 77))
+    pts = np.tile(pts, ((n + 2047) // 2048, 1))[:n]
+    rs = np.random.RandomState(3)
+    scs = []
+    for _ in range(2):
+        a = rs.randint(0, 2**63, size=(n, 4), dtype=np.int64).astype(np.uint64)
+        a[:, 3] &= np.uint64((1 << 60) - 1)
+        scs.append(a)
+    dpts = ctx.to_device(pts)
+    ctx.msm_precompute(dpts.ptr, n)
+    d0, d1 = ctx.to_device(scs[0]), ctx.to_device(scs[1])
+    res = ctx.msm_batch_dev([d0.ptr, d1.ptr, d0.ptr], dpts.ptr, n)
+    exp = [OC.g1_to_affine(OC.best_multiexp(s, pts)) for s in scs]
+    got = [OC.g1_to_affine(r) for r in res]
+    assert np.array_equal(got[0], exp[0]) and np.array_equal(got[1], exp[1]) and np.array_equal(got[2], exp[0])
