@@ -384,6 +384,11 @@ int cq_sha_spread_table_dev(cq_ctx* ctx, size_t size, uint64_t* dense_dev, uint6
 /* ---- harness RNG (not in the reference: its test draws from OsRng) ---------------------------------- */
 void cq_xoshiro256ss_seed(uint64_t seed, uint64_t state[4]);
 uint64_t cq_xoshiro256ss_next_u64(void* state /* uint64_t[4] */);
+/* `count` consecutive outputs of the generator above into dst, advancing the state -- the same words and final state
+ * as `count` calls of cq_xoshiro256ss_next_u64, produced by up to `threads` host threads (jump-ahead on the
+ * GF(2)-linear state transition).  cq_create_proof* draws the vanishing argument's random polynomial this way
+ * (8 * 2^k words: the RNG, not the GPU, bounds the first rounds of a large proof otherwise). */
+void cq_xoshiro256ss_fill(uint64_t state[4], uint64_t* dst, size_t count, uint32_t threads);
 /* replays a pre-drawn stream: state = {const uint64_t* words; size_t pos; size_t len} */
 typedef struct { const uint64_t* words; size_t pos; size_t len; } cq_buffer_rng;
 uint64_t cq_buffer_rng_next_u64(void* state /* cq_buffer_rng* */);

@@ -149,6 +149,8 @@ def _declare(lib):  # noqa: F811
     lib.cq_xoshiro256ss_seed.argtypes = [C.c_uint64, vp]
     lib.cq_xoshiro256ss_next_u64.restype = C.c_uint64
     lib.cq_xoshiro256ss_next_u64.argtypes = [vp]
+    lib.cq_xoshiro256ss_fill.restype = None
+    lib.cq_xoshiro256ss_fill.argtypes = [vp, vp, C.c_size_t, C.c_uint32]
     lib.cq_buffer_rng_next_u64.restype = C.c_uint64
     lib.cq_buffer_rng_next_u64.argtypes = [vp]
     lib.cq_msm_precompute_dev.argtypes = [vp, vp, C.c_size_t]

@@ -3,6 +3,7 @@
 #include <cstring>
 #include <vector>
 #include "cq.hpp"
+#include "xoshiro.hpp"
 #include "ctx.hpp"
 #include "g1fft.hpp"
 #include "plonk.hpp"
@@ -880,6 +881,9 @@ uint64_t cq_xoshiro256ss_next_u64(void* st) {
   s[2] ^= t;
   s[3] = rotl64(s[3], 45);
   return result;
+}
+void cq_xoshiro256ss_fill(uint64_t state[4], uint64_t* dst, size_t count, uint32_t threads) {
+  cq::xoshiro_fill(state, dst, count, threads);
 }
 uint64_t cq_buffer_rng_next_u64(void* st) {
   cq_buffer_rng* b = (cq_buffer_rng*)st;

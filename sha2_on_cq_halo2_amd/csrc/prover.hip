@@ -15,7 +15,9 @@
 // circuit); that dead work is skipped.
 #include <algorithm>
 #include <array>
+#include <atomic>
 #include <cstring>
+#include <thread>
 #include <vector>
 #include "blake2b.hpp"
 #include "cq.hpp"
@@ -23,6 +25,7 @@
 #include "msm.hpp"
 #include "plonk.hpp"
 #include "prover.hpp"
+#include "xoshiro.hpp"
 
 using namespace cq;
 
@@ -116,20 +119,7 @@ struct Rng {
   // call per u64 costs more than the generator: 2^21 draws per k=18 proof)
   void fill(uint64_t* dst, size_t count) {
     if (next == cq_xoshiro256ss_next_u64) {
-      uint64_t* st = (uint64_t*)state;
-      uint64_t s0 = st[0], s1 = st[1], s2 = st[2], s3 = st[3];
-      for (size_t i = 0; i < count; i++) {
-        const uint64_t r5 = s1 * 5;
-        dst[i] = ((r5 << 7) | (r5 >> 57)) * 9;
-        const uint64_t t = s1 << 17;
-        s2 ^= s0;
-        s3 ^= s1;
-        s1 ^= s2;
-        s0 ^= s3;
-        s2 ^= t;
-        s3 = (s3 << 45) | (s3 >> 19);
-      }
-      st[0] = s0; st[1] = s1; st[2] = s2; st[3] = s3;
+      xoshiro_fill((uint64_t*)state, dst, count, 8);  // several threads for long runs, the same stream (xoshiro.hpp)
     } else if (next == cq_buffer_rng_next_u64) {
       cq_buffer_rng* b = (cq_buffer_rng*)state;
       const size_t avail = b->pos < b->len ? b->len - b->pos : 0, take = std::min(avail, count);
@@ -501,17 +491,47 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, const uint64_
   }
 
   std::vector<Fr> z_tails(S * bf), plk_tails(PL * 2 * (bf + 1)), plkz_tails(PL * bf);
-  uint64_t* rng_pin = nullptr;
-  size_t rng_first = 0;
-  // second half of the vanishing argument's draws + the blind, upload, and the words -> field elements kernel
-  auto finish_random_poly = [&]() -> int {
-    if (rng_first < 8 * n) {
-      rng.fill(rng_pin + rng_first, 8 * n - rng_first);
-      CQ_HIP(c, hipMemcpyAsync(rng_dev + rng_first, rng_pin + rng_first, (8 * n - rng_first) * sizeof(uint64_t), hipMemcpyHostToDevice,
-                               c->copy_stream));
+  // The vanishing argument's random polynomial (vanishing/prover.rs:51-55: n field elements = 8n words, then one
+  // blind) is the bulk of the RNG stream -- 2^21 words at k = 18, 2^25 (268 MB) at k = 22, more host time than the
+  // GPU needs for the advice and round-1 commitments together.  Every draw that precedes it in stream order is made
+  // up front by the main thread; the words themselves are drawn by a helper thread, chunk by chunk, each chunk
+  // uploaded on the side stream as soon as it is drawn, while the main thread runs rounds 0 and 1.  The main thread
+  // does not touch the RNG again before it has joined the helper (just before round 2 commits the polynomial).
+  struct RandomPolyDrawer {
+    std::thread th;
+    bool running = false;
+    std::atomic<bool> done{false};
+    hipError_t err = hipSuccess;
+    void start(cq_ctx* c, Rng* rng, uint64_t* pin, uint64_t* dev, size_t words) {
+      running = true;
+      th = std::thread([=]() {
+        hipError_t e = hipSetDevice(c->device);
+        const size_t chunk = std::max<size_t>(words / 16, (size_t)1 << 16);
+        for (size_t off = 0; off < words && e == hipSuccess; off += chunk) {
+          const size_t cnt = std::min(chunk, words - off);
+          rng->fill(pin + off, cnt);
+          e = hipMemcpyAsync(dev + off, pin + off, cnt * sizeof(uint64_t), hipMemcpyHostToDevice, c->copy_stream);
+        }
+        (void)rng->fr();  // random_blind
+        if (e == hipSuccess) e = hipEventRecord(c->copy_done, c->copy_stream);
+        err = e;
+        done.store(true);
+      });
     }
-    (void)rng.fr();  // random_blind
-    CQ_HIP(c, hipEventRecord(c->copy_done, c->copy_stream));
+    int join() {
+      if (running) {
+        th.join();
+        running = false;
+      }
+      return err == hipSuccess ? 0 : -1;
+    }
+    ~RandomPolyDrawer() {
+      if (running) th.join();
+    }
+  } drawer;
+  // joins the helper, orders the main stream after the uploads, words -> field elements
+  auto finish_random_poly = [&]() -> int {
+    if (drawer.join() != 0) return c->fail(CQ_ERR_HIP, "random polynomial upload failed");
     CQ_HIP(c, hipStreamWaitEvent(s, c->copy_done, 0));
     return poly_from_u512(c, rng_dev, (uint32_t)n, random_poly);
   };
@@ -575,15 +595,9 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, const uint64_
       for (uint32_t r = 0; r < bf; r++) plkz_tails[l * bf + r] = rng.fr();
       (void)rng.fr();
     }
-    // Drawing 8n words on the host (2^21 at k = 18) takes longer than the advice MSMs run, so only the first
-    // half is drawn here; the second half is drawn while the round-1 commitments are computed (no other draw
-    // comes in between).  The uploads ride a side stream so that they overlap the kernels queued on `s`.
+    // the random polynomial's words: drawn and uploaded by the helper thread from here on (see RandomPolyDrawer)
     CQ_TRY(c->ensure_copy_stream());
-    rng_pin = (uint64_t*)pin;
-    rng_first = (L || PL) ? 4 * n : 8 * n;
-    rng.fill(rng_pin, rng_first);
-    CQ_HIP(c, hipMemcpyAsync(rng_dev, rng_pin, rng_first * sizeof(uint64_t), hipMemcpyHostToDevice, c->copy_stream));
-    if (!L && !PL) CQ_TRY(finish_random_poly());
+    drawer.start(c, &rng, (uint64_t*)pin, rng_dev, 8 * n);
     }
     // batch_normalize (:363-366), write (:370-374)
     if (AC) {
@@ -741,7 +755,6 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, const uint64_
       }
       CQ_TRY(fork.end());
     }
-    CQ_TRY(finish_random_poly());  // host draws overlap the MSM kernels just queued
     CQ_TRY(r1.end(cm));
     for (size_t q = 0; q < 2 * PL; q++)
       if (!tr.write_point(cm[q])) return c->fail(CQ_ERR_TRANSCRIPT, "permuted lookup commitment is the identity");
@@ -855,6 +868,11 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, const uint64_
       woff += w;
     }
     if (L) CQ_TRY(domain_lagrange_to_coeff(dom, bpoly, bpoly, (uint32_t)L, n, n));  // f: under round 1's launch
+    // The helper thread has had rounds 0 and 1 and this round's preparation to draw the random polynomial.  From
+    // k = 20 on that is not enough (2^25 words take ~25 ms at k = 22): then the polynomial is committed in a launch
+    // of its own after the round's other MSMs, which start now.
+    const bool random_late = !drawer.done.load();
+    if (!random_late) CQ_TRY(finish_random_poly());
     // commitments, one batch of launches: the permutation products (permutation/prover.rs:177, written first),
     // then a, a0 (dense over the table SRS), q_a (over [qs_0|qs_1|...]), p, b0 (n-1 terms of b[1..]) and the
     // vanishing argument's random polynomial (vanishing/prover.rs:58)
@@ -875,7 +893,7 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, const uint64_
         sc.push_back(bpoly + l * n + 1); bs.push_back(pk->b0_g1_bound); ln.push_back(n - 1);                 // p (:299)
         woff += w;
       }
-      sc.push_back(random_poly); bs.push_back(pk->params->g); ln.push_back(n);
+      if (!random_late) { sc.push_back(random_poly); bs.push_back(pk->params->g); ln.push_back(n); }
       Commit r2cm;
       const uint64_t seq = c->msm_tail_seq;
       CQ_TRY(r2cm.begin(pk, sc, bs, ln));
@@ -890,7 +908,13 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, const uint64_
         if (general && A) CQ_TRY(domain_coeff_to_extended(dom, adv, B.adv_cosets, (uint32_t)A, n, ext));
         CQ_TRY(fork.end());
       }
+      if (random_late) CQ_TRY(finish_random_poly());  // queued behind the launch above
       CQ_TRY(r2cm.end(r2));
+      if (random_late) {
+        std::vector<G1Affine> rc;
+        CQ_TRY(commit_batch(pk, {random_poly}, {pk->params->g}, n, rc));
+        r2.push_back(rc[0]);
+      }
     }
     for (size_t st = 0; st < S; st++)
       if (!tr.write_point(r2[st])) return c->fail(CQ_ERR_TRANSCRIPT, "permutation product commitment is the identity");

@@ -79,3 +79,26 @@ def test_product_and_tools_never_import_the_oracle():
     for m in re.finditer(r"^\s*(from|import)\s+oracle\b", src, re.M):
         head = src[:m.start()]
         assert head.rfind("def cpu_baseline") > max(head.rfind("\ndef " + n) for n in ("main", "plonk_variant", "two_in_flight", "ntt_standalone"))
+
+
+def test_xoshiro_parallel_fill_is_the_same_stream():
+    """cq_xoshiro256ss_fill (jump-ahead, several threads) yields exactly the words and the final state of repeated
+    cq_xoshiro256ss_next_u64 -- for lengths around the per-thread threshold, odd lengths, and one to eight threads."""
+    import numpy as np
+
+    lib = load()
+    for seed, count, threads in [(1, 10, 8), (2, 70000, 1), (3, 131072, 2), (4, 200001, 3), (5, 1 << 20, 8), (6, (1 << 20) + 12345, 7)]:
+        st_a = (C.c_uint64 * 4)()
+        st_b = (C.c_uint64 * 4)()
+        lib.cq_xoshiro256ss_seed(seed, st_a)
+        lib.cq_xoshiro256ss_seed(seed, st_b)
+        got = np.zeros(count, dtype=np.uint64)
+        lib.cq_xoshiro256ss_fill(st_a, got.ctypes.data, count, threads)
+        exp = np.zeros(count, dtype=np.uint64)
+        lib.cq_xoshiro256ss_fill(st_b, exp.ctypes.data, count, 1)  # serial path
+        assert np.array_equal(got, exp) and list(st_a) == list(st_b), (seed, count, threads)
+        # and the serial path is the per-word generator
+        st_c = (C.c_uint64 * 4)()
+        lib.cq_xoshiro256ss_seed(seed, st_c)
+        head = [lib.cq_xoshiro256ss_next_u64(st_c) for _ in range(min(count, 50))]
+        assert head == [int(x) for x in exp[: len(head)]]
