@@ -503,8 +503,7 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, const uint64_
     std::atomic<bool> done{false};
     hipError_t err = hipSuccess;
     void start(cq_ctx* c, Rng* rng, uint64_t* pin, uint64_t* dev, size_t words) {
-      running = true;
-      th = std::thread([=]() {
+      auto work = [=]() {
         hipError_t e = hipSetDevice(c->device);
         const size_t chunk = std::max<size_t>(words / 16, (size_t)1 << 16);
         for (size_t off = 0; off < words && e == hipSuccess; off += chunk) {
@@ -516,7 +515,13 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, const uint64_
         if (e == hipSuccess) e = hipEventRecord(c->copy_done, c->copy_stream);
         err = e;
         done.store(true);
-      });
+      };
+      try {
+        th = std::thread(work);
+        running = true;
+      } catch (...) {  // no thread to be had: draw here (nothing may unwind across the C ABI)
+        work();
+      }
     }
     int join() {
       if (running) {

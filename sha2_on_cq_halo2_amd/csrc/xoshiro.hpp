@@ -111,7 +111,11 @@ static inline void xoshiro_fill(uint64_t* st, uint64_t* dst, size_t count, unsig
   std::vector<std::thread> th;
   for (unsigned t = 0; t < threads; t++) {
     const size_t off = t * per, cnt = (t + 1 == threads) ? count - off : per;
-    th.emplace_back([&start, dst, t, off, cnt]() { xoshiro_fill_serial(start[t].s, dst + off, cnt); });
+    try {
+      th.emplace_back([&start, dst, t, off, cnt]() { xoshiro_fill_serial(start[t].s, dst + off, cnt); });
+    } catch (...) {  // no thread to be had: this part on the calling thread
+      xoshiro_fill_serial(start[t].s, dst + off, cnt);
+    }
   }
   for (auto& x : th) x.join();
   for (int w = 0; w < 4; w++) st[w] = start[threads - 1].s[w];  // the last part ends where the whole run ends
