@@ -131,6 +131,7 @@ def main():
             f"lookups into 2^12-entry (dense, spread) tables, degree 3; full create_proof (GWC, Blake2b), proof {len(proof)} B",
             "k": k,
             "msm_scalars_per_proof": scalars_per_step,
+            "msm_scalars_in_gpu_launches": wl.msm_scalars_in_launches(),
             "ntt_elems_per_proof": wl.ntt_elems_per_proof(),
             "parallelism": (f"one proof, MSM point ranges sharded x{world}, all-gather of partial sums (RCCL)" if shard else
                             f"replicas x{world} (one independent proof per GPU, no collective)"),
@@ -142,7 +143,9 @@ def main():
         # dominant kernel: msm_accumulate_kernel (bucket accumulation).  Algorithmic bytes = 96 B per
         # (scalar, base) pair; the kernel is VALU-bound (256-bit modular arithmetic), so frac is small.
         acc_s = acc_ms / 1e3
-        units = scalars_per_step * args.steps
+        # the accumulate launches take in the scalars of every MSM the backend runs (the f commitments of the proof are
+        # derived from the advice commitments by linearity and are not among them)
+        units = wl.msm_scalars_in_launches() * args.steps
         achieved = MSM_BYTES_PER_SCALAR * units / acc_s / 1e9 if acc_s > 0 else 0.0
         out["roofline"] = {
             "kernel": "msm_accumulate_kernel",

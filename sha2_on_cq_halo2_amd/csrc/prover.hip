@@ -186,6 +186,24 @@ struct Commit {
   }
 };
 
+// k * P on the host (4-bit fixed window over the canonical scalar): used where a commitment is a known linear
+// combination of commitments already computed -- f = sum_j theta^(w-1-j) e_j over plain advice columns gives
+// [f] = sum_j theta^(w-1-j) [e_j], the same group element as the n-term MSM the reference runs.
+G1Jac host_scalar_mul(const G1Jac& p, const Fr& k) {
+  G1Jac table[16];
+  table[0] = G1Jac::identity();
+  table[1] = p;
+  for (int i = 2; i < 16; i++) table[i] = (i & 1) ? jac_add(table[i - 1], p) : jac_dbl(table[i / 2]);
+  const U256 e = k.to_canonical();
+  G1Jac acc = G1Jac::identity();
+  for (int nib = 63; nib >= 0; nib--) {
+    for (int d = 0; d < 4; d++) acc = jac_dbl(acc);
+    const uint32_t v = (e.l[nib >> 3] >> ((nib & 7) * 4)) & 15u;
+    if (v) acc = jac_add(acc, table[v]);
+  }
+  return acc;
+}
+
 // Work for the side stream (ctx.hpp): between begin() and end() every library call that enqueues on `c->stream`
 // lands on the low-priority stream instead, ordered after the accumulate kernel of the MSM launch queued last (all
 // earlier kernels of the main stream are complete by then, and what remains of the MSM only touches its own
@@ -545,6 +563,7 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, const uint64_
   //      challenges ----------------------------------------------------------------------------------------------
   const size_t NC = pk->challenge_phase.size();
   std::vector<Fr> user_challenges(NC, Fr::zero());
+  std::vector<G1Affine> advice_commitments(A, G1Affine::identity());
   auto phase_of = [&](size_t a) -> uint32_t { return pk->advice_phase.empty() ? 0u : pk->advice_phase[a]; };
   for (uint32_t phase = 0; phase < pk->num_phases; phase++) {
     const bool last_phase = phase + 1 == pk->num_phases;
@@ -610,6 +629,7 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, const uint64_
       CQ_TRY(adv_cm.end(pts));
       for (auto& p : pts)
         if (!tr.write_point(p)) return c->fail(CQ_ERR_TRANSCRIPT, "advice commitment is the identity");
+      for (size_t j = 0; j < AC; j++) advice_commitments[cols[j]] = pts[j];
     } else {
       CQ_HIP(c, hipStreamSynchronize(s));
     }
@@ -736,12 +756,44 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, const uint64_
     std::vector<size_t> ln;
     for (size_t l = 0; l < PL; l++)
       for (int which = 2; which <= 3; which++) { sc.push_back(plk_buf(l, which)); bs.push_back(pk->params->g_lagrange); ln.push_back(n); }
-    for (size_t l = 0; l < L; l++) { sc.push_back(f_lag + l * n); bs.push_back(pk->params->g_lagrange); ln.push_back(n); }
+    // f_cm: when every input of a lookup is a plain advice column, f = sum_j theta^(w-1-j) e_j over whole columns
+    // (blinding rows included), so [f] = sum_j theta^(w-1-j) [e_j] -- w - 1 scalar multiplications of commitments
+    // round 0 already produced, done by host threads while the GPU commits m, instead of an n-term MSM.
+    std::vector<int> f_linear(L, 0);
+    std::vector<G1Jac> f_host(L);
+    for (size_t l = 0; l < L; l++) {
+      f_linear[l] = 1;
+      for (int pj : pk->lookups[l].prog) f_linear[l] &= pj < 0;
+    }
+    std::vector<size_t> f_slot(L, 0);
+    for (size_t l = 0; l < L; l++)
+      if (!f_linear[l]) { f_slot[l] = sc.size(); sc.push_back(f_lag + l * n); bs.push_back(pk->params->g_lagrange); ln.push_back(n); }
+    const size_t m_first = sc.size();
     for (size_t l = 0; l < L; l++) { sc.push_back(m_fr + l * N); bs.push_back(pk->table_cfg->g1_lagrange); ln.push_back(N); }
     std::vector<G1Affine> cm;
     Commit r1;
     const uint64_t seq = c->msm_tail_seq;
     CQ_TRY(r1.begin(pk, sc, bs, ln));
+    struct Joiner {
+      std::vector<std::thread> th;
+      ~Joiner() {
+        for (auto& t : th) t.join();
+      }
+    } f_threads;
+    for (size_t l = 0; l < L; l++) {
+      if (!f_linear[l]) continue;
+      auto work = [&, l]() {
+        const auto& lcols = pk->lookups[l].cols;
+        G1Jac acc = jac_from_affine(advice_commitments[lcols[0]]);
+        for (size_t j = 1; j < lcols.size(); j++) acc = jac_add(host_scalar_mul(acc, theta), jac_from_affine(advice_commitments[lcols[j]]));
+        f_host[l] = acc;
+      };
+      try {
+        f_threads.th.emplace_back(work);
+      } catch (...) {
+        work();
+      }
+    }
     {
       // under the launch's tail: f -> coefficients (:326-334) and onto the extended coset (evaluation.rs:533-548 reads
       // it), the instance cosets -- none of them depends on beta / gamma
@@ -761,11 +813,14 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, const uint64_
       CQ_TRY(fork.end());
     }
     CQ_TRY(r1.end(cm));
+    for (auto& t : f_threads.th) t.join();
+    f_threads.th.clear();
     for (size_t q = 0; q < 2 * PL; q++)
       if (!tr.write_point(cm[q])) return c->fail(CQ_ERR_TRANSCRIPT, "permuted lookup commitment is the identity");
     for (size_t l = 0; l < L; l++) {
-      if (!tr.write_point(cm[2 * PL + l])) return c->fail(CQ_ERR_TRANSCRIPT, "f commitment is the identity");
-      if (!tr.write_point(cm[2 * PL + L + l])) return c->fail(CQ_ERR_TRANSCRIPT, "m commitment is the identity");
+      const G1Affine f_cm = f_linear[l] ? jac_to_affine(f_host[l]) : cm[f_slot[l]];
+      if (!tr.write_point(f_cm)) return c->fail(CQ_ERR_TRANSCRIPT, "f commitment is the identity");
+      if (!tr.write_point(cm[m_first + l])) return c->fail(CQ_ERR_TRANSCRIPT, "m commitment is the identity");
     }
   }
   const Fr beta = tr.squeeze();   // prover.rs:529

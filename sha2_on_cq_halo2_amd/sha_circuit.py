@@ -149,6 +149,11 @@ class ShaCqWorkload:
         table = L * N + 2 * L * N + L * 2 * N                          # m, (a, a0), q_a
         return dense + table
 
+    def msm_scalars_in_launches(self) -> int:
+        """What the MSM kernels of this backend actually take in: the L commitments to f are obtained as
+        theta * [a_2p] + [a_2p+1] from the advice commitments (plain advice columns as lookup inputs), not by an MSM."""
+        return self.msm_scalars_per_proof() - self.pairs * self.n
+
     def ntt_elems_per_proof(self) -> int:
         L, A, n = self.pairs, 2 * self.pairs, self.n
         return (2 * L + A) * n + 2 * L * 2 * n + 2 * n  # iNTT(b,f), iNTT(advice), coset NTTs, iNTT(ext)
