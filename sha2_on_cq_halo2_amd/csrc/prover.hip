@@ -16,6 +16,7 @@
 #include <algorithm>
 #include <array>
 #include <atomic>
+#include <chrono>
 #include <cstring>
 #include <thread>
 #include <vector>
@@ -519,15 +520,28 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, const uint64_
     std::thread th;
     bool running = false;
     std::atomic<bool> done{false};
+    std::atomic<uint32_t> chunks_done{0};
+    uint32_t chunks_total = 1;
+    std::chrono::steady_clock::time_point t_start;
     hipError_t err = hipSuccess;
+    // estimated time to completion in microseconds (from the progress so far); 0 when done
+    double remaining_us() const {
+      if (done.load()) return 0.0;
+      const double el = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_start).count();
+      const uint32_t d = chunks_done.load();
+      return d ? el * (double)(chunks_total - d + 1) / d : 1e9;  // +1: the last upload's event
+    }
     void start(cq_ctx* c, Rng* rng, uint64_t* pin, uint64_t* dev, size_t words) {
+      const size_t chunk = std::max<size_t>(words / 16, (size_t)1 << 16);
+      chunks_total = (uint32_t)((words + chunk - 1) / chunk);
+      t_start = std::chrono::steady_clock::now();
       auto work = [=]() {
         hipError_t e = hipSetDevice(c->device);
-        const size_t chunk = std::max<size_t>(words / 16, (size_t)1 << 16);
         for (size_t off = 0; off < words && e == hipSuccess; off += chunk) {
           const size_t cnt = std::min(chunk, words - off);
           rng->fill(pin + off, cnt);
           e = hipMemcpyAsync(dev + off, pin + off, cnt * sizeof(uint64_t), hipMemcpyHostToDevice, c->copy_stream);
+          chunks_done.fetch_add(1);
         }
         (void)rng->fr();  // random_blind
         if (e == hipSuccess) e = hipEventRecord(c->copy_done, c->copy_stream);
@@ -931,6 +945,16 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, const uint64_
     // The helper thread has had rounds 0 and 1 and this round's preparation to draw the random polynomial.  From
     // k = 20 on that is not enough (2^25 words take ~25 ms at k = 22): then the polynomial is committed in a launch
     // of its own after the round's other MSMs, which start now.
+    // Not done yet?  A launch of its own for the polynomial costs ~0.7 ms of GPU time; waiting costs what is left of
+    // the draws.  Wait while the estimate (from the chunks done so far) stays below that, give up otherwise.
+    {
+      const auto t0 = std::chrono::steady_clock::now();
+      while (!drawer.done.load()) {
+        const double waited = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+        if (waited > 100.0 && drawer.remaining_us() > 700.0) break;
+        std::this_thread::yield();
+      }
+    }
     const bool random_late = !drawer.done.load();
     if (!random_late) CQ_TRY(finish_random_poly());
     // commitments, one batch of launches: the permutation products (permutation/prover.rs:177, written first),
