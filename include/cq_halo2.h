@@ -48,6 +48,9 @@ typedef struct cq_pk cq_pk;           /* ProvingKey slice read by the CQ-only pr
 /* `R: RngCore` of create_proof (plonk/prover.rs:65): the library calls next_u64 exactly as
  * `Fr::random` does (8 calls per scalar, low limb first, bn256/fr.rs:159-170). */
 typedef uint64_t (*cq_rng_next_u64)(void* state);
+/* Optional bulk form of the same generator (`RngCore::fill_bytes`): writes the next `count` outputs of next_u64 to
+ * dst and advances the state.  See cq_pk_set_rng_fill. */
+typedef void (*cq_rng_fill_fn)(void* state, uint64_t* dst, size_t count);
 /* Collective hook for MSM sharding (one process per GPU): gathers `bytes_per_rank` bytes from every rank
  * into `recv` (world x bytes_per_rank, rank order).  The host application implements it with RCCL /
  * torch.distributed; returns 0 on success. */
@@ -331,6 +334,12 @@ int cq_pk_set_sharding(cq_pk* pk, uint32_t rank, uint32_t world, cq_allgather_fn
 #define CQ_OPENER_GWC 0
 #define CQ_OPENER_SHPLONK 1
 int cq_pk_set_opener(cq_pk* pk, int opener);
+/* The vanishing argument's random polynomial takes 8 * 2^k words of the caller's RNG (vanishing/prover.rs:51-55): one
+ * indirect next_u64 call per word, made on a helper thread of the library while the GPU runs the first rounds.  A
+ * caller whose generator can produce words in bulk registers `fill` here (NULL = back to per-word calls); the
+ * `rng_state` given to cq_create_proof* is handed to it, and it must yield exactly the words `count` next_u64 calls
+ * would.  Either way the callbacks may run on a thread other than the caller's, never concurrently. */
+int cq_pk_set_rng_fill(cq_pk* pk, cq_rng_fill_fn fill);
 void cq_pk_destroy(cq_pk* pk);
 uint32_t cq_pk_usable_rows(const cq_pk* pk);
 size_t cq_pk_proof_size(const cq_pk* pk);
@@ -389,9 +398,16 @@ uint64_t cq_xoshiro256ss_next_u64(void* state /* uint64_t[4] */);
  * GF(2)-linear state transition).  cq_create_proof* draws the vanishing argument's random polynomial this way
  * (8 * 2^k words: the RNG, not the GPU, bounds the first rounds of a large proof otherwise). */
 void cq_xoshiro256ss_fill(uint64_t state[4], uint64_t* dst, size_t count, uint32_t threads);
-/* replays a pre-drawn stream: state = {const uint64_t* words; size_t pos; size_t len} */
-typedef struct { const uint64_t* words; size_t pos; size_t len; } cq_buffer_rng;
+/* replays a pre-drawn stream: state = {const uint64_t* words; size_t pos; size_t len; size_t overrun}.  Words asked
+ * for beyond `len` read as zero and are counted in `overrun`; cq_create_proof* fails with CQ_ERR_ARG when the stream
+ * it was given ran out (a proof blinded with zeros is not zero-knowledge).  Like the xoshiro generator below this is
+ * for tests and benches; production blinding comes from the caller's CSPRNG through cq_rng_next_u64. */
+typedef struct { const uint64_t* words; size_t pos; size_t len; size_t overrun; } cq_buffer_rng;
 uint64_t cq_buffer_rng_next_u64(void* state /* cq_buffer_rng* */);
+/* The xoshiro generator behind a function the library does NOT recognise (state: uint64_t[4]): stands in for a
+ * caller's opaque `RngCore` in tests and in bench.py's `generic_rng` leg (same words as cq_xoshiro256ss_next_u64). */
+uint64_t cq_opaque_rng_next_u64(void* state);
+void cq_opaque_rng_fill(void* state, uint64_t* dst, size_t count);
 
 /* ---- measurement support ---------------------------------------------------------------------- */
 /* When enabled, the library brackets its dominant kernels with HIP events on the context's stream.

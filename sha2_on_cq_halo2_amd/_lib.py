@@ -153,6 +153,11 @@ def _declare(lib):  # noqa: F811
     lib.cq_xoshiro256ss_fill.argtypes = [vp, vp, C.c_size_t, C.c_uint32]
     lib.cq_buffer_rng_next_u64.restype = C.c_uint64
     lib.cq_buffer_rng_next_u64.argtypes = [vp]
+    lib.cq_opaque_rng_next_u64.restype = C.c_uint64
+    lib.cq_opaque_rng_next_u64.argtypes = [vp]
+    lib.cq_opaque_rng_fill.restype = None
+    lib.cq_opaque_rng_fill.argtypes = [vp, vp, C.c_size_t]
+    lib.cq_pk_set_rng_fill.argtypes = [vp, vp]
     lib.cq_msm_precompute_dev.argtypes = [vp, vp, C.c_size_t]
     lib.cq_msm_set_precompute.argtypes = [vp, C.c_int]
     lib.cq_msm_forget_dev.argtypes = [vp, vp]

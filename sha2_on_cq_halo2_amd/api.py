@@ -562,7 +562,7 @@ def _lower_plonk(cs, fixed, mapping, keep: list, from_raw: bool = False) -> _CqP
 
 
 class _BufferRng(C.Structure):
-    _fields_ = [("words", C.POINTER(C.c_uint64)), ("pos", C.c_size_t), ("len", C.c_size_t)]
+    _fields_ = [("words", C.POINTER(C.c_uint64)), ("pos", C.c_size_t), ("len", C.c_size_t), ("overrun", C.c_size_t)]
 
 
 class ProvingKey(_Handle):
@@ -662,17 +662,23 @@ class ProvingKey(_Handle):
         self.ctx._chk(self.ctx.lib.cq_pk_vk_commitments(self.h, f.ctypes.data, p.ctypes.data))
         return f[:nf], p[:npc]
 
-    def _rng(self, rng_words=None, seed=None):
+    def set_rng_fill(self, name):
+        """cq_pk_set_rng_fill: None (per-word callbacks) or "opaque" (the harness generator's bulk form)."""
+        fn = C.cast(self.ctx.lib.cq_opaque_rng_fill, C.c_void_p) if name == "opaque" else None
+        self.ctx._chk(self.ctx.lib.cq_pk_set_rng_fill(self.h, fn))
+
+    def _rng(self, rng_words=None, seed=None, opaque=False):
         lib = self.ctx.lib
         if rng_words is not None:
             w = np.ascontiguousarray(rng_words, dtype=np.uint64)
-            st = _BufferRng(w.ctypes.data_as(C.POINTER(C.c_uint64)), 0, w.shape[0])
+            st = _BufferRng(w.ctypes.data_as(C.POINTER(C.c_uint64)), 0, w.shape[0], 0)
             self._rng_keep = (w, st)
             return C.cast(lib.cq_buffer_rng_next_u64, C.c_void_p), C.cast(C.byref(st), C.c_void_p)
         st = (C.c_uint64 * 4)()
         lib.cq_xoshiro256ss_seed(seed, st)
         self._rng_keep = st
-        return C.cast(lib.cq_xoshiro256ss_next_u64, C.c_void_p), C.cast(st, C.c_void_p)
+        # opaque: the same generator behind a function pointer the library does not recognise (a caller's RngCore)
+        return C.cast(lib.cq_opaque_rng_next_u64 if opaque else lib.cq_xoshiro256ss_next_u64, C.c_void_p), C.cast(st, C.c_void_p)
 
     def create_proof(self, advice, rng_words=None, seed=None, instances=None) -> bytes:
         """`create_proof` (plonk/prover.rs:51) with host advice columns (uint64[n,4] each; rows
@@ -714,8 +720,8 @@ class ProvingKey(_Handle):
         self.ctx._chk(self.ctx.lib.cq_create_proof_phases(self.h, arr, iptr, ilen, cb, None, fn, st, proof, self.proof_size, C.byref(plen)))
         return bytes(proof[: plen.value])
 
-    def create_proof_dev(self, advice_ptrs, rng_words=None, seed=None, instances=None) -> bytes:
-        fn, st = self._rng(rng_words, seed)
+    def create_proof_dev(self, advice_ptrs, rng_words=None, seed=None, instances=None, opaque_rng=False) -> bytes:
+        fn, st = self._rng(rng_words, seed, opaque_rng)
         return self._run(self.ctx.lib.cq_create_proof, list(advice_ptrs), fn, st, instances, on_device=True)
 
 

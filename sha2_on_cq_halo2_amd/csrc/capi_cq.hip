@@ -20,6 +20,33 @@ static uint32_t log2u(size_t x) {
   return l;
 }
 
+// Owns a half-built object (and plain device allocations) until release(): every early return -- CQ_HIP included --
+// destroys it, so a failing constructor leaks nothing and never hands back a live handle next to an error code.
+namespace {
+template <class T>
+struct Building {
+  T* p;
+  void (*destroy)(T*);
+  std::vector<void*> dev;       // temporaries, hipFree'd on every path
+  std::vector<const void*> reg; // temporary MSM window tables, unregistered on every path
+  cq_ctx* c = nullptr;
+  cq_domain* dom = nullptr;
+  Building(T* p_, void (*d)(T*), cq_ctx* c_) : p(p_), destroy(d), c(c_) {}
+  ~Building() {
+    if (c) hipStreamSynchronize(c->stream);
+    for (const void* r : reg) msm_unregister_tables(c, r);
+    for (void* d : dev) hipFree(d);
+    if (dom) domain_destroy(dom);
+    if (p) destroy(p);
+  }
+  T* release() {
+    T* q = p;
+    p = nullptr;
+    return q;
+  }
+};
+}  // namespace
+
 extern "C" {
 
 // ---- StaticTableConfig ---------------------------------------------------------------------------
@@ -27,15 +54,15 @@ int cq_table_config_create(cq_ctx* c, size_t size, const uint64_t* g1_lagrange, 
                            cq_table_config** out) {
   if (!c || !g1_lagrange || !opening_at_0 || !out || !is_pow2(size) || size > (1u << 28)) return CQ_ERR_ARG;
   CQ_HIP(c, hipSetDevice(c->device));
+  *out = nullptr;
   cq_table_config* t = new cq_table_config();
+  Building<cq_table_config> guard(t, cq_table_config_destroy, c);
   t->ctx = c;
   t->N = size;
   t->log_n = log2u(size);
   const size_t bytes = size * sizeof(G1Affine);
-  if (hipMalloc(&t->g1_lagrange, bytes) != hipSuccess || hipMalloc(&t->g_lagrange_opening_at_0, bytes) != hipSuccess) {
-    delete t;
+  if (hipMalloc(&t->g1_lagrange, bytes) != hipSuccess || hipMalloc(&t->g_lagrange_opening_at_0, bytes) != hipSuccess)
     return c->fail(CQ_ERR_HIP, "hipMalloc(table config)");
-  }
   CQ_HIP(c, hipMemcpyAsync(t->g1_lagrange, g1_lagrange, bytes, hipMemcpyHostToDevice, c->stream));
   CQ_HIP(c, hipMemcpyAsync(t->g_lagrange_opening_at_0, opening_at_0, bytes, hipMemcpyHostToDevice, c->stream));
   CQ_HIP(c, hipStreamSynchronize(c->stream));
@@ -44,22 +71,22 @@ int cq_table_config_create(cq_ctx* c, size_t size, const uint64_t* g1_lagrange, 
     if ((rc2 = msm_register_tables(c, t->g1_lagrange, size)) != CQ_OK) return rc2;
     if ((rc2 = msm_register_tables(c, t->g_lagrange_opening_at_0, size)) != CQ_OK) return rc2;
   }
-  *out = t;
+  *out = guard.release();
   return CQ_OK;
 }
 
 int cq_table_config_setup_from_toxic_waste(cq_ctx* c, size_t size, const uint64_t s[4], cq_table_config** out) {
   if (!c || !s || !out || !is_pow2(size) || size > (1u << 28)) return CQ_ERR_ARG;
   CQ_HIP(c, hipSetDevice(c->device));
+  *out = nullptr;
   cq_table_config* t = new cq_table_config();
+  Building<cq_table_config> guard(t, cq_table_config_destroy, c);
   t->ctx = c;
   t->N = size;
   t->log_n = log2u(size);
   const size_t bytes = size * sizeof(G1Affine);
-  if (hipMalloc(&t->g1_lagrange, bytes) != hipSuccess || hipMalloc(&t->g_lagrange_opening_at_0, bytes) != hipSuccess) {
-    delete t;
+  if (hipMalloc(&t->g1_lagrange, bytes) != hipSuccess || hipMalloc(&t->g_lagrange_opening_at_0, bytes) != hipSuccess)
     return c->fail(CQ_ERR_HIP, "hipMalloc(table config)");
-  }
   void* tmp;
   int rc;
   if ((rc = c->ensure_scratch(1, 2 * size * sizeof(Fr), &tmp)) != CQ_OK) return rc;
@@ -73,7 +100,7 @@ int cq_table_config_setup_from_toxic_waste(cq_ctx* c, size_t size, const uint64_
     if ((rc = msm_register_tables(c, t->g_lagrange_opening_at_0, size)) != CQ_OK) return rc;
   }
   CQ_HIP(c, hipStreamSynchronize(c->stream));
-  *out = t;
+  *out = guard.release();
   return CQ_OK;
 }
 
@@ -98,36 +125,27 @@ int cq_table_config_download(cq_table_config* t, uint64_t* g1_lagrange, uint64_t
 }
 
 // ---- StaticTableValues -----------------------------------------------------------------------------
-static int table_alloc(cq_ctx* c, size_t size, const uint64_t* values, cq_static_table** out) {
-  cq_static_table* t = new cq_static_table();
+// fills a fresh object the caller already guards (Building): nothing to undo here on failure
+static int table_alloc(cq_ctx* c, size_t size, const uint64_t* values, cq_static_table* t) {
   t->ctx = c;
   t->N = size;
-  if (hipMalloc(&t->values, size * sizeof(Fr)) != hipSuccess || hipMalloc(&t->qs, size * sizeof(G1Affine)) != hipSuccess) {
-    delete t;
+  if (hipMalloc(&t->values, size * sizeof(Fr)) != hipSuccess || hipMalloc(&t->qs, size * sizeof(G1Affine)) != hipSuccess)
     return c->fail(CQ_ERR_HIP, "hipMalloc(static table)");
-  }
-  if (hipMemcpyAsync(t->values, values, size * sizeof(Fr), hipMemcpyHostToDevice, c->stream) != hipSuccess) {
-    delete t;
-    return c->fail(CQ_ERR_HIP, "upload(table values)");
-  }
-  int rc = cq_table_build_index(c, t->values, (uint32_t)size, &t->slots, &t->nslots);
-  if (rc != CQ_OK) {
-    hipFree(t->values);
-    hipFree(t->qs);
-    delete t;
-    return rc;
-  }
-  *out = t;
-  return CQ_OK;
+  CQ_HIP(c, hipMemcpyAsync(t->values, values, size * sizeof(Fr), hipMemcpyHostToDevice, c->stream));
+  return cq_table_build_index(c, t->values, (uint32_t)size, &t->slots, &t->nslots);
 }
 
 int cq_static_table_create(cq_ctx* c, size_t size, const uint64_t* values, const uint64_t* qs_affine, cq_static_table** out) {
   if (!c || !values || !qs_affine || !out || !is_pow2(size) || size > (1u << 28)) return CQ_ERR_ARG;  // static_lookup.rs:80
   CQ_HIP(c, hipSetDevice(c->device));
-  int rc = table_alloc(c, size, values, out);
+  *out = nullptr;
+  cq_static_table* t = new cq_static_table();
+  Building<cq_static_table> guard(t, cq_static_table_destroy, c);
+  int rc = table_alloc(c, size, values, t);
   if (rc != CQ_OK) return rc;
-  CQ_HIP(c, hipMemcpyAsync((*out)->qs, qs_affine, size * sizeof(G1Affine), hipMemcpyHostToDevice, c->stream));
+  CQ_HIP(c, hipMemcpyAsync(t->qs, qs_affine, size * sizeof(G1Affine), hipMemcpyHostToDevice, c->stream));
   CQ_HIP(c, hipStreamSynchronize(c->stream));
+  *out = guard.release();
   return CQ_OK;
 }
 
@@ -135,12 +153,14 @@ int cq_static_table_setup_from_toxic_waste(cq_ctx* c, size_t size, const uint64_
                                            cq_static_table** out) {
   if (!c || !values || !s || !out || !is_pow2(size) || size > (1u << 28)) return CQ_ERR_ARG;
   CQ_HIP(c, hipSetDevice(c->device));
-  int rc = table_alloc(c, size, values, out);
+  *out = nullptr;
+  cq_static_table* t = new cq_static_table();
+  Building<cq_static_table> guard(t, cq_static_table_destroy, c);
+  int rc = table_alloc(c, size, values, t);
   if (rc != CQ_OK) return rc;
-  cq_static_table* t = *out;
   // T(s): interpolate the values over the size-N domain, evaluate at s
-  cq_domain* dom = nullptr;
-  if ((rc = domain_create(c, 2, log2u(size), &dom)) != CQ_OK) return rc;
+  if ((rc = domain_create(c, 2, log2u(size), &guard.dom)) != CQ_OK) return rc;
+  cq_domain* dom = guard.dom;
   void* tmp;
   if ((rc = c->ensure_scratch(1, 2 * size * sizeof(Fr), &tmp)) != CQ_OK) return rc;
   Fr* coeffs = (Fr*)tmp;
@@ -152,7 +172,7 @@ int cq_static_table_setup_from_toxic_waste(cq_ctx* c, size_t size, const uint64_
   if ((rc = cq_qs_scalars(c, t->values, (uint32_t)size, ts, sf, dom->omega, dom->ifft_divisor, sc)) != CQ_OK) return rc;
   if ((rc = fixed_base_mul(c, sc, (uint32_t)size, t->qs)) != CQ_OK) return rc;
   CQ_HIP(c, hipStreamSynchronize(c->stream));
-  domain_destroy(dom);
+  *out = guard.release();
   return CQ_OK;
 }
 
@@ -174,11 +194,8 @@ int cq_static_table_download_qs(cq_static_table* t, uint64_t* qs_affine) {
 }
 
 // ---- proving key -------------------------------------------------------------------------------------
-// frees whatever a partially built key owns; `rc` is passed through
-static int pk_abort(cq_pk* pk, int rc) {
-  cq_pk_destroy(pk);
-  return rc;
-}
+// `rc` is passed through
+static int pk_abort(cq_pk*, int rc) { return rc; }  // the Building guard of pk_create_impl destroys the key
 
 // Cursor over a ProvingKey::write byte stream (plonk.rs:349-362): big-endian u32 counts, raw 32-byte elements
 namespace {
@@ -227,7 +244,9 @@ static int pk_create_impl(cq_ctx* c, cq_params* params, const cq_circuit* cs, cq
   if (cs->num_lookups > CQ_MAX_LOOKUPS) return c->fail(CQ_ERR_ARG, "pk: too many lookups");
   CQ_HIP(c, hipSetDevice(c->device));
   const cq_plonk* pl = cs->plonk;
+  *out = nullptr;
   cq_pk* pk = new cq_pk();
+  Building<cq_pk> guard(pk, cq_pk_destroy, c);  // every failing return below (CQ_HIP included) destroys the key
   pk->ctx = c;
   pk->params = params;
   pk->k = cs->k;
@@ -545,7 +564,7 @@ static int pk_create_impl(cq_ctx* c, cq_params* params, const cq_circuit* cs, cq
   }
   if (pk->b0_g1_bound && c->msm_precompute && (rc = msm_register_tables(c, pk->b0_g1_bound, n - 1)) != CQ_OK) return pk_abort(pk, rc);
   CQ_HIP(c, hipStreamSynchronize(c->stream));
-  *out = pk;
+  *out = guard.release();
   return CQ_OK;
 }
 
@@ -630,6 +649,12 @@ int cq_pk_set_opener(cq_pk* pk, int opener) {
   return CQ_OK;
 }
 
+int cq_pk_set_rng_fill(cq_pk* pk, cq_rng_fill_fn fill) {
+  if (!pk) return CQ_ERR_ARG;
+  pk->rng_fill = fill;
+  return CQ_OK;
+}
+
 int cq_pk_set_sharding(cq_pk* pk, uint32_t rank, uint32_t world, cq_allgather_fn fn, void* user) {
   if (!pk || world == 0 || rank >= world || (world > 1 && !fn)) return CQ_ERR_ARG;
   pk->shard_rank = rank;
@@ -690,6 +715,9 @@ static int create_proof_any(cq_pk* pk, const uint64_t* const* advice_dev, const 
   std::vector<uint8_t> out;
   if (pk->num_phases > 1 && !phase_fn) return c->fail(CQ_ERR_ARG, "create_proof: a multi-phase circuit needs cq_create_proof_phases");
   int rc = create_proof_dev(pk, advice_dev, instances, instance_lens, phase_fn, phase_user, rng, rng_state, out);
+  // checked before rc: an all-zero random polynomial also trips the identity-commitment check of the transcript
+  if (rng == cq_buffer_rng_next_u64 && ((cq_buffer_rng*)rng_state)->overrun)
+    return c->fail(CQ_ERR_ARG, "create_proof: the pre-drawn RNG stream ran out (blinding would be zero)");
   if (rc != CQ_OK) return rc;
   if (out.size() > proof_cap) return c->fail(CQ_ERR_ARG, "proof buffer too small");
   memcpy(proof, out.data(), out.size());
@@ -796,19 +824,24 @@ int cq_sha_decomposition_table_dev(cq_ctx* c, uint32_t first_limb_len, uint32_t 
 int cq_static_table_new(cq_ctx* c, size_t size, const uint64_t* values, const uint64_t* srs_g1, cq_static_table** out) {
   if (!c || !values || !srs_g1 || !out || !is_pow2(size) || size > (1u << 20)) return CQ_ERR_ARG;
   CQ_HIP(c, hipSetDevice(c->device));
-  int rc = table_alloc(c, size, values, out);
+  *out = nullptr;
+  cq_static_table* t = new cq_static_table();
+  Building<cq_static_table> guard(t, cq_static_table_destroy, c);
+  int rc = table_alloc(c, size, values, t);
   if (rc != CQ_OK) return rc;
-  cq_static_table* t = *out;
   const uint32_t N = (uint32_t)size;
-  cq_domain* dom = nullptr;
-  if ((rc = domain_create(c, 2, log2u(size), &dom)) != CQ_OK) return rc;
+  if ((rc = domain_create(c, 2, log2u(size), &guard.dom)) != CQ_OK) return rc;
+  cq_domain* dom = guard.dom;
   const uint32_t group = 16;  // roots per MSM launch
   G1Affine* srs = nullptr;
   Fr *coeffs = nullptr, *quot = nullptr;
-  if (hipMalloc(&srs, size * sizeof(G1Affine)) != hipSuccess || hipMalloc(&coeffs, size * sizeof(Fr)) != hipSuccess ||
-      hipMalloc(&quot, (size_t)group * size * sizeof(Fr)) != hipSuccess)
-    return c->fail(CQ_ERR_HIP, "hipMalloc(static_table_new)");
+  const bool alloc_ok = hipMalloc(&srs, size * sizeof(G1Affine)) == hipSuccess && hipMalloc(&coeffs, size * sizeof(Fr)) == hipSuccess &&
+                        hipMalloc(&quot, (size_t)group * size * sizeof(Fr)) == hipSuccess;
+  for (void* d : {(void*)srs, (void*)coeffs, (void*)quot})
+    if (d) guard.dev.push_back(d);
+  if (!alloc_ok) return c->fail(CQ_ERR_HIP, "hipMalloc(static_table_new)");
   CQ_HIP(c, hipMemcpyAsync(srs, srs_g1, size * sizeof(G1Affine), hipMemcpyHostToDevice, c->stream));
+  guard.reg.push_back(srs);  // unregistering an array that never got tables is a no-op
   if (c->msm_precompute && (rc = msm_register_tables(c, srs, size)) != CQ_OK) return rc;
   if ((rc = domain_lagrange_to_coeff(dom, t->values, coeffs, 1, size, size)) != CQ_OK) return rc;  // :99-105
   std::vector<uint64_t> jac(group * 12);
@@ -828,34 +861,31 @@ int cq_static_table_new(cq_ctx* c, size_t size, const uint64_t* values, const ui
   }
   CQ_HIP(c, hipMemcpyAsync(t->qs, host_qs.data(), size * sizeof(G1Affine), hipMemcpyHostToDevice, c->stream));
   CQ_HIP(c, hipStreamSynchronize(c->stream));
-  msm_unregister_tables(c, srs);
-  hipFree(srs);
-  hipFree(coeffs);
-  hipFree(quot);
-  domain_destroy(dom);
+  *out = guard.release();
   return CQ_OK;
 }
 
 int cq_static_table_new_fk(cq_ctx* c, size_t size, const uint64_t* values, const uint64_t* srs_g1, cq_static_table** out) {
   if (!c || !values || !srs_g1 || !out || !is_pow2(size) || size < 2 || size > (1u << 22)) return CQ_ERR_ARG;
   CQ_HIP(c, hipSetDevice(c->device));
-  int rc = table_alloc(c, size, values, out);
+  *out = nullptr;
+  cq_static_table* t = new cq_static_table();
+  Building<cq_static_table> guard(t, cq_static_table_destroy, c);
+  int rc = table_alloc(c, size, values, t);
   if (rc != CQ_OK) return rc;
-  cq_static_table* t = *out;
-  cq_domain* dom = nullptr;
-  if ((rc = domain_create(c, 2, log2u(size), &dom)) != CQ_OK) return rc;
+  if ((rc = domain_create(c, 2, log2u(size), &guard.dom)) != CQ_OK) return rc;
   G1Affine* srs = nullptr;
   Fr* coeffs = nullptr;
-  if (hipMalloc(&srs, size * sizeof(G1Affine)) != hipSuccess || hipMalloc(&coeffs, size * sizeof(Fr)) != hipSuccess)
-    return c->fail(CQ_ERR_HIP, "hipMalloc(static_table_new_fk)");
+  const bool alloc_ok = hipMalloc(&srs, size * sizeof(G1Affine)) == hipSuccess && hipMalloc(&coeffs, size * sizeof(Fr)) == hipSuccess;
+  for (void* d : {(void*)srs, (void*)coeffs})
+    if (d) guard.dev.push_back(d);
+  if (!alloc_ok) return c->fail(CQ_ERR_HIP, "hipMalloc(static_table_new_fk)");
   CQ_HIP(c, hipMemcpyAsync(srs, srs_g1, size * sizeof(G1Affine), hipMemcpyHostToDevice, c->stream));
-  rc = domain_lagrange_to_coeff(dom, t->values, coeffs, 1, size, size);  // :99-105
-  if (rc == CQ_OK) rc = fk_table_quotients(c, coeffs, srs, log2u(size), t->qs);
-  hipStreamSynchronize(c->stream);
-  hipFree(srs);
-  hipFree(coeffs);
-  domain_destroy(dom);
-  return rc;
+  if ((rc = domain_lagrange_to_coeff(guard.dom, t->values, coeffs, 1, size, size)) != CQ_OK) return rc;  // :99-105
+  if ((rc = fk_table_quotients(c, coeffs, srs, log2u(size), t->qs)) != CQ_OK) return rc;
+  CQ_HIP(c, hipStreamSynchronize(c->stream));
+  *out = guard.release();
+  return CQ_OK;
 }
 
 // ---- harness RNGs ----------------------------------------------------------------------------------------
@@ -887,9 +917,15 @@ void cq_xoshiro256ss_fill(uint64_t state[4], uint64_t* dst, size_t count, uint32
 }
 uint64_t cq_buffer_rng_next_u64(void* st) {
   cq_buffer_rng* b = (cq_buffer_rng*)st;
-  if (b->pos >= b->len) return 0;
+  if (b->pos >= b->len) {
+    b->overrun++;
+    return 0;
+  }
   return b->words[b->pos++];
 }
+// not compared against by the prover: an "unknown" generator as a caller's RngCore is
+uint64_t cq_opaque_rng_next_u64(void* st) { return cq_xoshiro256ss_next_u64(st); }
+void cq_opaque_rng_fill(void* st, uint64_t* dst, size_t count) { cq::xoshiro_fill((uint64_t*)st, dst, count, 8); }
 
 }  // extern "C"
 

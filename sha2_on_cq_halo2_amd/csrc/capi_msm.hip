@@ -171,6 +171,31 @@ static int msm_batch(cq_ctx* c, const Fr* const* scalars, const G1Affine* bases,
   return cq_msm_multi(c, scalars, bp.data(), len, count, out_jac);
 }
 
+namespace {
+// destroys a half-built cq_params on every failing return (CQ_HIP included); release() on success
+struct ParamsGuard {
+  cq_params* p;
+  explicit ParamsGuard(cq_params* p_) : p(p_) {}
+  ~ParamsGuard() {
+    if (p) cq_params_destroy(p);
+  }
+  cq_params* release() {
+    cq_params* q = p;
+    p = nullptr;
+    return q;
+  }
+};
+cq_params* params_new(cq_ctx* c, uint32_t k) {
+  cq_params* p = new cq_params();
+  p->ctx = c;
+  p->k = k;
+  p->n = (size_t)1 << k;
+  p->g = nullptr;
+  p->g_lagrange = nullptr;
+  return p;
+}
+}  // namespace
+
 extern "C" {
 
 int cq_msm_precompute_dev(cq_ctx* c, const uint64_t* bases_dev, size_t n) {
@@ -234,17 +259,13 @@ int cq_best_multiexp(cq_ctx* c, const uint64_t* coeffs, const uint64_t* bases, s
 int cq_params_create(cq_ctx* c, uint32_t k, const uint64_t* g, const uint64_t* g_lagrange, cq_params** out) {
   if (!c || !g || !g_lagrange || !out || k > FR_S) return CQ_ERR_ARG;
   CQ_HIP(c, hipSetDevice(c->device));
-  cq_params* p = new cq_params();
-  p->ctx = c;
-  p->k = k;
-  p->n = (size_t)1 << k;
+  *out = nullptr;
+  cq_params* p = params_new(c, k);
+  ParamsGuard guard(p);
   const size_t bytes = p->n * sizeof(G1Affine);
   hipError_t e;
-  if ((e = hipMalloc(&p->g, bytes)) != hipSuccess || (e = hipMalloc(&p->g_lagrange, bytes)) != hipSuccess) {
-    if (p->g) hipFree(p->g);
-    delete p;
+  if ((e = hipMalloc(&p->g, bytes)) != hipSuccess || (e = hipMalloc(&p->g_lagrange, bytes)) != hipSuccess)
     return c->hip_fail(e, "hipMalloc(params)");
-  }
   CQ_HIP(c, hipMemcpyAsync(p->g, g, bytes, hipMemcpyHostToDevice, c->stream));
   CQ_HIP(c, hipMemcpyAsync(p->g_lagrange, g_lagrange, bytes, hipMemcpyHostToDevice, c->stream));
   CQ_HIP(c, hipStreamSynchronize(c->stream));
@@ -253,7 +274,7 @@ int cq_params_create(cq_ctx* c, uint32_t k, const uint64_t* g, const uint64_t* g
     if ((rc2 = msm_register_tables(c, p->g, p->n)) != CQ_OK) return rc2;
     if ((rc2 = msm_register_tables(c, p->g_lagrange, p->n)) != CQ_OK) return rc2;
   }
-  *out = p;
+  *out = guard.release();
   return CQ_OK;
 }
 
@@ -261,17 +282,13 @@ int cq_params_create(cq_ctx* c, uint32_t k, const uint64_t* g, const uint64_t* g
 int cq_params_setup_from_toxic_waste(cq_ctx* c, uint32_t k, const uint64_t s[4], cq_params** out) {
   if (!c || !s || !out || k > FR_S) return CQ_ERR_ARG;
   CQ_HIP(c, hipSetDevice(c->device));
-  cq_params* p = new cq_params();
-  p->ctx = c;
-  p->k = k;
-  p->n = (size_t)1 << k;
+  *out = nullptr;
+  cq_params* p = params_new(c, k);
+  ParamsGuard guard(p);
   const size_t bytes = p->n * sizeof(G1Affine);
   hipError_t e;
-  if ((e = hipMalloc(&p->g, bytes)) != hipSuccess || (e = hipMalloc(&p->g_lagrange, bytes)) != hipSuccess) {
-    if (p->g) hipFree(p->g);
-    delete p;
+  if ((e = hipMalloc(&p->g, bytes)) != hipSuccess || (e = hipMalloc(&p->g_lagrange, bytes)) != hipSuccess)
     return c->hip_fail(e, "hipMalloc(params)");
-  }
   void* tmp;
   int rc;
   if ((rc = c->ensure_scratch(1, p->n * sizeof(Fr), &tmp)) != CQ_OK) return rc;
@@ -282,7 +299,7 @@ int cq_params_setup_from_toxic_waste(cq_ctx* c, uint32_t k, const uint64_t s[4],
     if ((rc = msm_register_tables(c, p->g_lagrange, p->n)) != CQ_OK) return rc;
   }
   CQ_HIP(c, hipStreamSynchronize(c->stream));
-  *out = p;
+  *out = guard.release();
   return CQ_OK;
 }
 
@@ -303,15 +320,12 @@ int cq_params_read_raw(cq_ctx* c, const uint8_t* buf, size_t len, int checked, c
   const size_t n = (size_t)1 << k;
   if (len < 4 + 2 * n * sizeof(G1Affine)) return c->fail(CQ_ERR_ARG, "params: buffer too short");
   CQ_HIP(c, hipSetDevice(c->device));
-  cq_params* p = new cq_params();
-  p->ctx = c;
-  p->k = k;
-  p->n = n;
+  *out = nullptr;
+  cq_params* p = params_new(c, k);
+  ParamsGuard guard(p);
   const size_t bytes = n * sizeof(G1Affine);
-  if (hipMalloc(&p->g, bytes) != hipSuccess || hipMalloc(&p->g_lagrange, bytes) != hipSuccess) {
-    delete p;
+  if (hipMalloc(&p->g, bytes) != hipSuccess || hipMalloc(&p->g_lagrange, bytes) != hipSuccess)
     return c->fail(CQ_ERR_HIP, "hipMalloc(params)");
-  }
   CQ_HIP(c, hipMemcpyAsync(p->g, buf + 4, bytes, hipMemcpyHostToDevice, c->stream));
   CQ_HIP(c, hipMemcpyAsync(p->g_lagrange, buf + 4 + bytes, bytes, hipMemcpyHostToDevice, c->stream));
   if (checked) {  // SerdeFormat::RawBytes: coordinates < q and on the curve
@@ -324,12 +338,7 @@ int cq_params_read_raw(cq_ctx* c, const uint8_t* buf, size_t len, int checked, c
     uint32_t bad = 0;
     CQ_HIP(c, hipMemcpyAsync(&bad, tmp, 4, hipMemcpyDeviceToHost, c->stream));
     CQ_HIP(c, hipStreamSynchronize(c->stream));
-    if (bad) {
-      hipFree(p->g);
-      hipFree(p->g_lagrange);
-      delete p;
-      return c->fail(CQ_ERR_ARG, "params: invalid point encoding");
-    }
+    if (bad) return c->fail(CQ_ERR_ARG, "params: invalid point encoding");
   }
   CQ_HIP(c, hipStreamSynchronize(c->stream));
   if (c->msm_precompute) {
@@ -337,7 +346,7 @@ int cq_params_read_raw(cq_ctx* c, const uint8_t* buf, size_t len, int checked, c
     if ((rc2 = msm_register_tables(c, p->g, p->n)) != CQ_OK) return rc2;
     if ((rc2 = msm_register_tables(c, p->g_lagrange, p->n)) != CQ_OK) return rc2;
   }
-  *out = p;
+  *out = guard.release();
   return CQ_OK;
 }
 
@@ -352,15 +361,12 @@ int cq_params_downsize(cq_params* p, uint32_t k, cq_params** out) {
   if (!p || !out || k > p->k) return CQ_ERR_ARG;  // `assert!(k <= self.k)`
   cq_ctx* c = p->ctx;
   CQ_HIP(c, hipSetDevice(c->device));
-  cq_params* q = new cq_params();
-  q->ctx = c;
-  q->k = k;
-  q->n = (size_t)1 << k;
+  *out = nullptr;
+  cq_params* q = params_new(c, k);
+  ParamsGuard guard(q);
   const size_t bytes = q->n * sizeof(G1Affine);
-  if (hipMalloc(&q->g, bytes) != hipSuccess || hipMalloc(&q->g_lagrange, bytes) != hipSuccess) {
-    delete q;
+  if (hipMalloc(&q->g, bytes) != hipSuccess || hipMalloc(&q->g_lagrange, bytes) != hipSuccess)
     return c->fail(CQ_ERR_HIP, "hipMalloc(params)");
-  }
   CQ_HIP(c, hipMemcpyAsync(q->g, p->g, bytes, hipMemcpyDeviceToDevice, c->stream));
   int rc = g1_to_lagrange(c, q->g, k, q->g_lagrange);
   if (rc != CQ_OK) return rc;
@@ -368,7 +374,7 @@ int cq_params_downsize(cq_params* p, uint32_t k, cq_params** out) {
     if ((rc = msm_register_tables(c, q->g, q->n)) != CQ_OK) return rc;
     if ((rc = msm_register_tables(c, q->g_lagrange, q->n)) != CQ_OK) return rc;
   }
-  *out = q;
+  *out = guard.release();
   return CQ_OK;
 }
 
@@ -390,10 +396,10 @@ int cq_params_write_raw(cq_params* p, uint8_t* buf, size_t cap, size_t* written)
 void cq_params_destroy(cq_params* p) {
   if (!p) return;
   hipStreamSynchronize(p->ctx->stream);
-  msm_unregister_tables(p->ctx, p->g);
-  msm_unregister_tables(p->ctx, p->g_lagrange);
-  hipFree(p->g);
-  hipFree(p->g_lagrange);
+  if (p->g) msm_unregister_tables(p->ctx, p->g);
+  if (p->g_lagrange) msm_unregister_tables(p->ctx, p->g_lagrange);
+  if (p->g) hipFree(p->g);
+  if (p->g_lagrange) hipFree(p->g_lagrange);
   delete p;
 }
 

@@ -125,6 +125,7 @@ struct cq_pk {
   cq::Fr* ext_pow_lo = nullptr;     // extended_omega^t, t < 256
   cq::Fr* ext_pow_hi = nullptr;     // extended_omega^(256 b), b < max(ext / 256, 1)
   int opener = CQ_OPENER_GWC;
+  cq_rng_fill_fn rng_fill = nullptr;     // caller's bulk form of its RNG (cq_pk_set_rng_fill)
   std::vector<uint8_t> advice_phase;     // phase of every advice column
   std::vector<uint8_t> challenge_phase;  // phase after which user challenge i is squeezed
   uint32_t num_phases = 1;

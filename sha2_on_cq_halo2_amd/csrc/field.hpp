@@ -176,17 +176,16 @@ struct Fp {
   }
 
   // Montgomery product (same function as derive/field.rs:471-564); result < p.
-  // Device: CIOS over 32-bit limbs (v_mad_u64_u32).  Host: CIOS over 64-bit limbs with a 128-bit
-  // accumulator -- identical values, ~4x fewer multiplies for the host-side glue (window folding,
-  // normalisation, transcript scalars).
+  // Device: unsaturated 29-bit limbs (v_mad_u64_u32, below).  Host: CIOS over 64-bit limbs with a 128-bit
+  // accumulator -- identical values, for the host-side glue (window folding, normalisation, transcript scalars).
   CQ_HD Fp operator*(const Fp& b) const {
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(CQ_MUL_CIOS32)
+#if defined(__HIP_DEVICE_COMPILE__)
     // Unsaturated 9 x 29-bit limbs: every partial product lands in a 64-bit column accumulator with a
     // single v_mad_u64_u32 and no carry handling (9 products of < 2^58 plus 9 reduction products stay
     // below 2^63).  Montgomery reduction runs digit-serially in base 2^29 for 8 digits and finishes with
     // one 24-bit digit so that the overall divisor is exactly 2^256 (8*29 + 24): the value in memory
-    // keeps the reference's R = 2^256 form.  ~170 multiplies + ~170 simple ops, versus 136 + ~430 for
-    // the 32-bit CIOS below (whose carry plumbing the compiler turns into v_mov / 64-bit adds).
+    // keeps the reference's R = 2^256 form.  ~170 multiplies + ~170 simple ops (a CIOS over 8 x 32-bit limbs
+    // needed 136 + ~430: its carry plumbing turns into v_mov / 64-bit adds).
     constexpr uint32_t M29 = 0x1fffffffu;
     uint32_t A[9], B[9];
     unpack29(v.l, A);
@@ -229,36 +228,6 @@ struct Fp {
     r.v.l[6] = (r29[6] >> 18) | (r29[7] << 11);
     r.v.l[7] = (r29[7] >> 21) | (r29[8] << 8);
     cond_sub_p(r.v.l, 0);
-    return r;
-#elif defined(__HIP_DEVICE_COMPILE__)
-    uint32_t t[10];
-    CQ_UNROLL for (int i = 0; i < 10; i++) t[i] = 0;
-    CQ_UNROLL for (int i = 0; i < 8; i++) {
-      uint64_t c = 0;
-      const uint32_t bi = b.v.l[i];
-      CQ_UNROLL for (int j = 0; j < 8; j++) {
-        c += (uint64_t)v.l[j] * bi + t[j];
-        t[j] = (uint32_t)c;
-        c >>= 32;
-      }
-      c += t[8];
-      t[8] = (uint32_t)c;
-      t[9] = (uint32_t)(c >> 32);
-      const uint32_t m = t[0] * P::INV;
-      c = (uint64_t)m * P::MOD[0] + t[0];
-      c >>= 32;
-      CQ_UNROLL for (int j = 1; j < 8; j++) {
-        c += (uint64_t)m * P::MOD[j] + t[j];
-        t[j - 1] = (uint32_t)c;
-        c >>= 32;
-      }
-      c += t[8];
-      t[7] = (uint32_t)c;
-      t[8] = t[9] + (uint32_t)(c >> 32);
-    }
-    Fp r;
-    CQ_UNROLL for (int i = 0; i < 8; i++) r.v.l[i] = t[i];
-    cond_sub_p(r.v.l, t[8]);
     return r;
 #else
     typedef unsigned __int128 u128;

@@ -7,16 +7,17 @@
 // the contract: the proof bytes equal the reference's for
 // the same (pk, witness, RNG stream).
 //
-// Scope: one circuit with advice / fixed / instance columns, custom gates (postfix programs, plonk.hip),
-// the permutation argument and static lookups whose inputs are `advice[col] @ Rotation::cur()` (the shape
-// of the reference's one CQ test, tests/my_test.rs).  Not built: legacy (plookup-style) lookups,
-// multi-phase challenges, SHPLONK.  One deliberate omission: evaluation.rs:317-335 transforms
-// every advice / instance polynomial to the extended coset even when no term reads them (a CQ-only
-// circuit); that dead work is skipped.
+// Scope: one circuit with advice / fixed / instance columns, custom gates (postfix programs, plonk.hip), the
+// permutation argument, static (CQ) lookups whose inputs are arbitrary expressions, legacy plookup-style lookups
+// (grand product on the GPU, the sort of `permute_expression_pair` on the host), multi-phase circuits with user
+// challenges (cq_create_proof_phases), ProverGWC or ProverSHPLONK.  One deliberate omission:
+// evaluation.rs:317-335 transforms every advice / instance polynomial to the extended coset even when no term
+// reads them (a CQ-only circuit); that dead work is skipped.
 #include <algorithm>
 #include <array>
 #include <atomic>
 #include <chrono>
+#include <cstdlib>
 #include <cstring>
 #include <thread>
 #include <vector>
@@ -107,6 +108,7 @@ G1Jac jac_from_limbs(const uint64_t* l) {
 struct Rng {
   cq_rng_next_u64 next;
   void* state;
+  cq_rng_fill_fn bulk = nullptr;  // the caller's own bulk form (cq_pk_set_rng_fill)
   // Fr::random (bn256/fr.rs:159-170): eight next_u64, low limb first
   void words(uint64_t* w8) {
     for (int i = 0; i < 8; i++) w8[i] = next(state);
@@ -119,7 +121,9 @@ struct Rng {
   // `count` consecutive draws; the library's own generators are recognised and run inline (the indirect
   // call per u64 costs more than the generator: 2^21 draws per k=18 proof)
   void fill(uint64_t* dst, size_t count) {
-    if (next == cq_xoshiro256ss_next_u64) {
+    if (bulk) {
+      bulk(state, dst, count);
+    } else if (next == cq_xoshiro256ss_next_u64) {
       xoshiro_fill((uint64_t*)state, dst, count, 8);  // several threads for long runs, the same stream (xoshiro.hpp)
     } else if (next == cq_buffer_rng_next_u64) {
       cq_buffer_rng* b = (cq_buffer_rng*)state;
@@ -127,6 +131,7 @@ struct Rng {
       memcpy(dst, b->words + b->pos, take * sizeof(uint64_t));
       memset(dst + take, 0, (count - take) * sizeof(uint64_t));
       b->pos += take;
+      b->overrun += count - take;  // create_proof fails on an exhausted stream (capi_cq.hip)
     } else {
       for (size_t i = 0; i < count; i++) dst[i] = next(state);
     }
@@ -186,6 +191,19 @@ struct Commit {
     return CQ_OK;
   }
 };
+
+// A decision that changes the STRUCTURE of a round (how many launches, hence how many collectives and of what size) must
+// come out the same on every rank: true everywhere iff `flag` is set on any rank (one 8-byte all-gather).
+int shard_any(const cq_pk* pk, bool flag, bool& out) {
+  out = flag;
+  if (pk->shard_world <= 1) return CQ_OK;
+  const uint64_t mine = flag ? 1 : 0;
+  std::vector<uint64_t> all(pk->shard_world, 0);
+  if (pk->allgather(pk->allgather_user, &mine, all.data(), sizeof(uint64_t)) != 0)
+    return pk->ctx->fail(CQ_ERR_INTERNAL, "allgather callback failed");
+  for (uint64_t v : all) out = out || v != 0;
+  return CQ_OK;
+}
 
 // k * P on the host (4-bit fixed window over the canonical scalar): used where a commitment is a known linear
 // combination of commitments already computed -- f = sum_j theta^(w-1-j) e_j over plain advice columns gives
@@ -467,7 +485,7 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, const uint64_
   const bool general = pk->general();
   const size_t PL = pk->legacy.size();
   hipStream_t s = c->stream;
-  Rng rng{rng_next, rng_state};
+  Rng rng{rng_next, rng_state, pk->rng_fill};
   Transcript tr;
 
   // ---- carve the arena --------------------------------------------------------------------------
@@ -947,15 +965,20 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, const uint64_
     // of its own after the round's other MSMs, which start now.
     // Not done yet?  A launch of its own for the polynomial costs ~0.7 ms of GPU time; waiting costs what is left of
     // the draws.  Wait while the estimate (from the chunks done so far) stays below that, give up otherwise.
+    // The choice is timing-dependent, so sharded ranks agree on it first (late on any rank = late on all: a rank that
+    // has the polynomial ready just commits it in the second launch too).  CQ_RANDOM_LATE=0/1 pins it (tests).
+    bool random_late = false;
     {
+      const char* force = getenv("CQ_RANDOM_LATE");
       const auto t0 = std::chrono::steady_clock::now();
       while (!drawer.done.load()) {
+        if (force && force[0] == '1') break;
         const double waited = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
-        if (waited > 100.0 && drawer.remaining_us() > 700.0) break;
+        if (!(force && force[0] == '0') && waited > 100.0 && drawer.remaining_us() > 700.0) break;
         std::this_thread::yield();
       }
+      CQ_TRY(shard_any(pk, (force && force[0] == '1') || !drawer.done.load(), random_late));
     }
-    const bool random_late = !drawer.done.load();
     if (!random_late) CQ_TRY(finish_random_poly());
     // commitments, one batch of launches: the permutation products (permutation/prover.rs:177, written first),
     // then a, a0 (dense over the table SRS), q_a (over [qs_0|qs_1|...]), p, b0 (n-1 terms of b[1..]) and the

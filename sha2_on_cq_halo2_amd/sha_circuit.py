@@ -142,6 +142,15 @@ class ShaCqWorkload:
     def prove(self, seed: int = 1) -> bytes:
         return self.pk.create_proof_dev([c.ptr for c in self.cols], seed=seed)
 
+    def close(self, shared: bool = True):
+        """Frees the witness and the proving key, and (shared=True) the SRS / table objects -- 17 window tables per SRS
+        array, 4.3 GiB each at k = 22."""
+        objs = [self.pk, self.words_dev] + list(self.cols)
+        if shared:
+            objs += [self.dense, self.spread, self.cfg, self.params]
+        for o in objs:
+            o.close()
+
     # work counts of one proof (for throughput figures)
     def msm_scalars_per_proof(self) -> int:
         L, A, n, N = self.pairs, 2 * self.pairs, self.n, self.cfg.size
@@ -153,6 +162,13 @@ class ShaCqWorkload:
         """What the MSM kernels of this backend actually take in: the L commitments to f are obtained as
         theta * [a_2p] + [a_2p+1] from the advice commitments (plain advice columns as lookup inputs), not by an MSM."""
         return self.msm_scalars_per_proof() - self.pairs * self.n
+
+    def msm_scalars_full_width(self) -> int:
+        """The subset of msm_scalars_in_launches whose scalars are uniformly distributed field elements: p and b0, the
+        random polynomial, the h pieces, the opening witness, and a / a0 / q_a over the table (non-zero where m is).
+        Not counted: the advice columns (<= 24-bit limbs on 9.4 % of the rows) and m (small multiplicities)."""
+        L, n, N = self.pairs, self.n, self.cfg.size
+        return 2 * L * (n - 1) + n + 2 * n + (n - 1) + 2 * L * N + L * 2 * N
 
     def ntt_elems_per_proof(self) -> int:
         L, A, n = self.pairs, 2 * self.pairs, self.n

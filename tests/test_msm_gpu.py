@@ -167,3 +167,43 @@ def test_msm_batch_with_repeated_scalar_vector(ctx):
     exp = [OC.g1_to_affine(OC.best_multiexp(s, pts)) for s in scs]
     got = [OC.g1_to_affine(r) for r in res]
     assert np.array_equal(got[0], exp[0]) and np.array_equal(got[1], exp[1]) and np.array_equal(got[2], exp[0])
+
+
+def test_msm_k18_round2_shaped_launch_matches_c_oracle(ctx):
+    """One table-mode launch of the size a k = 18 proof really issues: 11 multiexps of 2^18 terms over a registered
+    SRS array in ONE cq_msm_batch_dev call (~49 M sorted entries, equal sub-lists, shared lists for the repeated
+    scalar vector), each compared with the C restatement of `best_multiexp` (arithmetic.rs:132-159).  Scalar mixes
+    as in a proof: uniform field elements, 12-bit limbs, a 0/1 selector, one constant column, a sparse column."""
+    from oracle import cbind as OC
+    from sha2_on_cq_halo2_amd import ParamsKZG
+
+    k = 18
+    n = 1 << k
+    s = B.to_mont_limbs([B.fr_random(B.Xoshiro256ss(0x18))])[0]
+    params = ParamsKZG.setup_from_toxic_waste(ctx, k, s)  # g_lagrange registered: 17 window tables
+    _, gl = params.download()
+    rs = np.random.RandomState(18)
+
+    def uniform():
+        a = rs.randint(0, 2**63, size=(n, 4), dtype=np.int64).astype(np.uint64)
+        a[:, 3] &= np.uint64((1 << 60) - 1)
+        return a
+
+    def small(bits):
+        a = np.zeros((n, 4), dtype=np.uint64)
+        a[:, 0] = rs.randint(0, 1 << bits, size=n).astype(np.uint64)
+        return a  # raw limbs: x * 2^-256 as field elements, i.e. still "random" values but with a fixed pattern
+
+    lim = np.tile(B.to_mont_limbs([int(v) for v in rs.randint(0, 4096, size=4096)]), (n // 4096, 1))
+    bits = np.tile(B.to_mont_limbs([int(v) for v in rs.randint(0, 2, size=4096)]), (n // 4096, 1))
+    const = np.tile(B.to_mont_limbs([B.fr_random(B.Xoshiro256ss(5))]), (n, 1))
+    sparse = np.zeros((n, 4), dtype=np.uint64)
+    sparse[::997] = uniform()[::997]
+    vecs = [uniform(), uniform(), lim, bits, const, sparse, uniform(), small(40), uniform(), uniform()]
+    dev = [ctx.to_device(v) for v in vecs]
+    order = list(range(len(vecs))) + [0]  # 11 MSMs, the last over the first one's scalars again
+    res = ctx.msm_batch_dev([dev[i].ptr for i in order], params.g_lagrange_dev, n)
+    exp = [OC.g1_to_affine(OC.best_multiexp(v, gl)) for v in vecs]
+    for j, i in enumerate(order):
+        assert np.array_equal(OC.g1_to_affine(res[j]), exp[i]), "MSM %d of the launch differs from the oracle" % j
+    params.close()

@@ -71,3 +71,18 @@ def test_best_fft_two_level_twiddles(monkeypatch):
             assert np.array_equal(c2.best_fft(a, w, log_n), OC.best_fft(a, w, log_n))
     finally:
         c2.close()
+
+
+@pytest.mark.parametrize("log_n", [18, 19, 20])
+def test_best_fft_full_size_matches_c_oracle(ctx, log_n):
+    """The BASELINE sizes themselves, element for element against the C restatement of `best_fft`
+    (arithmetic.rs:171-274): 2^18 and 2^19 take three Stockham passes (k = 18 and its extended domain), 2^20 four."""
+    from oracle import cbind as OC
+
+    rs = np.random.RandomState(1000 + log_n)
+    a = rs.randint(0, 2**63, size=(1 << log_n, 4), dtype=np.int64).astype(np.uint64)
+    a[:, 3] &= np.uint64((1 << 60) - 1)
+    a[::7919] = 0  # zeros and a maximal element among the inputs
+    a[1] = B.to_mont_limbs([B.R_MOD - 1])[0]
+    w = B.to_mont_limbs([_omega(log_n)])[0]
+    assert np.array_equal(ctx.best_fft(a, w, log_n), OC.best_fft(a, w, log_n))

@@ -60,6 +60,12 @@ single = wl.prove(seed=9)
 wl.pk.set_sharding(rank, world)
 sharded = wl.prove(seed=9)
 assert sharded == single, "sharded proof differs from the single-GPU proof"
+# The random polynomial is committed with round 2 or in a launch of its own, by a timing-dependent choice that the ranks
+# must make together (one launch more = one all-gather more): pin it differently per rank, then both ways.
+for late in (("1", "0"), ("0", "1"), ("1", "1"), ("0", "0")):
+    os.environ["CQ_RANDOM_LATE"] = late[rank]
+    assert wl.prove(seed=9) == single, "sharded proof differs with CQ_RANDOM_LATE=%%s" %% (late,)
+del os.environ["CQ_RANDOM_LATE"]
 wl.pk.set_sharding(0, 1)
 assert wl.prove(seed=9) == single
 dist.barrier(); dist.destroy_process_group(); ctx.close()

@@ -112,3 +112,34 @@ def test_lookup_failure_is_an_error(ctx):
     with pytest.raises(CqError) as e:
         env["gpk"].create_proof(cols, seed=1)
     assert e.value.code == -4
+
+
+def test_exhausted_rng_stream_is_an_error(ctx):
+    """A pre-drawn stream that runs out must fail the proof (zero blinding otherwise), not pad with zeros."""
+    from sha2_on_cq_halo2_amd import CqError
+
+    tv = {"t": list(range(16))}
+    env = _setup(ctx, 4, tv, [[(0, "t")]], 1, 9, srs_len=16)
+    cols = [B.to_mont_limbs([3, 5, 7] + [0] * 13)]
+    need = 8 * (1 * 7 + 16 + 1 + 2)  # 6 tail rows + 1 blind, n + 1 vanishing, 2 h blinds
+    words = B.Xoshiro256ss(3).words(need)
+    assert len(env["gpk"].create_proof(cols, rng_words=words)) == env["gpk"].proof_size
+    for short in (need - 1, need - 8 * 17, 5):
+        with pytest.raises(CqError) as e:
+            env["gpk"].create_proof(cols, rng_words=words[:short])
+        assert e.value.code == -1
+
+
+def test_opaque_caller_rng_gives_the_same_proof(ctx):
+    """A caller's RngCore is an opaque next_u64 callback: per-word draws on the helper thread (and the caller's own
+    bulk form, cq_pk_set_rng_fill) must give the bytes of the library's recognised generator for the same seed."""
+    from sha2_on_cq_halo2_amd.sha_circuit import ShaCqWorkload
+
+    wl = ShaCqWorkload(ctx, 12, pairs=2)
+    ref = wl.prove(seed=21)
+    ptrs = [c.ptr for c in wl.cols]
+    assert wl.pk.create_proof_dev(ptrs, seed=21, opaque_rng=True) == ref
+    wl.pk.set_rng_fill("opaque")
+    assert wl.pk.create_proof_dev(ptrs, seed=21, opaque_rng=True) == ref
+    wl.pk.set_rng_fill(None)
+    assert wl.pk.create_proof_dev(ptrs, seed=22, opaque_rng=True) != ref

@@ -62,12 +62,14 @@ def test_witness_fill_matches_decomposition_table(ctx):
     assert all(v == 0 for v in cols[0][rows_used:wl.pk.usable_rows])
 
 
-@pytest.mark.parametrize("k", [10, 12])
-def test_proof_bytes_equal_c_reference_restatement(ctx, k):
+@pytest.mark.parametrize("k,pairs", [(10, 2), (12, 2), (16, 4)])
+def test_proof_bytes_equal_c_reference_restatement(ctx, k, pairs):
+    """k = 16 with 4 pairs is BASELINE configs[1] (16 SHA blocks, 8 advice columns): byte for byte against the C
+    restatement of the reference prover ("parity unpinned" against the Rust prover itself: it holds no fixture)."""
     from sha2_on_cq_halo2_amd.api import fr_to_mont
     from sha2_on_cq_halo2_amd.sha_circuit import ShaCqWorkload, small_to_mont, spread16
 
-    wl = ShaCqWorkload(ctx, k, pairs=2)
+    wl = ShaCqWorkload(ctx, k, pairs=pairs)
     n = 1 << k
     proof = wl.prove(seed=5)
     g, gl = wl.params.download()
@@ -120,6 +122,34 @@ def test_k18_proof_is_accepted_and_deterministic(ctx):
     assert p1 == p2 and p1 != p3
     s = (seed * 0x9E3779B97F4A7C15 + 12345) % B.R_MOD
     assert _verify_workload_proof(wl, p1, s)
+
+
+@pytest.mark.parametrize("k", [20, 22])
+def test_large_k_proof_is_accepted_and_deterministic(ctx, k):
+    """BASELINE configs[3] and [4] on one GPU (k = 20: 256 blocks; k = 22: 1024 blocks, the per-GPU unit of the batched
+    configuration): the proof is accepted by the restated verifier, identical for identical (pk, witness, RNG seed),
+    different for another seed, and an opaque caller RNG gives the same bytes."""
+    from sha2_on_cq_halo2_amd.sha_circuit import BLOCKS_FOR_K, ShaCqWorkload
+
+    seed = 0x5348413243515F
+    wl = ShaCqWorkload(ctx, k, seed=seed)
+    assert wl.blocks == BLOCKS_FOR_K[k]
+    try:
+        p1 = wl.prove(seed=31)
+        p2 = wl.prove(seed=31)
+        p3 = wl.prove(seed=32)
+        assert p1 == p2 and p1 != p3 and len(p1) == wl.pk.proof_size
+        assert wl.pk.create_proof_dev([c.ptr for c in wl.cols], seed=31, opaque_rng=True) == p1
+        s = (seed * 0x9E3779B97F4A7C15 + 12345) % B.R_MOD
+        assert _verify_workload_proof(wl, p1, s)
+        bad = bytearray(p1)
+        bad[40] ^= 0x02  # inside the second advice commitment
+        try:
+            assert not _verify_workload_proof(wl, bytes(bad), s)
+        except ValueError:
+            pass
+    finally:  # 4.3 GiB of window tables per SRS array at k = 22: give them back before the next test
+        wl.close()
 
 
 @pytest.mark.parametrize("k", [10, 14])
