@@ -57,6 +57,7 @@ void cq_ctx_destroy(cq_ctx* c) {
     if (c->scratch[i]) hipFree(c->scratch[i]);
   if (c->pinned) hipHostFree(c->pinned);
   if (c->pinned_msm) hipHostFree(c->pinned_msm);
+  if (c->pinned_small) hipHostFree(c->pinned_small);
   if (c->prof_entries) hipHostFree(c->prof_entries);
   if (c->copy_done) hipEventDestroy(c->copy_done);
   if (c->copy_stream) hipStreamDestroy(c->copy_stream);

@@ -64,7 +64,7 @@ int msm_multi_begin(cq_ctx* c, const Fr* const* scalars, const G1Affine* const* 
     ln.Wb = L.Wb;
     ln.cols = L.cols;
     ln.slot = slots;
-    slots += (size_t)2 * batch * L.Wb;  // a (V, U) pair per bucket set
+    slots += (size_t)MSM_SET_POINTS * batch * L.Wb;  // bit-plane sums of every bucket set
     pend.launches.push_back(ln);
     done += batch;
   }
@@ -100,19 +100,36 @@ int msm_multi_begin(cq_ctx* c, const Fr* const* scalars, const G1Affine* const* 
 
 int msm_multi_end(cq_ctx* c, MsmPending& pend, uint64_t* out_jac) {
   CQ_HIP(c, hipStreamSynchronize(c->stream));
-  for (auto& ln : pend.launches) {
+  // the host's share of the reduction (msm_set_value: ~33 group operations per bucket set), spread over the context's
+  // worker threads when a launch has many sets
+  struct Item { const MsmPending::Launch* ln; uint32_t j; };
+  std::vector<Item> items;
+  size_t sets = 0;
+  for (auto& ln : pend.launches)
     for (uint32_t j = 0; j < ln.batch; j++) {
-      uint64_t* o = out_jac + (ln.first + j) * 12;
-      if (ln.empty) {
-        memset(o, 0, 12 * sizeof(uint64_t));
-        continue;
-      }
-      const G1Jac* res = (const G1Jac*)pend.host + ln.slot;
-      G1Jac r = ln.pre ? msm_set_value(res + (size_t)2 * j, ln.cols) : msm_fold_windows(res + (size_t)2 * j * ln.W, ln.W, ln.c, ln.cols);
-      r.x.to_limbs64(o);
-      r.y.to_limbs64(o + 4);
-      r.z.to_limbs64(o + 8);
+      items.push_back({&ln, j});
+      if (!ln.empty) sets += ln.pre ? 1 : ln.W;
     }
+  const G1Jac* host = (const G1Jac*)pend.host;
+  auto fold = [&](size_t i) {
+    const MsmPending::Launch& ln = *items[i].ln;
+    const uint32_t j = items[i].j;
+    uint64_t* o = out_jac + (ln.first + j) * 12;
+    if (ln.empty) {
+      memset(o, 0, 12 * sizeof(uint64_t));
+      return;
+    }
+    const G1Jac* res = host + ln.slot;
+    G1Jac r = ln.pre ? msm_set_value(res + (size_t)MSM_SET_POINTS * j, ln.cols)
+                     : msm_fold_windows(res + (size_t)MSM_SET_POINTS * j * ln.W, ln.W, ln.c, ln.cols);
+    r.x.to_limbs64(o);
+    r.y.to_limbs64(o + 4);
+    r.z.to_limbs64(o + 8);
+  };
+  if (sets > 6) {
+    c->pool().parallel_for(items.size(), fold);
+  } else {
+    for (size_t i = 0; i < items.size(); i++) fold(i);
   }
   return CQ_OK;
 }

@@ -1,12 +1,14 @@
 // Library context: one GPU, one stream, grow-only scratch buffers, cached NTT tables.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <memory>
 #include <string>
 #include <vector>
 #include "../../include/cq_halo2.h"
 #include "field.hpp"
 #include "ntt.hpp"
+#include "hostpool.hpp"
 
 struct cq_ctx {
   int device = 0;
@@ -131,6 +133,29 @@ struct cq_ctx {
     e = hipEventCreateWithFlags(&msm_tail_event, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&aux_done, hipEventDisableTiming);
     if (e != hipSuccess) return hip_fail(e, "hipEventCreate(aux)");
+    return CQ_OK;
+  }
+  // worker threads for the host-side glue (hostpool.hpp); CQ_HOST_THREADS overrides the count (0 = none)
+  std::unique_ptr<cq::HostPool> pool_;
+  cq::HostPool& pool() {
+    if (!pool_) {
+      unsigned hw = std::thread::hardware_concurrency();
+      unsigned w = hw > 3 ? (hw - 2 < 6 ? hw - 2 : 6) : 0;
+      if (const char* e = getenv("CQ_HOST_THREADS")) w = (unsigned)atoi(e);
+      pool_.reset(new cq::HostPool(w));
+    }
+    return *pool_;
+  }
+  // a page of pinned memory for the scalars a proof reads back (error flags, b(0), z values): a device-to-host copy into
+  // pageable memory is staged and blocks the host for ~25 us each, into pinned memory it is a plain asynchronous DMA
+  void* pinned_small = nullptr;
+  static constexpr size_t PINNED_SMALL_BYTES = 16384;
+  int ensure_pinned_small(void** out) {
+    if (!pinned_small) {
+      hipError_t e = hipHostMalloc(&pinned_small, PINNED_SMALL_BYTES, hipHostMallocDefault);
+      if (e != hipSuccess) return hip_fail(e, "hipHostMalloc");
+    }
+    *out = pinned_small;
     return CQ_OK;
   }
   void* pinned_msm = nullptr;  // MSM results (kept apart from `pinned`, which stages RNG words)

@@ -305,6 +305,13 @@ __global__ __launch_bounds__(PART_THREADS) void msm_bucket_count_kernel(const ui
   if (t < PART_BUCKETS && hist[t]) atomicAdd(&counts[(pid << PART_BITS) + t], hist[t]);
 }
 
+// an MSM that accumulates from another one's lists (same scalar vector) takes a copy of its bucket counts
+__global__ __launch_bounds__(256) void msm_alias_counts_kernel(uint32_t* __restrict__ counts, const uint64_t* __restrict__ list_src, uint32_t B) {
+  const uint32_t m = blockIdx.y, src = (uint32_t)list_src[m];
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (src != m && i < B) counts[(size_t)m * B + i] = counts[(size_t)src * B + i];
+}
+
 // Same idea one level down: a tile's entries are sorted by bucket in LDS, then copied out run by run (~32 entries =
 // one 128-byte line per bucket and tile).
 __global__ __launch_bounds__(PART_THREADS) void msm_bucket_place_kernel(const uint2* __restrict__ part_buf, const uint32_t* __restrict__ poff,
@@ -359,14 +366,25 @@ __global__ __launch_bounds__(PART_THREADS) void msm_bucket_place_kernel(const ui
 
 // ---- 2. plan: exclusive scans over the flat bucket array -----------------------------------------
 // Sequence 0 is the histogram itself (-> list start of every bucket); sequence k >= 1 is the
-// number of level-k sub-lists of every bucket: t1 = ceil(cnt/S1); t_k = ceil(t_{k-1}/S2) while t_{k-1} > MSM_SHORT,
-// else 0: a bucket with 2..MSM_SHORT partial sums is finished by msm_combine_short_kernel, which is indexed by
-// bucket and needs no slot; one with a single partial sum was written to its bucket by the level before.
+// number of level-k sub-lists of every bucket: t1 = ceil(cnt/S1); t_k = ceil(t_{k-1}/S2) while t_{k-1} > MSM_SHORT_MIN,
+// else 0: a bucket with 2..MSM_SHORT_MIN partial sums is always finished by the lane groups of msm_combine_level_kernel,
+// which are indexed by bucket and need no slot; one with a single partial sum was written to its bucket by the level
+// before.  Lists of MSM_SHORT_MIN+1..MSM_SHORT partial sums own a slot (one wave) that is used only when the launch
+// has few of them -- see combine_short_limit.
 static __device__ __forceinline__ uint32_t level_value(uint32_t cnt, uint32_t lv, uint32_t s1) {
   if (lv == 0) return cnt;
   uint32_t t = (cnt + s1 - 1) / s1;
-  for (uint32_t k = 2; k <= lv; k++) t = t <= MSM_SHORT ? 0 : (t + MSM_S2 - 1) / MSM_S2;
+  for (uint32_t k = 2; k <= lv; k++) t = t <= MSM_SHORT_MIN ? 0 : (t + MSM_S2 - 1) / MSM_S2;
   return t;
+}
+// Who sums a list of MSM_SHORT_MIN < t <= MSM_SHORT partial sums?  A lane group walks it serially (t / Q dependent
+// additions, work-optimal), a wave sums it as a tree (one load per lane and six shuffle levels: ~8x the lane-operations,
+// a third of the depth).  With hundreds of thousands of such lists the launch is throughput-bound and the lane groups
+// win; with a few (a sparse or skewed column: the SHA limb columns, the multiplicities m) the launch is waiting for its
+// longest dependent chain and the waves win.  Decided on the device from the number of wave slots of the level
+// (`slots` = off_cur[Bt], already there from the plan scan), the same way by both halves of the kernel.
+static __device__ __forceinline__ uint32_t combine_short_limit(uint32_t slots) {
+  return slots <= MSM_WAVE_BUDGET ? MSM_SHORT_MIN : MSM_SHORT;
 }
 
 // exclusive scan of one value per thread over a 256-thread block; returns prefix, total via out param
@@ -557,55 +575,56 @@ __global__ __launch_bounds__(MSM_ACC_THREADS) void msm_accumulate_kernel(
   store_xyzz29(t == 1 ? buckets + g : partial + j, acc);
 }
 
-// level k >= 2, long lists (more than MSM_SHORT partial sums of level k-1 -- 0/1 columns, sparse top windows): one
-// WAVE per sub-list of <= MSM_S2 of them.  Only these lists have slots at level k, so off_cur[Bt] is small (usually
-// zero) and almost every wave of the grid leaves at the first test.
-__global__ __launch_bounds__(256) void msm_combine_kernel(
+// Level k >= 2 in ONE launch.  Blocks [0, short_blocks): Q lanes per BUCKET sum the short lists (2..limit partial sums
+// of level k-1, always the whole bucket): indexed by bucket, no search, a bucket that is empty, already final (one
+// partial sum) or long costs one load; a group sums strided parts and folds them with log2(Q) shuffles.  The remaining
+// blocks: one WAVE per sub-list of <= MSM_S2 partial sums of the longer lists (strided lane sums + 6-step shuffle tree);
+// only those lists own slots at level k, so off_cur[Bt] is small (usually zero) and almost every wave leaves at the
+// first test.  The two halves write different buckets and do not depend on each other: one launch instead of two
+// keeps the level's latency at the longer of the two chains.
+template <uint32_t Q>
+__global__ __launch_bounds__(256) void msm_combine_level_kernel(
     const XYZZ* __restrict__ prev, const uint32_t* __restrict__ t_prev, const uint32_t* __restrict__ off_prev,
-    const uint32_t* __restrict__ t_cur, const uint32_t* __restrict__ off_cur, uint32_t Bt, XYZZ* __restrict__ partial,
-    XYZZ* __restrict__ buckets) {
+    const uint32_t* __restrict__ t_cur, const uint32_t* __restrict__ off_cur, uint32_t Bt, uint32_t short_blocks,
+    XYZZ* __restrict__ partial, XYZZ* __restrict__ buckets) {
+  const uint32_t slots = off_cur[Bt];
+  const uint32_t limit = combine_short_limit(slots);
+  if (blockIdx.x < short_blocks) {
+    const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t g = gt / Q, sub = gt % Q;
+    const uint32_t tp = g < Bt ? t_prev[g] : 0;
+    const bool mine = tp >= 2 && tp <= limit;
+    if (!__any(mine)) return;  // wave-uniform
+    const uint32_t lo = mine ? off_prev[g] : 0;
+    XYZZ29 acc = XYZZ29::identity();
+    if (mine)
+      for (uint32_t e = sub; e < tp; e += Q) xyzz29_add(acc, load_xyzz29(prev + lo + e));
+#pragma unroll 1
+    for (int delta = Q / 2; delta >= 1; delta >>= 1) {
+      XYZZ29 o = xyzz29_shfl_down(acc, delta);  // all lanes take part in the shuffle
+      if (mine && sub + delta < Q) xyzz29_add(acc, o);
+    }
+    if (mine && sub == 0) store_xyzz29(buckets + g, acc);
+    return;
+  }
   const uint32_t lane = threadIdx.x & 63;
-  const uint32_t j = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);  // wave-uniform
-  if (j >= off_cur[Bt]) return;
+  const uint32_t j = (blockIdx.x - short_blocks) * (blockDim.x >> 6) + (threadIdx.x >> 6);  // wave-uniform
+  if (j >= slots) return;
   const uint32_t g = owner_of(off_cur, Bt, j);
   const uint32_t tp = t_prev[g];
+  if (tp <= limit) return;  // a lane group of the other half owns this list (throughput-bound launch)
   const uint32_t r = j - off_cur[g];
   const uint32_t lo = off_prev[g] + r * MSM_S2;
   const uint32_t hi = min(off_prev[g] + tp, lo + MSM_S2);
   XYZZ29 acc = XYZZ29::identity();
   for (uint32_t e = lo + lane; e < hi; e += 64) xyzz29_add(acc, load_xyzz29(prev + e));
+  const int top = hi - lo > 32 ? 32 : hi - lo > 16 ? 16 : hi - lo > 8 ? 8 : hi - lo > 4 ? 4 : hi - lo > 2 ? 2 : 1;
 #pragma unroll 1
-  for (int delta = 32; delta >= 1; delta >>= 1) {
+  for (int delta = top; delta >= 1; delta >>= 1) {  // lanes >= hi - lo hold the identity: the tree starts where the data ends
     XYZZ29 o = xyzz29_shfl_down(acc, delta);
     xyzz29_add(acc, o);
   }
   if (lane == 0) store_xyzz29(t_cur[g] == 1 ? buckets + g : partial + j, acc);
-}
-
-// level k >= 2, short lists (2..MSM_SHORT partial sums, always the whole bucket): Q lanes per BUCKET.  The additions
-// of one list are dependent, so with few buckets (a launch of one or two MSMs is latency-bound) a quad sums strided
-// quarters and folds them with two shuffles (depth tp/4 + 2 instead of tp); a launch with hundreds of thousands of
-// buckets is throughput-bound and uses one lane per bucket (no idle shuffle levels).  Indexed by bucket: no search,
-// and a bucket that is empty, already final (one partial sum) or long costs one load.
-template <uint32_t Q>
-__global__ __launch_bounds__(MSM_ACC_THREADS) void msm_combine_short_kernel(
-    const XYZZ* __restrict__ prev, const uint32_t* __restrict__ t_prev, const uint32_t* __restrict__ off_prev, uint32_t Bt,
-    XYZZ* __restrict__ buckets) {
-  const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x;
-  const uint32_t g = gt / Q, sub = gt % Q;
-  const uint32_t tp = g < Bt ? t_prev[g] : 0;
-  const bool mine = tp >= 2 && tp <= MSM_SHORT;
-  if (!__any(mine)) return;  // wave-uniform
-  const uint32_t lo = mine ? off_prev[g] : 0;
-  XYZZ29 acc = XYZZ29::identity();
-  if (mine)
-    for (uint32_t e = sub; e < tp; e += Q) xyzz29_add(acc, load_xyzz29(prev + lo + e));
-#pragma unroll 1
-  for (int delta = Q / 2; delta >= 1; delta >>= 1) {
-    XYZZ29 o = xyzz29_shfl_down(acc, delta);  // all lanes take part in the shuffle
-    if (mine && sub + delta < Q) xyzz29_add(acc, o);
-  }
-  if (mine && sub == 0) store_xyzz29(buckets + g, acc);
 }
 
 // ---- precomputed window tables (one-off setup) -----------------------------------------------------------
@@ -695,36 +714,34 @@ __global__ __launch_bounds__(64) void msm_rowcol_kernel(const XYZZ* __restrict__
   if (seg == 0 && q < rows + cols) store_xyzz29(sums + (size_t)set * (rows + cols) + q, acc);
 }
 
-// sum_{j < count} (j + first_weight) X_j over one wave, count <= 128; result in lane 0
-static __device__ __forceinline__ XYZZ29 wave_weighted_sum(const XYZZ* __restrict__ X, uint32_t count, uint32_t first_weight) {
-  const uint32_t lane = threadIdx.x & 63;
-  const XYZZ29 a = 2 * lane < count ? load_xyzz29(X + 2 * lane) : XYZZ29::identity();
-  const XYZZ29 b = 2 * lane + 1 < count ? load_xyzz29(X + 2 * lane + 1) : XYZZ29::identity();
-  // sum_j j X_j = sum_l (2l (a_l + b_l) + b_l) = 2 sum_l l S_l + sum_l b_l,   sum_l l S_l = sum_{l >= 1} Suffix_l
-  XYZZ29 suf = a;
-  xyzz29_add(suf, b);  // S_l
-#pragma unroll 1
-  for (int delta = 1; delta < 64; delta <<= 1) {
-    XYZZ29 o = xyzz29_shfl_down(suf, delta);
-    if (lane + delta < 64) xyzz29_add(suf, o);
-  }
-  XYZZ29 v = lane >= 1 ? xyzz29_dbl(suf) : XYZZ29::identity();
-  xyzz29_add(v, b);
-  if (first_weight) {  // + first_weight * sum_j X_j (the total is lane 0's suffix); first_weight is 0 or 1 here
-    if (lane == 0) xyzz29_add(v, suf);
-  }
-  return wave_sum(v);
-}
-
-// Two waves per bucket set, one per weighted sum.  The set's value is cols * V + U with V = sum_hi hi R_hi and
-// U = sum_lo (lo + 1) C_lo; the log2(cols) doublings and the last addition are left to the host (a single wave needs
-// ~9 us per dependent EC operation here, the CPU a fraction of a microsecond): out[2 set] = V, out[2 set + 1] = U.
-__global__ __launch_bounds__(128) void msm_weighted_kernel(const XYZZ* __restrict__ sums, uint32_t rows, uint32_t cols,
+// sum_{j < count} (j + first_weight) X_j, count <= 128, as sum_t 2^t S_t with S_t = the sum of the X_j whose index has
+// bit t set: seven independent 64-term trees (six shuffle levels) instead of a suffix scan followed by a tree (fifteen
+// dependent additions, ~190 us for a lone wave -- the longest single stretch of a launch's tail; a doubling costs a
+// lone wave as much as an addition, so the "2^t" may not run here either).  The kernel stops at the S_t: the Horner
+// over t, the plain total of the "+ first_weight" term, the log2(cols) doublings and the last additions are ~33 group
+// operations per bucket set for the host (msm_set_value), which needs a fraction of a microsecond for each where a
+// lone wave needs ~10 us.  One block per (bucket set, row / column side), eight waves: wave t < 7 -> S_t, wave 7 (column
+// side) -> the total.  out[set][0..6] = row planes, [7..13] = column planes, [14] = column total (MSM_SET_POINTS).
+__global__ __launch_bounds__(512) void msm_weighted_kernel(const XYZZ* __restrict__ sums, uint32_t rows, uint32_t cols,
                                                            G1Jac* __restrict__ out) {
-  const uint32_t set = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const XYZZ* S = sums + (size_t)set * (rows + cols);
-  const XYZZ29 v = wave == 0 ? wave_weighted_sum(S, rows, 0) : wave_weighted_sum(S + rows, cols, 1);
-  if (lane == 0) out[2 * set + wave] = xyzz29_to_jac(v);
+  const uint32_t set = blockIdx.x >> 1, which = blockIdx.x & 1;
+  const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const XYZZ* X = sums + (size_t)set * (rows + cols) + (which ? rows : 0);
+  const uint32_t count = which ? cols : rows;
+  G1Jac* o = out + (size_t)set * MSM_SET_POINTS;
+  XYZZ29 v = XYZZ29::identity();
+  if (wave < 7) {
+    const uint32_t t = wave;
+    const uint32_t j = ((lane >> t) << (t + 1)) | (1u << t) | (lane & ((1u << t) - 1u));  // lane-th index with bit t set
+    if (j < count) v = load_xyzz29(X + j);
+    v = wave_sum(v);
+    if (lane == 0) o[7 * which + t] = xyzz29_to_jac(v);
+  } else if (which) {
+    if (lane < count) v = load_xyzz29(X + lane);
+    if (lane + 64 < count) xyzz29_add(v, load_xyzz29(X + lane + 64));
+    v = wave_sum(v);
+    if (lane == 0) o[14] = xyzz29_to_jac(v);
+  }
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -773,11 +790,11 @@ MsmLayout::MsmLayout(uint32_t n_, uint32_t c_, uint32_t batch_, bool pre_) : n(n
   off_off = o;     o = up(o + (size_t)nseq * (Bt + 1) * sizeof(uint32_t));
   off_tk = o;      o = up(o + (size_t)levels * Bt * sizeof(uint32_t));
   off_sorted = o;  o = up(o + (size_t)E * sizeof(uint32_t));
-  // partial sums: level 1 has at most ceil(E/S1) + Bt sub-lists; level k >= 2 only serves lists of more than
-  // MSM_SHORT items, so at most items/S2 + items/SHORT + 1 sub-lists
+  // partial sums: level 1 has at most ceil(E/S1) + Bt sub-lists; level k >= 2 only reserves slots for lists of more
+  // than MSM_SHORT_MIN items, so at most items/S2 + items/SHORT_MIN + 1 sub-lists
   for (uint32_t k = 0; k < 8; k++) tmax[k] = 0;
   tmax[0] = (E + MSM_S1 - 1) / MSM_S1 + Bt;
-  for (uint32_t k = 1; k < levels; k++) tmax[k] = tmax[k - 1] / MSM_S2 + tmax[k - 1] / MSM_SHORT + 1;
+  for (uint32_t k = 1; k < levels; k++) tmax[k] = tmax[k - 1] / MSM_S2 + tmax[k - 1] / MSM_SHORT_MIN + 1;
   off_part[0] = o;
   o = up(o + (size_t)tmax[0] * sizeof(XYZZ));
   off_part[1] = o;
@@ -862,11 +879,7 @@ int msm_run(cq_ctx* ctx, const Fr* const* scalars_host_ptrs, const G1Affine* con
     msm_part_scatter_kernel<<<dim3((n + PSC_THREADS - 1) / PSC_THREADS, batch), PSC_THREADS, 0, s>>>(d_scalars, d_lens, c, W, L.npart, poff, pcursor,
                                                                                                      part_buf);
     msm_bucket_count_kernel<<<dim3(P, PART_SPLIT), PART_THREADS, 0, s>>>(part_buf, poff, counts);
-    if (any_alias)
-      for (uint32_t i = 0; i < batch; i++)
-        if (alias[i] != i && hipMemcpyAsync(counts + (size_t)i * L.B, counts + (size_t)alias[i] * L.B, (size_t)L.B * sizeof(uint32_t),
-                                            hipMemcpyDeviceToDevice, s) != hipSuccess)
-          return -1;
+    if (any_alias) msm_alias_counts_kernel<<<dim3((L.B + 255) / 256, batch), 256, 0, s>>>(counts, d_src, L.B);
     msm_scan_reduce_kernel<<<L.nblk, 256, 0, s>>>(counts, Bt, L.nseq, s1, blocksums);
     msm_scan_spine_kernel<<<1, 1024, 0, s>>>(blocksums, L.nblk, L.nseq);
     msm_scan_apply_kernel<<<L.nblk, 256, 0, s>>>(counts, Bt, L.nseq, s1, blocksums, off, tk);
@@ -893,34 +906,41 @@ int msm_run(cq_ctx* ctx, const Fr* const* scalars_host_ptrs, const G1Affine* con
     const uint32_t* off_prev = off + (size_t)k * (Bt + 1);
     const uint32_t* t_cur = tk + (size_t)k * Bt;
     const uint32_t* off_cur = off + (size_t)(k + 1) * (Bt + 1);
-    // ping-pong: level k+1 reads part[(k-1)&1], writes part[k&1]; one wave per sub-list
-    const uint32_t q = Bt <= (1u << 15) ? 4u : Bt <= (1u << 17) ? 2u : 1u;  // lanes per bucket, see the kernel
-    const uint32_t cs_blocks = (uint32_t)(((uint64_t)Bt * q + MSM_ACC_THREADS - 1) / MSM_ACC_THREADS);
-    if (q == 4) msm_combine_short_kernel<4><<<cs_blocks, MSM_ACC_THREADS, 0, s>>>(part[(k - 1) & 1], t_prev, off_prev, Bt, buckets);
-    else if (q == 2) msm_combine_short_kernel<2><<<cs_blocks, MSM_ACC_THREADS, 0, s>>>(part[(k - 1) & 1], t_prev, off_prev, Bt, buckets);
-    else msm_combine_short_kernel<1><<<cs_blocks, MSM_ACC_THREADS, 0, s>>>(part[(k - 1) & 1], t_prev, off_prev, Bt, buckets);
-    msm_combine_kernel<<<(uint32_t)((L.tmax[k] + 3) / 4), 256, 0, s>>>(part[(k - 1) & 1], t_prev, off_prev, t_cur, off_cur, Bt,
-                                                                       part[k & 1], buckets);
+    // ping-pong: level k+1 reads part[(k-1)&1], writes part[k&1]
+    const uint32_t q = Bt <= (1u << 18) ? 4u : Bt <= (1u << 19) ? 2u : 1u;  // lanes per bucket, see the kernel
+    const uint32_t cs_blocks = (uint32_t)(((uint64_t)Bt * q + 255) / 256);
+    const uint32_t wv_blocks = (uint32_t)((L.tmax[k] + 3) / 4);
+    if (q == 4) msm_combine_level_kernel<4><<<cs_blocks + wv_blocks, 256, 0, s>>>(part[(k - 1) & 1], t_prev, off_prev, t_cur, off_cur, Bt, cs_blocks, part[k & 1], buckets);
+    else if (q == 2) msm_combine_level_kernel<2><<<cs_blocks + wv_blocks, 256, 0, s>>>(part[(k - 1) & 1], t_prev, off_prev, t_cur, off_cur, Bt, cs_blocks, part[k & 1], buckets);
+    else msm_combine_level_kernel<1><<<cs_blocks + wv_blocks, 256, 0, s>>>(part[(k - 1) & 1], t_prev, off_prev, t_cur, off_cur, Bt, cs_blocks, part[k & 1], buckets);
   }
-  if (batch * L.Wb <= 4)
-    msm_rowcol_kernel<64><<<dim3(L.rows + L.cols, batch * L.Wb), 64, 0, s>>>(buckets, M, L.rows, L.cols, pairs);
+  const uint32_t sets = batch * L.Wb;
+  if (sets <= 4)
+    msm_rowcol_kernel<64><<<dim3(L.rows + L.cols, sets), 64, 0, s>>>(buckets, M, L.rows, L.cols, pairs);
+  else if (sets <= 12)
+    msm_rowcol_kernel<32><<<dim3((L.rows + L.cols + 1) / 2, sets), 64, 0, s>>>(buckets, M, L.rows, L.cols, pairs);
   else
-    msm_rowcol_kernel<16><<<dim3((L.rows + L.cols + 3) / 4, batch * L.Wb), 64, 0, s>>>(buckets, M, L.rows, L.cols, pairs);
-  msm_weighted_kernel<<<batch * L.Wb, 128, 0, s>>>(pairs, L.rows, L.cols, window_sums_dev);
+    msm_rowcol_kernel<16><<<dim3((L.rows + L.cols + 3) / 4, sets), 64, 0, s>>>(buckets, M, L.rows, L.cols, pairs);
+  msm_weighted_kernel<<<2 * sets, 512, 0, s>>>(pairs, L.rows, L.cols, window_sums_dev);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
-G1Jac msm_set_value(const G1Jac* pair, uint32_t cols) {
-  G1Jac v = pair[0];
+// cols * V + U from the bit-plane sums of msm_weighted_kernel: V = sum_t 2^t R_t, U = sum_t 2^t C_t + C_total
+G1Jac msm_set_value(const G1Jac* planes, uint32_t cols) {
+  G1Jac v = planes[6], u = planes[13];
+  for (int t = 5; t >= 0; t--) {
+    v = jac_add(jac_dbl(v), planes[t]);
+    u = jac_add(jac_dbl(u), planes[7 + t]);
+  }
   for (uint32_t l = cols; l > 1; l >>= 1) v = jac_dbl(v);
-  return jac_add(v, pair[1]);
+  return jac_add(jac_add(v, u), planes[14]);
 }
 
 G1Jac msm_fold_windows(const G1Jac* pairs, uint32_t W, uint32_t c, uint32_t cols) {
   G1Jac acc = G1Jac::identity();
   for (int w = (int)W - 1; w >= 0; w--) {
     for (uint32_t j = 0; j < c; j++) acc = jac_dbl(acc);
-    acc = jac_add(acc, msm_set_value(pairs + 2 * w, cols));
+    acc = jac_add(acc, msm_set_value(pairs + (size_t)MSM_SET_POINTS * w, cols));
   }
   return acc;
 }

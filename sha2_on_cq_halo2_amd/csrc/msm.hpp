@@ -27,9 +27,15 @@ constexpr uint32_t MSM_S1_BIG_LOAD = CQ_MSM_S1_BIG_LOAD;
 #endif
 constexpr uint32_t MSM_PARTIALS_TARGET = CQ_MSM_PARTIALS_TARGET;  // partial sums per bucket aimed at under heavy load (< MSM_SHORT)
 static_assert(MSM_S1_BIG >= MSM_S1, "the workspace is sized for MSM_S1");
-constexpr uint32_t MSM_S2 = 256;        // max partial sums summed by one wave (levels >= 2)
-constexpr uint32_t MSM_SHORT = 64;       // level >= 2 lists up to this long are summed by one lane
+constexpr uint32_t MSM_S2 = 64;         // max partial sums summed by one wave (levels >= 2): one load per lane, six shuffle levels
+constexpr uint32_t MSM_SHORT = 64;       // level >= 2 lists up to this long are summed by a lane group when the launch is throughput-bound
+constexpr uint32_t MSM_SHORT_MIN = 16;   // ... and lists up to this long always; the ones in between go to a wave each when they are few
+#ifndef CQ_MSM_WAVE_BUDGET
+#define CQ_MSM_WAVE_BUDGET 4096
+#endif
+constexpr uint32_t MSM_WAVE_BUDGET = CQ_MSM_WAVE_BUDGET;  // "few": at most this many wave slots in the level (4 per SIMD)
 constexpr uint32_t MSM_MAX_BATCH = 32;  // MSMs per launch
+constexpr uint32_t MSM_SET_POINTS = 15; // points a bucket set leaves for the host: 7 + 7 bit-plane sums and a total (msm_set_value)
 
 struct MsmPtrs {
   const void* p[MSM_MAX_BATCH];
@@ -50,16 +56,16 @@ struct MsmLayout {
 
 uint32_t msm_window_bits(uint32_t n);
 // Enqueues the whole pipeline on ctx->stream.
-// `scalars` / `bases`: HOST arrays of `batch` device pointers; window_sums_dev receives a PAIR of points (V, U) per
-// bucket set -- the set's value is cols * V + U (msm_set_value; cols = MsmLayout::cols) -- batch*W pairs.
+// `scalars` / `bases`: HOST arrays of `batch` device pointers; window_sums_dev receives MSM_SET_POINTS points per
+// bucket set -- bit-plane sums the host folds into the set's value (msm_set_value; cols = MsmLayout::cols).
 // `pre`: every bases[j] points to a precomputed table [W][table_stride] with table[w][i] = 2^(c*w)*base[i]
-// (msm_precompute_tables); then there is ONE bucket set, i.e. one pair, per MSM.
+// (msm_precompute_tables); then there is ONE bucket set per MSM.
 // lens[j] <= n: per-MSM lengths (one launch may mix lengths; n is the maximum)
 int msm_run(cq_ctx* ctx, const Fr* const* scalars, const G1Affine* const* bases, const size_t* lens, uint32_t n, uint32_t c,
             uint32_t batch, bool pre, const size_t* table_strides, void* workspace, G1Jac* window_sums_dev);
 int msm_precompute_tables(cq_ctx* ctx, const G1Affine* bases, uint32_t n, uint32_t c, G1Affine* table);
-// Host: value of one bucket set from its pair; sum_w 2^(c*w) * (value of set w) over W consecutive pairs.
-G1Jac msm_set_value(const G1Jac* pair, uint32_t cols);
+// Host: value of one bucket set from its MSM_SET_POINTS points; sum_w 2^(c*w) * (value of set w) over W consecutive sets.
+G1Jac msm_set_value(const G1Jac* planes, uint32_t cols);
 G1Jac msm_fold_windows(const G1Jac* pairs, uint32_t W, uint32_t c, uint32_t cols);
 
 }  // namespace cq

@@ -4,6 +4,7 @@
 // coalesced read and write per element, arithmetic fused so every vector is touched once.
 #include "poly.hpp"
 #include <algorithm>
+#include <cstring>
 #include "ctx.hpp"
 
 namespace cq {
@@ -219,6 +220,21 @@ __global__ void fill_usable_rows_kernel(Fr* out, uint32_t n, uint32_t u) {
   st(out + i, i < u ? Fr::one() : Fr::zero());
 }
 
+// one 16-byte half element per lane
+__global__ __launch_bounds__(256) void advice_fill_kernel(AdviceFillArgs a, const Fr* __restrict__ tails, uint32_t n, uint32_t u) {
+  const uint32_t col = blockIdx.y;
+  const uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;  // half-element index
+  if (h >= 2 * n) return;
+  const uint32_t i = h >> 1;
+  const uint4* src = i < u ? reinterpret_cast<const uint4*>(a.src[col]) + h
+                           : reinterpret_cast<const uint4*>(tails + (size_t)col * (n - u)) + (h - 2 * u);
+  reinterpret_cast<uint4*>(a.dst[col])[h] = *src;
+}
+__global__ void gather_scalars_kernel(GatherArgs a, Fr* out) {
+  const uint32_t i = threadIdx.x;
+  if (i < a.count) st(out + i, ld(a.src[i]));
+}
+
 // =================================================================================================
 // host drivers
 // =================================================================================================
@@ -259,7 +275,8 @@ int poly_eval_batch(cq_ctx* c, const Fr* const* p, const uint32_t* len, uint32_t
       y = y.sqr();
     }
     const uint32_t nb = (curmax + EVAL_TILE - 1) / EVAL_TILE;
-    block_eval_kernel<<<dim3(nb, count), 256, 0, c->stream>>>(args, stride, level_in, buf[which], stride, pw);
+    // the last level leaves its `count` results next to each other
+    block_eval_kernel<<<dim3(nb, count), 256, 0, c->stream>>>(args, stride, level_in, buf[which], nb == 1 ? 1u : stride, pw);
     for (uint32_t i = 0; i < count; i++) args.cur_len[i] = (args.cur_len[i] + EVAL_TILE - 1) / EVAL_TILE;
     level_in = buf[which];
     curmax = nb;
@@ -267,11 +284,15 @@ int poly_eval_batch(cq_ctx* c, const Fr* const* p, const uint32_t* len, uint32_t
     which ^= 1;
     x = y;  // x^(8 * 2^8) = x^2048
   }
-  // results sit at level_in[poly * stride]; gather with one strided copy
-  if (hipMemcpy2DAsync(out_host, sizeof(Fr), level_in, (size_t)stride * sizeof(Fr), sizeof(Fr), count, hipMemcpyDeviceToHost,
-                       c->stream) != hipSuccess)
+  // one plain copy into pinned memory (a strided copy into pageable memory took the host ~100 us)
+  void* small;
+  if ((rc = c->ensure_pinned_small(&small)) != CQ_OK) return rc;
+  Fr* stage = (Fr*)((char*)small + 4096);
+  static_assert(4096 + EVAL_MAX_BATCH * sizeof(Fr) <= cq_ctx::PINNED_SMALL_BYTES, "pinned page layout");
+  if (hipMemcpyAsync(stage, level_in, (size_t)count * sizeof(Fr), hipMemcpyDeviceToHost, c->stream) != hipSuccess)
     return c->fail(CQ_ERR_HIP, "eval: D2H failed");
   if (hipStreamSynchronize(c->stream) != hipSuccess) return c->fail(CQ_ERR_HIP, "eval: sync failed");
+  memcpy(out_host, stage, (size_t)count * sizeof(Fr));
   // empty polynomials evaluate to zero (their blocks wrote zero already)
   return CQ_OK;
 }
@@ -345,6 +366,18 @@ int poly_cq_quotient(cq_ctx* c, const CqQuotientArgs& args, uint32_t ext, Fr* h)
 int poly_fill_usable_rows(cq_ctx* c, Fr* out, uint32_t n, uint32_t u) {
   fill_usable_rows_kernel<<<blocks_for(n), 256, 0, c->stream>>>(out, n, u);
   return hipGetLastError() == hipSuccess ? CQ_OK : c->fail(CQ_ERR_HIP, "fill launch failed");
+}
+
+int poly_advice_fill(cq_ctx* c, const AdviceFillArgs& a, const Fr* tails_dev, uint32_t n, uint32_t u) {
+  if (!a.count) return CQ_OK;
+  advice_fill_kernel<<<dim3(blocks_for(2 * n), a.count), 256, 0, c->stream>>>(a, tails_dev, n, u);
+  return hipGetLastError() == hipSuccess ? CQ_OK : c->fail(CQ_ERR_HIP, "advice fill launch failed");
+}
+
+int poly_gather_scalars(cq_ctx* c, const GatherArgs& a, Fr* out_dev) {
+  if (!a.count) return CQ_OK;
+  gather_scalars_kernel<<<1, GATHER_MAX, 0, c->stream>>>(a, out_dev);
+  return hipGetLastError() == hipSuccess ? CQ_OK : c->fail(CQ_ERR_HIP, "gather launch failed");
 }
 
 }  // namespace cq

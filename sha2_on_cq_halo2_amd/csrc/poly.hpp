@@ -9,7 +9,7 @@ struct cq_ctx;
 
 namespace cq {
 
-constexpr uint32_t POLY_CHUNK = 64;   // coefficients per lane in chunked Horner / division
+constexpr uint32_t POLY_CHUNK = 16;   // coefficients per lane in chunked Horner / division (64: 4096 lanes at n = 2^18, each kernel ~60 us of latency)
 constexpr uint32_t LINCOMB_MAX = 40;  // polynomials per linear combination launch
 constexpr uint32_t CQ_MAX_LOOKUPS = 16;
 
@@ -53,6 +53,22 @@ int poly_from_u512(cq_ctx* c, const uint64_t* words_dev, uint32_t n, Fr* out_dev
 int poly_cq_b_denominators(cq_ctx* c, const Fr* f, uint32_t n, uint32_t u, const Fr& beta, Fr* out);
 int poly_cq_quotient(cq_ctx* c, const CqQuotientArgs& args, uint32_t ext, Fr* h);
 int poly_fill_usable_rows(cq_ctx* c, Fr* out, uint32_t n, uint32_t u);
+// dst[j] rows [0, u) <- src[j] rows [0, u), rows [u, n) <- tails[j * (n - u) ..]: the advice columns of a phase with their
+// blinding rows, one launch for up to ADVICE_FILL_MAX columns
+constexpr uint32_t ADVICE_FILL_MAX = 32;
+struct AdviceFillArgs {
+  const Fr* src[ADVICE_FILL_MAX];
+  Fr* dst[ADVICE_FILL_MAX];
+  uint32_t count;
+};
+int poly_advice_fill(cq_ctx* c, const AdviceFillArgs& a, const Fr* tails_dev, uint32_t n, uint32_t u);
+// out[i] = *src[i] (device scalars scattered over polynomials -> one contiguous run the host reads with one copy)
+constexpr uint32_t GATHER_MAX = 64;
+struct GatherArgs {
+  const Fr* src[GATHER_MAX];
+  uint32_t count;
+};
+int poly_gather_scalars(cq_ctx* c, const GatherArgs& a, Fr* out_dev);
 
 }  // namespace cq
 

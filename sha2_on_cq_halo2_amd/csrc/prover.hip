@@ -311,6 +311,7 @@ struct Buffers {
   Fr *adv, *inst_lag, *inst_coeff, *f_lag, *f_coeff, *bpoly, *random_poly, *z, *mv, *cosets, *adv_cosets, *inst_cosets,
       *z_cosets, *lk_inputs, *plk, *plk_cosets, *h_ext, *h_coeff, *gwc_batch, *gwc_wit, *shplonk, *t_comp, *den, *a_val, *m_fr, *a_scaled;
   Fr* challenges;  // user challenges (Expression::Challenge), uploaded as the phases complete
+  Fr *tails, *gather;  // blinding rows of a phase's advice columns (staging); scalars on their way to the host
   uint64_t* rng_dev;
   uint32_t *m_counts, *err_dev;
 };
@@ -366,6 +367,8 @@ void carve(const cq_pk* pk, Arena& ar, Buffers& b) {
   b.m_fr = ar.take(L * N);
   b.a_scaled = ar.take(wsum * N);
   b.challenges = ar.take(pk->challenge_phase.size() + 8);
+  b.tails = ar.take(A * (pk->bf + 1) + 8);
+  b.gather = ar.take(GATHER_MAX);
   b.rng_dev = (uint64_t*)ar.take(2 * n);  // 64 B per element = 2 Fr
   b.m_counts = (uint32_t*)ar.take(L * N / 8 + 64);
   b.err_dev = b.m_counts ? b.m_counts + L * N : nullptr;
@@ -498,7 +501,7 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, const uint64_
      *h_ext = B.h_ext, *h_coeff = B.h_coeff, *t_comp = B.t_comp, *den = B.den, *a_val = B.a_val, *m_fr = B.m_fr,
      *a_scaled = B.a_scaled;
   uint64_t* rng_dev = B.rng_dev;
-  uint32_t *m_counts = B.m_counts, *err_dev = B.err_dev;
+  uint32_t* m_counts = B.m_counts;
 
   // side stream: drain whatever an aborted proof may have left there; its NTTs must find their twiddle tables built
   CQ_TRY(c->ensure_aux_stream());
@@ -590,6 +593,75 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, const uint64_
     CQ_HIP(c, hipStreamWaitEvent(s, c->copy_done, 0));
     return poly_from_u512(c, rng_dev, (uint32_t)n, random_poly);
   };
+  // ---- CQ round 1, the part that does not depend on theta (static_lookup/prover.rs:91-107, 122-160): the lookup
+  //      inputs on the Lagrange basis and the multiplicities m.  With a single phase and no user challenge the witness
+  //      alone determines them, so they are computed right after the advice columns are in place and [m] is committed
+  //      in the advice launch -- the round then has no launch of its own (unless it has legacy lookups or an f that is
+  //      not a linear combination of advice columns).  The points are WRITTEN where the reference writes them.
+  uint32_t *m_counts_ = B.m_counts, *err_dev_ = B.err_dev;
+  std::vector<std::array<const Fr*, CQ_MAX_WIDTH>> lk_input(L);
+  void* small_v;
+  CQ_TRY(c->ensure_pinned_small(&small_v));
+  volatile uint32_t* herr = (volatile uint32_t*)small_v;             // lookup error flag
+  Fr* small_fr = (Fr*)((char*)small_v + 64);                         // scalars read back (b(0), z values)
+  auto count_multiplicities = [&]() -> int {
+    if (!L) return CQ_OK;
+    CQ_HIP(c, hipMemsetAsync(m_counts_, 0, (L * N + 16) * sizeof(uint32_t), s));
+    size_t input_slot = 0;
+    CqRound1Batch r1b;
+    r1b.count = 0;
+    for (size_t l = 0; l < L; l++) {
+      const cq_lookup_desc& lk = pk->lookups[l];
+      const uint32_t w = (uint32_t)lk.cols.size();
+      // input expressions on the Lagrange basis: `evaluate(expr, n, 1, fixed, advice, instance)` (:91-107)
+      for (uint32_t j = 0; j < w; j++, input_slot++) {
+        if (lk.prog[j] < 0) {
+          lk_input[l][j] = B.adv + (size_t)lk.cols[j] * n;
+          continue;
+        }
+        GateEvalArgs ga;
+        ga.prog = pk->lookup_prog + lk.prog[j];
+        ga.num_polys = 1;
+        ga.constants = pk->constants;
+        ga.challenges = B.challenges;
+        ga.advice = B.adv;
+        ga.fixed = pk->fixed_values;
+        ga.instance = B.inst_lag;
+        ga.stride = n;
+        ga.size = (uint32_t)n;
+        ga.rot_scale = 1;
+        ga.y = Fr::zero();
+        Fr* dst = B.lk_inputs + input_slot * n;
+        CQ_TRY(gate_eval(c, ga, dst));
+        lk_input[l][j] = dst;
+      }
+      CqRound1Args& ra = r1b.a[r1b.count];
+      ra.width = w;
+      for (uint32_t j = 0; j < w; j++) {
+        ra.cols[j] = lk_input[l][j];
+        ra.values[j] = lk.tables[j]->values;
+        ra.slots[j] = lk.tables[j]->slots;
+        ra.nslots[j] = lk.tables[j]->nslots;
+      }
+      r1b.m_counts[r1b.count++] = m_counts_ + l * N;
+      if (r1b.count == CQ_ROUND1_BATCH || l + 1 == L) {  // the lookups of a proof share launches
+        CQ_TRY(cq_round1(c, r1b, u, err_dev_));
+        r1b.count = 0;
+      }
+    }
+    CQ_TRY(cq_m_to_fr(c, m_counts_, (uint32_t)(L * N), B.m_fr));  // the L vectors are adjacent
+    *herr = 0;
+    CQ_HIP(c, hipMemcpyAsync((void*)herr, err_dev_, 4, hipMemcpyDeviceToHost, s));  // read after the next synchronisation
+    return CQ_OK;
+  };
+  auto lookup_error = [&]() -> int {
+    if (*herr == 1) return c->fail(CQ_ERR_LOOKUP, "witness value not in table");
+    if (*herr == 2) return c->fail(CQ_ERR_LOOKUP, "Vector lookup must be on the same table row");
+    return CQ_OK;
+  };
+  const bool early_m = L > 0 && pk->num_phases == 1 && pk->challenge_phase.empty();
+  std::vector<G1Affine> m_commitments(L, G1Affine::identity());
+
   // ---- advice, phase by phase (`next_phase`, prover.rs:299-391; the synthesis loop :436-463): copy the phase's
   //      columns in, blind rows u..n (:346-350), one unused blind per column (:352-355), commit, squeeze the phase's
   //      challenges ----------------------------------------------------------------------------------------------
@@ -610,26 +682,39 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, const uint64_
       if (!phase_fn || phase_fn(phase_user, phase, ch.data(), (uint64_t* const*)advice_dev) != 0)
         return c->fail(CQ_ERR_ARG, "create_proof: the phase callback failed");
     }
-    for (size_t a : cols)
-      CQ_HIP(c, hipMemcpyAsync(adv + a * n, advice_dev[a], (size_t)u * sizeof(Fr), hipMemcpyDeviceToDevice, s));
     const size_t AC = cols.size();
     std::vector<Fr> tails(AC * (n - u));
     for (size_t j = 0; j < AC; j++)
       for (size_t r = 0; r < n - u; r++) tails[j * (n - u) + r] = rng.fr();
     for (size_t j = 0; j < AC; j++) (void)rng.fr();
+    // pinned staging: [0, 64 n) the random polynomial's words (filled by the helper thread from the last phase on),
+    // behind it this phase's blinding rows -- no part is reused within a proof, so nothing waits for a copy to finish
     void* pin;
-    CQ_TRY(c->ensure_pinned(std::max(tails.size() * sizeof(Fr), (size_t)64 * n), &pin));
-    memcpy(pin, tails.data(), tails.size() * sizeof(Fr));
-    for (size_t j = 0; j < AC; j++)
-      CQ_HIP(c, hipMemcpyAsync(adv + cols[j] * n + u, (Fr*)pin + j * (n - u), (n - u) * sizeof(Fr), hipMemcpyHostToDevice, s));
-    CQ_HIP(c, hipStreamSynchronize(s));  // pinned buffer is reused below
+    CQ_TRY(c->ensure_pinned((size_t)64 * n + A * (n - u) * sizeof(Fr) + 64, &pin));
+    Fr* pin_tails = (Fr*)((char*)pin + (size_t)64 * n);
+    if (phase > 0) CQ_HIP(c, hipStreamSynchronize(s));  // the previous phase's upload out of the same bytes has been consumed
+    memcpy(pin_tails, tails.data(), tails.size() * sizeof(Fr));
+    if (AC) CQ_HIP(c, hipMemcpyAsync(B.tails, pin_tails, tails.size() * sizeof(Fr), hipMemcpyHostToDevice, s));
+    for (size_t off = 0; off < AC; off += ADVICE_FILL_MAX) {  // rows [0, u) from the caller's columns, [u, n) the blinding rows
+      AdviceFillArgs fa;
+      fa.count = (uint32_t)std::min<size_t>(ADVICE_FILL_MAX, AC - off);
+      for (uint32_t j = 0; j < fa.count; j++) {
+        fa.src[j] = (const Fr*)advice_dev[cols[off + j]];
+        fa.dst[j] = adv + cols[off + j] * n;
+      }
+      CQ_TRY(poly_advice_fill(c, fa, B.tails + off * (n - u), (uint32_t)n, u));
+    }
     // commit_lagrange per column (:356-360): enqueue now, collect after the host work below
     std::vector<const Fr*> sc(AC);
     std::vector<const G1Affine*> bs(AC, pk->params->g_lagrange);
     std::vector<size_t> ln(AC, n);
     for (size_t j = 0; j < AC; j++) sc[j] = adv + cols[j] * n;
+    if (early_m) {  // m_cm (:167-172, as a dense MSM over the table SRS) rides along
+      CQ_TRY(count_multiplicities());
+      for (size_t l = 0; l < L; l++) { sc.push_back(B.m_fr + l * N); bs.push_back(pk->table_cfg->g1_lagrange); ln.push_back(N); }
+    }
     Commit adv_cm;
-    if (AC) CQ_TRY(adv_cm.begin(pk, sc, bs, ln));
+    if (!sc.empty()) CQ_TRY(adv_cm.begin(pk, sc, bs, ln));
     if (last_phase) {
     // The next draws from the RNG are, per permutation set, `bf` blinding rows of z and one blind
     // (permutation/prover.rs:169-175), then the vanishing argument's n coefficients + 1 blind
@@ -656,12 +741,15 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, const uint64_
     drawer.start(c, &rng, (uint64_t*)pin, rng_dev, 8 * n);
     }
     // batch_normalize (:363-366), write (:370-374)
-    if (AC) {
+    if (!sc.empty()) {
       std::vector<G1Affine> pts;
       CQ_TRY(adv_cm.end(pts));
-      for (auto& p : pts)
-        if (!tr.write_point(p)) return c->fail(CQ_ERR_TRANSCRIPT, "advice commitment is the identity");
+      if (early_m) CQ_TRY(lookup_error());
+      for (size_t j = 0; j < AC; j++)
+        if (!tr.write_point(pts[j])) return c->fail(CQ_ERR_TRANSCRIPT, "advice commitment is the identity");
       for (size_t j = 0; j < AC; j++) advice_commitments[cols[j]] = pts[j];
+      if (early_m)
+        for (size_t l = 0; l < L; l++) m_commitments[l] = pts[AC + l];
     } else {
       CQ_HIP(c, hipStreamSynchronize(s));
     }
@@ -716,73 +804,29 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, const uint64_
 
   // ---- CQ round 1 (static_lookup/prover.rs:51-183) ------------------------------------------------
   bool adv_is_coeff = false;
-  if (L) CQ_HIP(c, hipMemsetAsync(m_counts, 0, (L * N + 16) * sizeof(uint32_t), s));
-  size_t input_slot = 0;
-  CqRound1Batch r1b;
-  r1b.count = 0;
+  if (L && !early_m) {
+    CQ_TRY(count_multiplicities());
+    CQ_HIP(c, hipStreamSynchronize(s));
+    CQ_TRY(lookup_error());
+  }
   for (size_t l = 0; l < L; l++) {
-    const cq_lookup_desc& lk = pk->lookups[l];
-    const uint32_t w = (uint32_t)lk.cols.size();
-    // input expressions on the Lagrange basis: `evaluate(expr, n, 1, fixed, advice, instance)` (:91-107)
-    const Fr* input[CQ_MAX_WIDTH];
-    for (uint32_t j = 0; j < w; j++, input_slot++) {
-      if (lk.prog[j] < 0) {
-        input[j] = adv + (size_t)lk.cols[j] * n;
-        continue;
-      }
-      GateEvalArgs ga;
-      ga.prog = pk->lookup_prog + lk.prog[j];
-      ga.num_polys = 1;
-      ga.constants = pk->constants;
-      ga.challenges = B.challenges;
-      ga.advice = adv;
-      ga.fixed = pk->fixed_values;
-      ga.instance = B.inst_lag;
-      ga.stride = n;
-      ga.size = (uint32_t)n;
-      ga.rot_scale = 1;
-      ga.y = Fr::zero();
-      Fr* dst = B.lk_inputs + input_slot * n;
-      CQ_TRY(gate_eval(c, ga, dst));
-      input[j] = dst;
-    }
     // f = sum_j theta^(w-1-j) * e_j   (:108-116, Horner with the first expression first)
+    const uint32_t w = (uint32_t)pk->lookups[l].cols.size();
     LincombArgs la;
     la.count = w;
     la.sub_const = Fr::zero();
     Fr p = Fr::one();
     for (int j = (int)w - 1; j >= 0; j--) {
-      la.p[j] = input[j];
+      la.p[j] = lk_input[l][j];
       la.len[j] = (uint32_t)n;
       la.coeff[j] = p;
       p = p * theta;
     }
     CQ_TRY(poly_lincomb(c, la, (uint32_t)n, f_lag + l * n));
-    CqRound1Args& ra = r1b.a[r1b.count];
-    ra.width = w;
-    for (uint32_t j = 0; j < w; j++) {
-      ra.cols[j] = input[j];
-      ra.values[j] = lk.tables[j]->values;
-      ra.slots[j] = lk.tables[j]->slots;
-      ra.nslots[j] = lk.tables[j]->nslots;
-    }
-    r1b.m_counts[r1b.count++] = m_counts + l * N;
-    if (r1b.count == CQ_ROUND1_BATCH || l + 1 == L) {  // the lookups of a proof share launches
-      CQ_TRY(cq_round1(c, r1b, u, err_dev));
-      r1b.count = 0;
-    }
-  }
-  if (L) {
-    CQ_TRY(cq_m_to_fr(c, m_counts, (uint32_t)(L * N), m_fr));  // the L vectors are adjacent
-    uint32_t herr = 0;
-    CQ_HIP(c, hipMemcpyAsync(&herr, err_dev, 4, hipMemcpyDeviceToHost, s));
-    CQ_HIP(c, hipStreamSynchronize(s));
-    if (herr == 1) return c->fail(CQ_ERR_LOOKUP, "witness value not in table");
-    if (herr == 2) return c->fail(CQ_ERR_LOOKUP, "Vector lookup must be on the same table row");
   }
   if (L || PL) {
-    // permuted input / table of every legacy lookup (lookup/prover.rs:136-151), then f_cm (:165) and m_cm
-    // (:167-172, as a dense MSM over the table SRS): one launch
+    // permuted input / table of every legacy lookup (lookup/prover.rs:136-151), then f_cm (:165) and, unless it went
+    // out with the advice launch, m_cm (:167-172): one launch
     std::vector<const Fr*> sc;
     std::vector<const G1Affine*> bs;
     std::vector<size_t> ln;
@@ -790,45 +834,42 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, const uint64_
       for (int which = 2; which <= 3; which++) { sc.push_back(plk_buf(l, which)); bs.push_back(pk->params->g_lagrange); ln.push_back(n); }
     // f_cm: when every input of a lookup is a plain advice column, f = sum_j theta^(w-1-j) e_j over whole columns
     // (blinding rows included), so [f] = sum_j theta^(w-1-j) [e_j] -- w - 1 scalar multiplications of commitments
-    // round 0 already produced, done by host threads while the GPU commits m, instead of an n-term MSM.
+    // round 0 already produced, done by host threads, instead of an n-term MSM.
     std::vector<int> f_linear(L, 0);
     std::vector<G1Jac> f_host(L);
     for (size_t l = 0; l < L; l++) {
       f_linear[l] = 1;
-      for (int pj : pk->lookups[l].prog) f_linear[l] &= pj < 0;
+      for (int64_t pj : pk->lookups[l].prog) f_linear[l] &= pj < 0;
     }
     std::vector<size_t> f_slot(L, 0);
     for (size_t l = 0; l < L; l++)
       if (!f_linear[l]) { f_slot[l] = sc.size(); sc.push_back(f_lag + l * n); bs.push_back(pk->params->g_lagrange); ln.push_back(n); }
     const size_t m_first = sc.size();
-    for (size_t l = 0; l < L; l++) { sc.push_back(m_fr + l * N); bs.push_back(pk->table_cfg->g1_lagrange); ln.push_back(N); }
+    if (!early_m)
+      for (size_t l = 0; l < L; l++) { sc.push_back(m_fr + l * N); bs.push_back(pk->table_cfg->g1_lagrange); ln.push_back(N); }
     std::vector<G1Affine> cm;
     Commit r1;
     const uint64_t seq = c->msm_tail_seq;
-    CQ_TRY(r1.begin(pk, sc, bs, ln));
-    struct Joiner {
-      std::vector<std::thread> th;
-      ~Joiner() {
-        for (auto& t : th) t.join();
-      }
-    } f_threads;
-    for (size_t l = 0; l < L; l++) {
-      if (!f_linear[l]) continue;
-      auto work = [&, l]() {
-        const auto& lcols = pk->lookups[l].cols;
-        G1Jac acc = jac_from_affine(advice_commitments[lcols[0]]);
-        for (size_t j = 1; j < lcols.size(); j++) acc = jac_add(host_scalar_mul(acc, theta), jac_from_affine(advice_commitments[lcols[j]]));
-        f_host[l] = acc;
-      };
-      try {
-        f_threads.th.emplace_back(work);
-      } catch (...) {
-        work();
-      }
-    }
+    if (!sc.empty()) CQ_TRY(r1.begin(pk, sc, bs, ln));
+    // (on the context's worker threads: the main thread goes on queueing the work that needs theta only)
+    std::vector<size_t> f_lin;
+    for (size_t l = 0; l < L; l++)
+      if (f_linear[l]) f_lin.push_back(l);
+    struct PoolJoin {  // an error path must not leave workers with references into this frame
+      HostPool& pool;
+      HostPool::Ticket t;
+      ~PoolJoin() { pool.wait(t); }
+    } f_job{c->pool(), nullptr};
+    f_job.t = c->pool().submit(f_lin.size(), [&](size_t i) {
+      const size_t l = f_lin[i];
+      const auto& lcols = pk->lookups[l].cols;
+      G1Jac acc = jac_from_affine(advice_commitments[lcols[0]]);
+      for (size_t j = 1; j < lcols.size(); j++) acc = jac_add(host_scalar_mul(acc, theta), jac_from_affine(advice_commitments[lcols[j]]));
+      f_host[l] = acc;
+    });
     {
-      // under the launch's tail: f -> coefficients (:326-334) and onto the extended coset (evaluation.rs:533-548 reads
-      // it), the instance cosets -- none of them depends on beta / gamma
+      // on the side stream (under the launch's tail when there is one): f -> coefficients (:326-334) and onto the
+      // extended coset (evaluation.rs:533-548 reads it), the instance cosets -- none of them depends on beta / gamma
       AuxFork fork(c);
       CQ_TRY(fork.begin(seq));
       if (L) {
@@ -844,15 +885,14 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, const uint64_
       }
       CQ_TRY(fork.end());
     }
-    CQ_TRY(r1.end(cm));
-    for (auto& t : f_threads.th) t.join();
-    f_threads.th.clear();
+    if (!sc.empty()) CQ_TRY(r1.end(cm));
+    c->pool().wait(f_job.t);
     for (size_t q = 0; q < 2 * PL; q++)
       if (!tr.write_point(cm[q])) return c->fail(CQ_ERR_TRANSCRIPT, "permuted lookup commitment is the identity");
     for (size_t l = 0; l < L; l++) {
       const G1Affine f_cm = f_linear[l] ? jac_to_affine(f_host[l]) : cm[f_slot[l]];
       if (!tr.write_point(f_cm)) return c->fail(CQ_ERR_TRANSCRIPT, "f commitment is the identity");
-      if (!tr.write_point(cm[m_first + l])) return c->fail(CQ_ERR_TRANSCRIPT, "m commitment is the identity");
+      if (!tr.write_point(early_m ? m_commitments[l] : cm[m_first + l])) return c->fail(CQ_ERR_TRANSCRIPT, "m commitment is the identity");
     }
   }
   const Fr beta = tr.squeeze();   // prover.rs:529
@@ -959,7 +999,15 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, const uint64_
       CQ_TRY(cq_a_values(c, den + l * N, m_counts + l * N, (uint32_t)N, tp, a_val + l * N, a_scaled + woff * N));
       woff += w;
     }
-    if (L) CQ_TRY(domain_lagrange_to_coeff(dom, bpoly, bpoly, (uint32_t)L, n, n));  // f: under round 1's launch
+    if (L) {
+      CQ_TRY(domain_lagrange_to_coeff(dom, bpoly, bpoly, (uint32_t)L, n, n));  // f: under round 1's launch
+      // b(0) of every lookup (for a(0), :318-324): on its way to the host while the round's MSMs run
+      GatherArgs ga;
+      ga.count = (uint32_t)L;
+      for (size_t l = 0; l < L; l++) ga.src[l] = bpoly + l * n;
+      CQ_TRY(poly_gather_scalars(c, ga, B.gather));
+      CQ_HIP(c, hipMemcpyAsync(small_fr, B.gather, L * sizeof(Fr), hipMemcpyDeviceToHost, s));
+    }
     // The helper thread has had rounds 0 and 1 and this round's preparation to draw the random polynomial.  From
     // k = 20 on that is not enough (2^25 words take ~25 ms at k = 22): then the polynomial is committed in a launch
     // of its own after the round's other MSMs, which start now.
@@ -1039,14 +1087,10 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, const uint64_
     }
     random_cm = r2[S + PL + 5 * L];
     // a(0) = (n*b(0) - (bf+1)/beta) / N   (:318-324)
-    if (L) {
-      std::vector<Fr> b0(L);
-      for (size_t l = 0; l < L; l++)
-        CQ_HIP(c, hipMemcpyAsync(&b0[l], bpoly + l * n, sizeof(Fr), hipMemcpyDeviceToHost, s));
-      CQ_HIP(c, hipStreamSynchronize(s));
+    if (L) {  // the copy of b(0) was queued before the launch; r2cm.end() has drained the stream
       const Fr n_table_inv = Fr::from_u64(N).inv();
       for (size_t l = 0; l < L; l++)
-        a_at_zero[l] = (b0[l] * Fr::from_u64(n) - Fr::from_u64(bf + 1) * beta_inv) * n_table_inv;
+        a_at_zero[l] = (small_fr[l] * Fr::from_u64(n) - Fr::from_u64(bf + 1) * beta_inv) * n_table_inv;
     }
   }
 
