@@ -622,7 +622,7 @@ __global__ __launch_bounds__(256) void msm_combine_level_kernel(
 #pragma unroll 1
   for (int delta = top; delta >= 1; delta >>= 1) {  // lanes >= hi - lo hold the identity: the tree starts where the data ends
     XYZZ29 o = xyzz29_shfl_down(acc, delta);
-    xyzz29_add(acc, o);
+    if ((int)lane < delta) xyzz29_add(acc, o);  // (the other lanes would add a point to itself: the doubling path)
   }
   if (lane == 0) store_xyzz29(t_cur[g] == 1 ? buckets + g : partial + j, acc);
 }
@@ -677,15 +677,6 @@ int msm_precompute_tables(cq_ctx* ctx, const G1Affine* bases, uint32_t n, uint32
 // independent.  Kernel 2: per bucket set two waves, one per weighted sum of <= 128 terms
 // (pair sums, suffix scan by shuffles, one tree); the host applies "cols *" and joins the two.  ~11 + ~16 dependent
 // operations instead of the ~46 of a lane-serial running sum over 1024-bucket groups.
-static __device__ __forceinline__ XYZZ29 wave_sum(XYZZ29 v) {
-#pragma unroll 1
-  for (int delta = 32; delta >= 1; delta >>= 1) {
-    XYZZ29 o = xyzz29_shfl_down(v, delta);
-    xyzz29_add(v, o);
-  }
-  return v;  // lane 0 holds the sum
-}
-
 // A wave serves 64 / SEG rows (or columns): SEG lanes per line, each summing cols / SEG consecutive buckets of it
 // serially, then a log2(SEG)-level shuffle tree.  SEG = 16 (depth 8 + 4, every lane busy in the serial part) when a
 // launch has many bucket sets -- with one wave per line and a 6-level tree only a quarter of the lane-operations were
@@ -720,28 +711,30 @@ __global__ __launch_bounds__(64) void msm_rowcol_kernel(const XYZZ* __restrict__
 // lone wave as much as an addition, so the "2^t" may not run here either).  The kernel stops at the S_t: the Horner
 // over t, the plain total of the "+ first_weight" term, the log2(cols) doublings and the last additions are ~33 group
 // operations per bucket set for the host (msm_set_value), which needs a fraction of a microsecond for each where a
-// lone wave needs ~10 us.  One block per (bucket set, row / column side), eight waves: wave t < 7 -> S_t, wave 7 (column
-// side) -> the total.  out[set][0..6] = row planes, [7..13] = column planes, [14] = column total (MSM_SET_POINTS).
-__global__ __launch_bounds__(512) void msm_weighted_kernel(const XYZZ* __restrict__ sums, uint32_t rows, uint32_t cols,
-                                                           G1Jac* __restrict__ out) {
-  const uint32_t set = blockIdx.x >> 1, which = blockIdx.x & 1;
-  const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+// lone wave needs ~10 us.  out[set][0..6] = row planes, [7..13] = column planes, [14] = column total (MSM_SET_POINTS).
+// One WAVE per block (and so, with a few dozen blocks on 256 CUs, per SIMD): two waves of such a chain on one SIMD share
+// its issue slots and each runs at half speed -- eight-wave blocks made this kernel take 150-220 us for six levels.
+__global__ __launch_bounds__(64) void msm_weighted_kernel(const XYZZ* __restrict__ sums, uint32_t rows, uint32_t cols,
+                                                          G1Jac* __restrict__ out) {
+  const uint32_t set = blockIdx.x / MSM_SET_POINTS, plane = blockIdx.x % MSM_SET_POINTS, lane = threadIdx.x;
+  const uint32_t which = plane >= 7 ? 1u : 0u;
   const XYZZ* X = sums + (size_t)set * (rows + cols) + (which ? rows : 0);
   const uint32_t count = which ? cols : rows;
-  G1Jac* o = out + (size_t)set * MSM_SET_POINTS;
   XYZZ29 v = XYZZ29::identity();
-  if (wave < 7) {
-    const uint32_t t = wave;
+  if (plane < 14) {
+    const uint32_t t = plane - 7 * which;
     const uint32_t j = ((lane >> t) << (t + 1)) | (1u << t) | (lane & ((1u << t) - 1u));  // lane-th index with bit t set
     if (j < count) v = load_xyzz29(X + j);
-    v = wave_sum(v);
-    if (lane == 0) o[7 * which + t] = xyzz29_to_jac(v);
-  } else if (which) {
+  } else {
     if (lane < count) v = load_xyzz29(X + lane);
     if (lane + 64 < count) xyzz29_add(v, load_xyzz29(X + lane + 64));
-    v = wave_sum(v);
-    if (lane == 0) o[14] = xyzz29_to_jac(v);
   }
+#pragma unroll 1
+  for (int delta = 32; delta >= 1; delta >>= 1) {
+    XYZZ29 o = xyzz29_shfl_down(v, delta);
+    if ((int)lane < delta) xyzz29_add(v, o);  // the lanes that still matter (the others would add a point to itself: the doubling path)
+  }
+  if (lane == 0) out[(size_t)set * MSM_SET_POINTS + plane] = xyzz29_to_jac(v);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -921,7 +914,7 @@ int msm_run(cq_ctx* ctx, const Fr* const* scalars_host_ptrs, const G1Affine* con
     msm_rowcol_kernel<32><<<dim3((L.rows + L.cols + 1) / 2, sets), 64, 0, s>>>(buckets, M, L.rows, L.cols, pairs);
   else
     msm_rowcol_kernel<16><<<dim3((L.rows + L.cols + 3) / 4, sets), 64, 0, s>>>(buckets, M, L.rows, L.cols, pairs);
-  msm_weighted_kernel<<<2 * sets, 512, 0, s>>>(pairs, L.rows, L.cols, window_sums_dev);
+  msm_weighted_kernel<<<MSM_SET_POINTS * sets, 64, 0, s>>>(pairs, L.rows, L.cols, window_sums_dev);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

@@ -109,6 +109,7 @@ struct Rng {
   cq_rng_next_u64 next;
   void* state;
   cq_rng_fill_fn bulk = nullptr;  // the caller's own bulk form (cq_pk_set_rng_fill)
+  HostPool* pool = nullptr;       // the context's worker threads
   // Fr::random (bn256/fr.rs:159-170): eight next_u64, low limb first
   void words(uint64_t* w8) {
     for (int i = 0; i < 8; i++) w8[i] = next(state);
@@ -124,7 +125,7 @@ struct Rng {
     if (bulk) {
       bulk(state, dst, count);
     } else if (next == cq_xoshiro256ss_next_u64) {
-      xoshiro_fill((uint64_t*)state, dst, count, 8);  // several threads for long runs, the same stream (xoshiro.hpp)
+      xoshiro_fill((uint64_t*)state, dst, count, 8, pool);  // several threads for long runs, the same stream (xoshiro.hpp)
     } else if (next == cq_buffer_rng_next_u64) {
       cq_buffer_rng* b = (cq_buffer_rng*)state;
       const size_t avail = b->pos < b->len ? b->len - b->pos : 0, take = std::min(avail, count);
@@ -488,7 +489,7 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, const uint64_
   const bool general = pk->general();
   const size_t PL = pk->legacy.size();
   hipStream_t s = c->stream;
-  Rng rng{rng_next, rng_state, pk->rng_fill};
+  Rng rng{rng_next, rng_state, pk->rng_fill, &c->pool()};
   Transcript tr;
 
   // ---- carve the arena --------------------------------------------------------------------------
@@ -553,7 +554,7 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, const uint64_
       return d ? el * (double)(chunks_total - d + 1) / d : 1e9;  // +1: the last upload's event
     }
     void start(cq_ctx* c, Rng* rng, uint64_t* pin, uint64_t* dev, size_t words) {
-      const size_t chunk = std::max<size_t>(words / 16, (size_t)1 << 16);
+      const size_t chunk = std::max<size_t>(words / 4, (size_t)1 << 18);  // each drawn by up to eight threads, uploaded while the next is drawn
       chunks_total = (uint32_t)((words + chunk - 1) / chunk);
       t_start = std::chrono::steady_clock::now();
       auto work = [=]() {

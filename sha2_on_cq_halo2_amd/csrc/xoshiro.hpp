@@ -10,6 +10,7 @@
 #include <mutex>
 #include <thread>
 #include <vector>
+#include "hostpool.hpp"
 
 namespace cq {
 
@@ -93,9 +94,10 @@ struct XoshiroJump {
   }
 };
 
-// the same words and the same final state as xoshiro_fill_serial, produced by up to `threads` threads
-static inline void xoshiro_fill(uint64_t* st, uint64_t* dst, size_t count, unsigned threads) {
-  const size_t MIN_PER_THREAD = (size_t)1 << 16;
+// the same words and the same final state as xoshiro_fill_serial, produced by up to `threads` threads: the context's
+// parked workers when `pool` is given (no thread is created: ~30 us each, more than a part's work), fresh ones otherwise
+static inline void xoshiro_fill(uint64_t* st, uint64_t* dst, size_t count, unsigned threads, HostPool* pool = nullptr) {
+  const size_t MIN_PER_THREAD = (size_t)1 << 15;
   if (threads > count / MIN_PER_THREAD) threads = (unsigned)(count / MIN_PER_THREAD);
   if (threads <= 1) {
     xoshiro_fill_serial(st, dst, count);
@@ -108,16 +110,23 @@ static inline void xoshiro_fill(uint64_t* st, uint64_t* dst, size_t count, unsig
     start[t] = start[t - 1];
     XoshiroJump::jump(start[t].s, per);
   }
-  std::vector<std::thread> th;
-  for (unsigned t = 0; t < threads; t++) {
+  auto part = [&start, dst, per, count, threads](size_t t) {
     const size_t off = t * per, cnt = (t + 1 == threads) ? count - off : per;
-    try {
-      th.emplace_back([&start, dst, t, off, cnt]() { xoshiro_fill_serial(start[t].s, dst + off, cnt); });
-    } catch (...) {  // no thread to be had: this part on the calling thread
-      xoshiro_fill_serial(start[t].s, dst + off, cnt);
+    xoshiro_fill_serial(start[t].s, dst + off, cnt);
+  };
+  if (pool) {
+    pool->parallel_for(threads, part);
+  } else {
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < threads; t++) {
+      try {
+        th.emplace_back(part, (size_t)t);
+      } catch (...) {  // no thread to be had: this part on the calling thread
+        part(t);
+      }
     }
+    for (auto& x : th) x.join();
   }
-  for (auto& x : th) x.join();
   for (int w = 0; w < 4; w++) st[w] = start[threads - 1].s[w];  // the last part ends where the whole run ends
 }
 
