@@ -397,42 +397,40 @@ def generic_rng(wl, steps):
     return res
 
 
-def _cpu_prove(ctx, k, threads):
-    """(cpu seconds, gpu seconds, proofs identical, workload) for one create_proof of the bench circuit at 2^k rows."""
-    from oracle import cbind as OC
-    from sha2_on_cq_halo2_amd.api import fr_to_mont
-    from sha2_on_cq_halo2_amd.sha_circuit import ShaCqWorkload, small_to_mont, spread16
-
-    n = 1 << k
-    wl = ShaCqWorkload(ctx, k, seed=0x5348413243515F)
-    wl.prove(seed=77)
-    t0 = time.perf_counter()
-    gpu_proof = wl.prove(seed=77)
-    gpu_s = time.perf_counter() - t0
-    g, gl = wl.params.download()
-    tl, t0pts = wl.cfg.download()
-    N = wl.cfg.size
-    idx = np.arange(N)
-    tvals = [small_to_mont(idx), small_to_mont(spread16(idx))]
-    tqs = [wl.dense.download_qs(), wl.spread.download_qs()]
-    advice = [c.download((n, 4)) for c in wl.cols]
-    lookups = [[(2 * p, 0), (2 * p + 1, 1)] for p in range(wl.pairs)]
-    la = OC.keygen_l_active(k, 5)
-    OC.lib().cqo_set_num_threads(threads)
-    t0 = time.perf_counter()
-    cpu_proof = OC.create_proof(k, 2 * wl.pairs, lookups, tvals, tqs, g, gl, tl, t0pts, g[1:], la, fr_to_mont(0xC0FFEE + k),
-                                advice, 77)
-    cpu_s = time.perf_counter() - t0
-    res = (cpu_s, gpu_s, cpu_proof == gpu_proof, wl.blocks, wl.msm_scalars_per_proof())
-    wl.close()
-    return res
-
-
 def cpu_baseline(ctx):
     """CPU leg (rank 0, N=1): the plain-C restatement of the reference's create_proof (oracle/, kind 'port') proving
     the metric's own k = 18 instance once, and the k = 16 instance (BASELINE configs[1]) as `sample_small`; the GPU
     proves the same instances and the proofs are compared byte for byte."""
     from oracle import cbind as OC
+
+    def _cpu_prove(ctx, k, threads):
+        """(cpu seconds, gpu seconds, proofs identical, workload) for one create_proof of the bench circuit at 2^k rows."""
+        from sha2_on_cq_halo2_amd.api import fr_to_mont
+        from sha2_on_cq_halo2_amd.sha_circuit import ShaCqWorkload, small_to_mont, spread16
+
+        n = 1 << k
+        wl = ShaCqWorkload(ctx, k, seed=0x5348413243515F)
+        wl.prove(seed=77)
+        t0 = time.perf_counter()
+        gpu_proof = wl.prove(seed=77)
+        gpu_s = time.perf_counter() - t0
+        g, gl = wl.params.download()
+        tl, t0pts = wl.cfg.download()
+        N = wl.cfg.size
+        idx = np.arange(N)
+        tvals = [small_to_mont(idx), small_to_mont(spread16(idx))]
+        tqs = [wl.dense.download_qs(), wl.spread.download_qs()]
+        advice = [c.download((n, 4)) for c in wl.cols]
+        lookups = [[(2 * p, 0), (2 * p + 1, 1)] for p in range(wl.pairs)]
+        la = OC.keygen_l_active(k, 5)
+        OC.lib().cqo_set_num_threads(threads)
+        t0 = time.perf_counter()
+        cpu_proof = OC.create_proof(k, 2 * wl.pairs, lookups, tvals, tqs, g, gl, tl, t0pts, g[1:], la, fr_to_mont(0xC0FFEE + k),
+                                    advice, 77)
+        cpu_s = time.perf_counter() - t0
+        res = (cpu_s, gpu_s, cpu_proof == gpu_proof, wl.blocks, wl.msm_scalars_per_proof())
+        wl.close()
+        return res
 
     # a 1-GPU job's CPU share on the GPU box is 16 cores (the box exposes more)
     threads = min(OC.lib().cqo_num_threads(), int(os.environ.get("CQ_CPU_BASELINE_THREADS", "16")))

@@ -55,6 +55,9 @@ typedef void (*cq_rng_fill_fn)(void* state, uint64_t* dst, size_t count);
  * into `recv` (world x bytes_per_rank, rank order).  The host application implements it with RCCL /
  * torch.distributed; returns 0 on success. */
 typedef int (*cq_allgather_fn)(void* user, const void* send, void* recv, size_t bytes_per_rank);
+/* Broadcast hook for column sharding: `buf` (host memory, `bytes` long) holds the payload on rank `root` and receives it
+ * on the others; returns 0 on success. */
+typedef int (*cq_bcast_fn)(void* user, void* buf, size_t bytes, uint32_t root);
 
 /* ---- context ------------------------------------------------------------------------- */
 /* `hip_stream` may be NULL (the library creates its own stream) or an existing hipStream_t
@@ -63,6 +66,19 @@ int cq_ctx_create(int device, void* hip_stream, cq_ctx** out);
 void cq_ctx_destroy(cq_ctx* ctx);
 const char* cq_last_error(const cq_ctx* ctx);
 int cq_ctx_sync(cq_ctx* ctx);
+/* RCCL communicator of the context (one process per GPU, xGMI within a node): rank 0 draws an id with
+ * cq_rccl_unique_id and hands it to the other ranks by whatever means the application has (a torch.distributed
+ * broadcast, MPI, a file); every rank then calls cq_ctx_comm_init_rccl -- collectively, it blocks until all have.  The
+ * library loads librccl at run time (the copy already in the process, e.g. PyTorch's, else ROCm's) and issues its
+ * collectives on the context's stream, on device buffers.  CQ_ERR_NO_DEVICE when librccl cannot be loaded. */
+#define CQ_RCCL_UNIQUE_ID_BYTES 128
+int cq_rccl_unique_id(uint8_t id[CQ_RCCL_UNIQUE_ID_BYTES]);
+int cq_ctx_comm_init_rccl(cq_ctx* ctx, uint32_t rank, uint32_t world, const uint8_t id[CQ_RCCL_UNIQUE_ID_BYTES]);
+int cq_ctx_comm_destroy(cq_ctx* ctx);
+/* Collective self-check of the communicator: an ncclAllGather and a grouped launch of ncclBroadcasts (one root per
+ * rank, unequal lengths) on device buffers with patterns every rank verifies -- the two exchanges the sharded prover
+ * makes.  Every rank calls it. */
+int cq_ctx_comm_selftest(cq_ctx* ctx);
 void* cq_ctx_stream(cq_ctx* ctx);
 const char* cq_version(void);
 
@@ -323,10 +339,20 @@ int cq_pk_read_raw(cq_ctx* ctx, cq_params* params, const cq_circuit* circuit, cq
 size_t cq_pk_raw_size(const cq_pk* pk, uint32_t num_selectors);
 int cq_pk_write_raw(cq_pk* pk, const uint8_t* selector_bits, uint32_t num_selectors, uint8_t* buf, size_t cap, size_t* written);
 /* Shards every commitment of cq_create_proof across `world` ranks by point range: rank r
- * multiplies the slice shard(len, r, world) of each (scalars, bases) pair, the 96-byte Jacobian partials are
- * all-gathered through `fn` and summed locally (EC addition is not an RCCL reduction op), so every rank
- * derives the same transcript.  Every rank must hold the same witness and RNG stream. */
+ * multiplies the slice shard(len, r, world) of each (scalars, bases) pair, the 96-byte Jacobian partials of a round are
+ * all-gathered and summed locally (EC addition is not an RCCL reduction op), so every rank derives the same
+ * transcript.  Every rank must hold the same witness and RNG stream.  `fn` = NULL: the exchange is an ncclAllGather
+ * on the context's RCCL communicator (cq_ctx_comm_init_rccl with the same rank / world); otherwise the caller's
+ * collective on host buffers.  The key's MSM window tables are rebuilt for the rank's slices only (1 / world of the
+ * 17 x SRS); world = 1 restores the unsharded key -- except over a one-rank RCCL communicator (fn = NULL), where the
+ * prover still issues every collective, over the one rank: the path a single-GPU machine can exercise. */
 int cq_pk_set_sharding(cq_pk* pk, uint32_t rank, uint32_t world, cq_allgather_fn fn, void* user);
+/* Column sharding, on by default when sharded and a transport for whole columns exists: the independent
+ * column transforms of a proof (advice / f / b -> coefficients, -> extended coset: plonk/prover.rs:587-603,
+ * evaluation.rs:317-335, static_lookup/prover.rs:271,327) are computed by their owner rank only and broadcast, instead
+ * of by every rank.  Transport: RCCL broadcasts on device buffers (`fn` = NULL, needs the context communicator), or the
+ * caller's broadcast on host buffers.  `on` = 0 replicates the transforms on every rank. */
+int cq_pk_set_column_sharding(cq_pk* pk, int on, cq_bcast_fn fn, void* user);
 /* Multi-open scheme of cq_create_proof*: `P: Prover` of create_proof (prover.rs:55).
  * CQ_OPENER_GWC = ProverGWC (poly/kzg/multiopen/gwc/prover.rs:42-91, one witness commitment per distinct
  * point; the default, as in tests/my_test.rs), CQ_OPENER_SHPLONK = ProverSHPLONK

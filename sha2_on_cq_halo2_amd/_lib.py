@@ -119,6 +119,11 @@ def _declare(lib):  # noqa: F811
     lib.cq_static_table_download_qs.argtypes = [vp, vp]
     lib.cq_pk_create.argtypes = [vp, vp, vp, vp, vp, C.c_int, C.POINTER(vp)]
     lib.cq_pk_set_sharding.argtypes = [vp, C.c_uint32, C.c_uint32, vp, vp]
+    lib.cq_pk_set_column_sharding.argtypes = [vp, C.c_int, vp, vp]
+    lib.cq_rccl_unique_id.argtypes = [vp]
+    lib.cq_ctx_comm_init_rccl.argtypes = [vp, C.c_uint32, C.c_uint32, vp]
+    lib.cq_ctx_comm_destroy.argtypes = [vp]
+    lib.cq_ctx_comm_selftest.argtypes = [vp]
     lib.cq_pk_destroy.restype = None
     lib.cq_pk_destroy.argtypes = [vp]
     lib.cq_pk_usable_rows.restype = C.c_uint32

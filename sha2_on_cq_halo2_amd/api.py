@@ -832,12 +832,68 @@ Context.sha_decomposition_table = _ctx_sha_decomposition_table
 
 
 _ALLGATHER_T = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)
+_BCAST_T = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32)
+RCCL_UNIQUE_ID_BYTES = 128
 
 
-def _pk_set_sharding(self, rank: int, world: int, group=None, device=None):
-    """Shards every commitment of `create_proof` across the ranks of a torch.distributed group
-    (cq_pk_set_sharding): the per-rank Jacobian partials travel through `all_gather` (RCCL with the
-    "nccl" backend when `device` is a cuda device, gloo on CPU tensors otherwise)."""
+def rccl_unique_id() -> bytes:
+    """cq_rccl_unique_id: drawn by ONE rank and handed to the others (e.g. with a torch.distributed broadcast)."""
+    buf = (C.c_uint8 * RCCL_UNIQUE_ID_BYTES)()
+    rc = load().cq_rccl_unique_id(buf)
+    if rc != 0:
+        raise CqError(rc, "cq_rccl_unique_id failed (librccl not loadable?)")
+    return bytes(buf)
+
+
+def _ctx_comm_init_rccl(self, rank: int, world: int, unique_id: bytes):
+    """cq_ctx_comm_init_rccl: the context's RCCL communicator (collective: every rank calls it with the same id)."""
+    assert len(unique_id) == RCCL_UNIQUE_ID_BYTES
+    buf = (C.c_uint8 * RCCL_UNIQUE_ID_BYTES).from_buffer_copy(unique_id)
+    self._chk(self.lib.cq_ctx_comm_init_rccl(self.h, rank, world, buf))
+
+
+def _ctx_comm_init_from_torch(self, device=None, group=None):
+    """Convenience for torch.distributed jobs: rank 0 draws the RCCL id, the process group broadcasts it (a CUDA tensor
+    over the "nccl" backend, a CPU tensor over gloo), every rank initialises the context's communicator."""
+    import torch
+    import torch.distributed as dist
+
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    t = torch.zeros(RCCL_UNIQUE_ID_BYTES, dtype=torch.uint8)
+    if rank == 0:
+        t = torch.frombuffer(bytearray(rccl_unique_id()), dtype=torch.uint8).clone()
+    if device is not None:
+        t = t.to(device)
+    dist.broadcast(t, src=0, group=group)
+    self.comm_init_rccl(rank, world, bytes(t.cpu().numpy().tobytes()))
+
+
+def _ctx_comm_destroy(self):
+    self._chk(self.lib.cq_ctx_comm_destroy(self.h))
+
+
+Context.comm_init_rccl = _ctx_comm_init_rccl
+Context.comm_init_from_torch = _ctx_comm_init_from_torch
+Context.comm_destroy = _ctx_comm_destroy
+Context.comm_selftest = lambda self: self._chk(self.lib.cq_ctx_comm_selftest(self.h))
+
+
+def _pk_set_sharding(self, rank: int, world: int, group=None, device=None, transport: str = "callback", columns: bool = True):
+    """Shards `create_proof` across the ranks of a job (cq_pk_set_sharding + cq_pk_set_column_sharding): every
+    commitment by point range (all-gather of the per-rank Jacobian partials) and, with `columns`, the independent column
+    transforms by owner (broadcast of the transformed columns).
+    transport "rccl": the library's own ncclAllGather / ncclBroadcast on device buffers, on the context's communicator
+    (Context.comm_init_rccl / comm_init_from_torch first); "callback": torch.distributed collectives of `group` on host
+    buffers (gloo on CPU tensors; with `device` the tensors travel through that device for the "nccl" backend)."""
+    if world <= 1:
+        self._allgather_cb = self._bcast_cb = None
+        self.ctx._chk(self.ctx.lib.cq_pk_set_sharding(self.h, 0, 1, None, None))
+        return
+    if transport == "rccl":
+        self._allgather_cb = self._bcast_cb = None
+        self.ctx._chk(self.ctx.lib.cq_pk_set_column_sharding(self.h, 1 if columns else 0, None, None))
+        self.ctx._chk(self.ctx.lib.cq_pk_set_sharding(self.h, rank, world, None, None))
+        return
     import torch
     import torch.distributed as dist
 
@@ -856,9 +912,24 @@ def _pk_set_sharding(self, rank: int, world: int, group=None, device=None):
         except Exception:  # never unwind into C
             return -1
 
-    self._allgather_cb = _ALLGATHER_T(allgather) if world > 1 else None
-    cb = C.cast(self._allgather_cb, C.c_void_p) if world > 1 else None
-    self.ctx._chk(self.ctx.lib.cq_pk_set_sharding(self.h, rank, world, cb, None))
+    def bcast(_user, buf, nbytes, root):
+        try:
+            mem = (C.c_uint8 * nbytes).from_address(buf)
+            t = torch.frombuffer(mem, dtype=torch.uint8)  # shares the library's host buffer
+            if device is not None:
+                d = t.to(device)
+                dist.broadcast(d, src=dist.get_global_rank(group, root) if group is not None else root, group=group)
+                t.copy_(d.cpu())
+            else:
+                dist.broadcast(t, src=dist.get_global_rank(group, root) if group is not None else root, group=group)
+            return 0
+        except Exception:
+            return -1
+
+    self._allgather_cb = _ALLGATHER_T(allgather)
+    self._bcast_cb = _BCAST_T(bcast)
+    self.ctx._chk(self.ctx.lib.cq_pk_set_column_sharding(self.h, 1 if columns else 0, C.cast(self._bcast_cb, C.c_void_p), None))
+    self.ctx._chk(self.ctx.lib.cq_pk_set_sharding(self.h, rank, world, C.cast(self._allgather_cb, C.c_void_p), None))
 
 
 ProvingKey.set_sharding = _pk_set_sharding

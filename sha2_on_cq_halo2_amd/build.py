@@ -56,7 +56,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     with ThreadPoolExecutor(max_workers=min(int(os.environ.get('CQ_BUILD_JOBS', '4')), max(1, len(jobs)))) as ex:
         list(ex.map(run, jobs))
     if jobs or not os.path.exists(LIB):
-        run([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs)
+        run([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"])
     return LIB
 
 

@@ -1,5 +1,6 @@
 // C ABI: context, device memory, arithmetic.rs entry points.  See include/cq_halo2.h.
 #include "ctx.hpp"
+#include "comm.hpp"
 #include "msm.hpp"
 #include "poly.hpp"
 #include <cstring>
@@ -58,6 +59,8 @@ void cq_ctx_destroy(cq_ctx* c) {
   if (c->pinned) hipHostFree(c->pinned);
   if (c->pinned_msm) hipHostFree(c->pinned_msm);
   if (c->pinned_small) hipHostFree(c->pinned_small);
+  cq::comm_rccl_destroy(c);
+  if (c->pinned_comm) hipHostFree(c->pinned_comm);
   if (c->prof_entries) hipHostFree(c->prof_entries);
   if (c->copy_done) hipEventDestroy(c->copy_done);
   if (c->copy_stream) hipStreamDestroy(c->copy_stream);
@@ -71,6 +74,26 @@ void cq_ctx_destroy(cq_ctx* c) {
 }
 
 const char* cq_last_error(const cq_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+int cq_rccl_unique_id(uint8_t id[CQ_RCCL_UNIQUE_ID_BYTES]) {
+  if (!id) return CQ_ERR_ARG;
+  return cq::comm_rccl_unique_id(id);
+}
+int cq_ctx_comm_init_rccl(cq_ctx* c, uint32_t rank, uint32_t world, const uint8_t id[CQ_RCCL_UNIQUE_ID_BYTES]) {
+  if (!c || !id || world == 0 || rank >= world) return CQ_ERR_ARG;
+  CQ_HIP(c, hipSetDevice(c->device));
+  return cq::comm_rccl_init(c, rank, world, id);
+}
+int cq_ctx_comm_selftest(cq_ctx* c) {
+  if (!c) return CQ_ERR_ARG;
+  CQ_HIP(c, hipSetDevice(c->device));
+  return cq::comm_rccl_selftest(c);
+}
+int cq_ctx_comm_destroy(cq_ctx* c) {
+  if (!c) return CQ_ERR_ARG;
+  cq::comm_rccl_destroy(c);
+  return CQ_OK;
+}
 
 int cq_ctx_sync(cq_ctx* c) {
   if (!c) return CQ_ERR_ARG;

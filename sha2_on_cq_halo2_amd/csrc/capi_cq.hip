@@ -10,6 +10,7 @@
 #include "prover.hpp"
 #include "setup.hpp"
 #include "msm.hpp"
+#include "comm.hpp"
 
 using namespace cq;
 
@@ -655,12 +656,73 @@ int cq_pk_set_rng_fill(cq_pk* pk, cq_rng_fill_fn fill) {
   return CQ_OK;
 }
 
+// MSM window tables of a sharded key: a rank only ever multiplies its slice of every (scalars, bases) range, so the
+// 17 x SRS tables are built for those slices alone (the union of the slices over the MSMs that share an array: lengths
+// n, n - 1, N, w N).  The full-array tables of the key's SRS objects are dropped; world = 1 brings them back.
+static int pk_shard_tables(cq_pk* pk) {
+  cq_ctx* c = pk->ctx;
+  for (const void* p : pk->shard_tables) msm_unregister_tables(c, p);
+  pk->shard_tables.clear();
+  if (!c->msm_precompute) return CQ_OK;
+  const size_t n = (size_t)1 << pk->k, N = pk->table_cfg ? pk->table_cfg->N : 0;
+  struct Use { const G1Affine* b; size_t len; };
+  std::vector<Use> uses{{pk->params->g_lagrange, n}, {pk->params->g, n}, {pk->params->g, n - 1}};
+  if (pk->table_cfg) {
+    uses.push_back({pk->table_cfg->g1_lagrange, N});
+    uses.push_back({pk->table_cfg->g_lagrange_opening_at_0, N});
+  }
+  for (size_t l = 0; l < pk->lookups.size(); l++) uses.push_back({pk->qs_concat[l], pk->lookups[l].tables.size() * N});
+  if (pk->b0_g1_bound) uses.push_back({pk->b0_g1_bound, n - 1});
+  int rc;
+  if (pk->shard_world <= 1) {  // back to whole arrays
+    for (auto& u : uses)
+      if ((rc = msm_register_tables(c, u.b, u.len)) != CQ_OK) return rc;
+    return CQ_OK;
+  }
+  for (auto& u : uses) msm_unregister_tables(c, u.b);
+  std::vector<std::pair<const G1Affine*, const G1Affine*>> iv;
+  for (auto& u : uses) {
+    size_t lo, hi;
+    shard_range(u.len, pk->shard_rank, pk->shard_world, lo, hi);
+    if (hi > lo) iv.push_back({u.b + lo, u.b + hi});
+  }
+  std::sort(iv.begin(), iv.end());
+  std::vector<std::pair<const G1Affine*, const G1Affine*>> merged;
+  for (auto& x : iv) {
+    if (!merged.empty() && x.first <= merged.back().second) merged.back().second = std::max(merged.back().second, x.second);
+    else merged.push_back(x);
+  }
+  for (auto& m : merged) {
+    if ((rc = msm_register_tables(c, m.first, (size_t)(m.second - m.first))) != CQ_OK) return rc;
+    pk->shard_tables.push_back(m.first);
+  }
+  return CQ_OK;
+}
+
 int cq_pk_set_sharding(cq_pk* pk, uint32_t rank, uint32_t world, cq_allgather_fn fn, void* user) {
-  if (!pk || world == 0 || rank >= world || (world > 1 && !fn)) return CQ_ERR_ARG;
+  if (!pk || world == 0 || rank >= world) return CQ_ERR_ARG;
+  cq_ctx* c = pk->ctx;
+  if (world > 1 && !fn && (!c->rccl_comm || c->rccl_world != world || c->rccl_rank != rank))
+    return c->fail(CQ_ERR_ARG, "set_sharding: no all-gather callback and no matching RCCL communicator on the context");
+  CQ_HIP(c, hipSetDevice(c->device));
+  CQ_HIP(c, hipStreamSynchronize(c->stream));
   pk->shard_rank = rank;
   pk->shard_world = world;
-  pk->allgather = fn;
+  // world = 1 over a one-rank RCCL communicator: still "sharded" -- every collective of the prover runs, over one rank
+  pk->shard_single = world == 1 && !fn && c->rccl_comm && c->rccl_world == 1;
+  pk->allgather = world > 1 ? fn : nullptr;
   pk->allgather_user = user;
+  int rc = pk_shard_tables(pk);
+  if (rc != CQ_OK) return rc;
+  CQ_HIP(c, hipStreamSynchronize(c->stream));
+  return CQ_OK;
+}
+
+int cq_pk_set_column_sharding(cq_pk* pk, int on, cq_bcast_fn fn, void* user) {
+  if (!pk) return CQ_ERR_ARG;
+  pk->shard_columns = on != 0;
+  pk->bcast = fn;
+  pk->bcast_user = user;
   return CQ_OK;
 }
 
@@ -673,6 +735,7 @@ void cq_pk_destroy(cq_pk* pk) {
                   (void*)pk->gate_prog, (void*)pk->constants, (void*)pk->lookup_prog, (void*)pk->legacy_prog, (void*)pk->perm_values, (void*)pk->perm_polys, (void*)pk->perm_cosets,
                   (void*)pk->omega_powers, (void*)pk->ext_pow_lo, (void*)pk->ext_pow_hi})
     if (p) hipFree(p);
+  for (const void* p : pk->shard_tables) msm_unregister_tables(pk->ctx, p);
   if (pk->b0_g1_bound) msm_unregister_tables(pk->ctx, pk->b0_g1_bound);
   if (pk->own_b0 && pk->b0_g1_bound) hipFree(pk->b0_g1_bound);
   for (auto p : pk->qs_concat) {

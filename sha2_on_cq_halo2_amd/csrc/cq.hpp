@@ -53,6 +53,15 @@ int fr_validate(cq_ctx* c, const Fr* v, size_t n, uint32_t* bad_dev);
 
 }  // namespace cq
 
+namespace cq {
+// contiguous slice [lo, hi) of an n-term multiexp (or of `n` columns) owned by `rank`; sizes differ by at most one
+inline void shard_range(size_t n, uint32_t rank, uint32_t world, size_t& lo, size_t& hi) {
+  const size_t base = n / world, rem = n % world;
+  lo = rank * base + (rank < rem ? rank : rem);
+  hi = lo + base + (rank < rem ? 1 : 0);
+}
+}  // namespace cq
+
 // ParamsKZG G1 part (poly/kzg/commitment.rs:31-39), SRS resident in HBM
 struct cq_params {
   cq_ctx* ctx;
@@ -139,6 +148,16 @@ struct cq_pk {
   // MSM sharding across ranks (one process per GPU): every rank commits its slice of each point range,
   // partial results are all-gathered through the caller's collective and summed locally
   uint32_t shard_rank = 0, shard_world = 1;
-  cq_allgather_fn allgather = nullptr;
+  // single-rank communicator: the collectives run over one rank (the path a 1-GPU box can exercise on hardware)
+  bool shard_single = false;
+  bool sharded() const { return shard_world > 1 || shard_single; }
+  cq_allgather_fn allgather = nullptr;  // nullptr with shard_world > 1: the context's RCCL communicator
   void* allgather_user = nullptr;
+  // column sharding: independent column transforms are split between the ranks by owner and the results
+  // broadcast (comm.hpp); `bcast`: host-buffer transport for it (nullptr: RCCL)
+  bool shard_columns = true;
+  cq_bcast_fn bcast = nullptr;
+  void* bcast_user = nullptr;
+  // the window tables this key's MSMs use when sharded: built for the rank's slices only (capi_cq.hip)
+  std::vector<const void*> shard_tables;
 };

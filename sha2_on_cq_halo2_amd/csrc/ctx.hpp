@@ -158,6 +158,27 @@ struct cq_ctx {
     *out = pinned_small;
     return CQ_OK;
   }
+  // RCCL communicator of the context (comm.hip; cq_ctx_comm_init_rccl) and the pinned staging of its small exchanges
+  void* rccl_comm = nullptr;
+  uint32_t rccl_rank = 0, rccl_world = 1;
+  void* pinned_comm = nullptr;
+  size_t pinned_comm_bytes = 0;
+  int ensure_pinned_comm(size_t bytes, void** out) {
+    if (pinned_comm_bytes < bytes) {
+      if (pinned_comm) {
+        hipStreamSynchronize(stream);
+        hipHostFree(pinned_comm);
+        pinned_comm = nullptr;
+        pinned_comm_bytes = 0;
+      }
+      const size_t want = bytes < 65536 ? 65536 : bytes;
+      hipError_t e = hipHostMalloc(&pinned_comm, want, hipHostMallocDefault);
+      if (e != hipSuccess) return hip_fail(e, "hipHostMalloc");
+      pinned_comm_bytes = want;
+    }
+    *out = pinned_comm;
+    return CQ_OK;
+  }
   void* pinned_msm = nullptr;  // MSM results (kept apart from `pinned`, which stages RNG words)
   size_t pinned_msm_bytes = 0;
   int ensure_pinned_msm(size_t bytes, void** out) {

@@ -22,6 +22,7 @@
 #include <thread>
 #include <vector>
 #include "blake2b.hpp"
+#include "comm.hpp"
 #include "cq.hpp"
 #include "ctx.hpp"
 #include "msm.hpp"
@@ -139,13 +140,6 @@ struct Rng {
   }
 };
 
-// contiguous slice of an n-term multiexp owned by `rank` (sizes differ by at most one)
-void shard_range(size_t n, uint32_t rank, uint32_t world, size_t& lo, size_t& hi) {
-  const size_t base = n / world, rem = n % world;
-  lo = rank * base + std::min<size_t>(rank, rem);
-  hi = lo + base + (rank < rem ? 1 : 0);
-}
-
 // Commitments of one transcript round.  begin() enqueues the (possibly sharded) MSMs, end() waits,
 // exchanges partial sums between ranks when sharded, and normalises (batch_normalize).
 struct Commit {
@@ -156,7 +150,7 @@ struct Commit {
             const std::vector<size_t>& lens) {
     pk = pk_;
     count = scalars.size();
-    if (pk->shard_world <= 1) return msm_multi_begin(pk->ctx, scalars.data(), bases.data(), lens.data(), count, pend);
+    if (!pk->sharded()) return msm_multi_begin(pk->ctx, scalars.data(), bases.data(), lens.data(), count, pend);
     std::vector<const Fr*> sc(count);
     std::vector<const G1Affine*> bs(count);
     std::vector<size_t> ln(count);
@@ -175,11 +169,11 @@ struct Commit {
     int rc = msm_multi_end(c, pend, jac.data());
     if (rc != CQ_OK) return rc;
     std::vector<G1Jac> j(count);
-    if (pk->shard_world > 1) {
+    if (pk->sharded()) {
       // all-gather of count x 96 B per rank, then the local EC sum (not an RCCL reduction op)
       std::vector<uint64_t> all((size_t)pk->shard_world * count * 12);
-      if (pk->allgather(pk->allgather_user, jac.data(), all.data(), count * 12 * sizeof(uint64_t)) != 0)
-        return c->fail(CQ_ERR_INTERNAL, "allgather callback failed");
+      int arc = shard_allgather_host(pk, jac.data(), all.data(), count * 12 * sizeof(uint64_t));
+      if (arc != CQ_OK) return arc;
       for (size_t i = 0; i < count; i++) {
         G1Jac acc = G1Jac::identity();
         for (uint32_t r = 0; r < pk->shard_world; r++) acc = jac_add(acc, jac_from_limbs(all.data() + ((size_t)r * count + i) * 12));
@@ -197,11 +191,11 @@ struct Commit {
 // come out the same on every rank: true everywhere iff `flag` is set on any rank (one 8-byte all-gather).
 int shard_any(const cq_pk* pk, bool flag, bool& out) {
   out = flag;
-  if (pk->shard_world <= 1) return CQ_OK;
+  if (!pk->sharded()) return CQ_OK;
   const uint64_t mine = flag ? 1 : 0;
   std::vector<uint64_t> all(pk->shard_world, 0);
-  if (pk->allgather(pk->allgather_user, &mine, all.data(), sizeof(uint64_t)) != 0)
-    return pk->ctx->fail(CQ_ERR_INTERNAL, "allgather callback failed");
+  int arc = shard_allgather_host(pk, &mine, all.data(), sizeof(uint64_t));
+  if (arc != CQ_OK) return arc;
   for (uint64_t v : all) out = out || v != 0;
   return CQ_OK;
 }
@@ -503,6 +497,32 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, const uint64_
      *a_scaled = B.a_scaled;
   uint64_t* rng_dev = B.rng_dev;
   uint32_t* m_counts = B.m_counts;
+
+  // Column sharding (cq_pk_set_column_sharding): a batch of independent column transforms is split
+  // between the ranks by owner -- contiguous ranges of columns, cq::shard_range -- and every rank's output columns are
+  // broadcast from their owner on the stream the transform ran on (one grouped RCCL launch).  Transforms chained on the
+  // same batch (coefficients, then the coset of the same columns) read what their own rank wrote, so they need not
+  // wait for the exchange.  Unsharded, or with fewer than two columns: the plain call.
+  auto sharded_transform = [&](bool to_extended, const Fr* in, Fr* out, uint32_t batch) -> int {
+    const size_t in_stride = n, out_stride = to_extended ? ext : n;
+    auto run = [&](size_t first, size_t count) -> int {
+      if (!count) return CQ_OK;
+      return to_extended ? domain_coeff_to_extended(dom, in + first * in_stride, out + first * out_stride, (uint32_t)count, in_stride, out_stride)
+                         : domain_lagrange_to_coeff(dom, in + first * in_stride, out + first * out_stride, (uint32_t)count, in_stride, out_stride);
+    };
+    if (!shard_columns_enabled(pk) || (batch < 2 && !pk->shard_single)) return run(0, batch);
+    size_t lo, hi;
+    shard_range(batch, pk->shard_rank, pk->shard_world, lo, hi);
+    CQ_TRY(run(lo, hi - lo));
+    std::vector<BcastPart> parts;
+    for (uint32_t r = 0; r < pk->shard_world; r++) {
+      shard_range(batch, r, pk->shard_world, lo, hi);
+      if (hi > lo) parts.push_back({out + lo * out_stride, (hi - lo) * out_stride * sizeof(Fr), r});
+    }
+    return shard_bcast_parts(pk, parts.data(), parts.size(), c->stream);
+  };
+  auto lagrange_to_coeff_cols = [&](const Fr* in, Fr* out, size_t batch) { return sharded_transform(false, in, out, (uint32_t)batch); };
+  auto coeff_to_extended_cols = [&](const Fr* in, Fr* out, size_t batch) { return sharded_transform(true, in, out, (uint32_t)batch); };
 
   // side stream: drain whatever an aborted proof may have left there; its NTTs must find their twiddle tables built
   CQ_TRY(c->ensure_aux_stream());
@@ -874,14 +894,14 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, const uint64_
       AuxFork fork(c);
       CQ_TRY(fork.begin(seq));
       if (L) {
-        CQ_TRY(domain_lagrange_to_coeff(dom, f_lag, f_coeff, (uint32_t)L, n, n));
-        CQ_TRY(domain_coeff_to_extended(dom, f_coeff, cosets + L * ext, (uint32_t)L, n, ext));
+        CQ_TRY(lagrange_to_coeff_cols(f_lag, f_coeff, L));
+        CQ_TRY(coeff_to_extended_cols(f_coeff, cosets + L * ext, L));
       }
-      if (general && I) CQ_TRY(domain_coeff_to_extended(dom, B.inst_coeff, B.inst_cosets, (uint32_t)I, n, ext));
+      if (general && I) CQ_TRY(coeff_to_extended_cols(B.inst_coeff, B.inst_cosets, I));
       if (A && S == 0) {
         // advice -> coefficients (prover.rs:587-603), in place: without a permutation argument nothing reads the
         // Lagrange values after round 1, and the round-2 inversions leave room for it
-        CQ_TRY(domain_lagrange_to_coeff(dom, adv, adv, (uint32_t)A, n, n));
+        CQ_TRY(lagrange_to_coeff_cols(adv, adv, A));
         adv_is_coeff = true;
       }
       CQ_TRY(fork.end());
@@ -1001,7 +1021,7 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, const uint64_
       woff += w;
     }
     if (L) {
-      CQ_TRY(domain_lagrange_to_coeff(dom, bpoly, bpoly, (uint32_t)L, n, n));  // f: under round 1's launch
+      CQ_TRY(lagrange_to_coeff_cols(bpoly, bpoly, L));  // f: under round 1's launch
       // b(0) of every lookup (for a(0), :318-324): on its way to the host while the round's MSMs run
       GatherArgs ga;
       ga.count = (uint32_t)L;
@@ -1059,9 +1079,9 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, const uint64_
         // (evaluation.rs:317-335), b onto the extended coset
         AuxFork fork(c);
         CQ_TRY(fork.begin(seq));
-        if (A && !adv_is_coeff) CQ_TRY(domain_lagrange_to_coeff(dom, adv, adv, (uint32_t)A, n, n));
-        if (L) CQ_TRY(domain_coeff_to_extended(dom, bpoly, cosets, (uint32_t)L, n, ext));
-        if (general && A) CQ_TRY(domain_coeff_to_extended(dom, adv, B.adv_cosets, (uint32_t)A, n, ext));
+        if (A && !adv_is_coeff) CQ_TRY(lagrange_to_coeff_cols(adv, adv, A));
+        if (L) CQ_TRY(coeff_to_extended_cols(bpoly, cosets, L));
+        if (general && A) CQ_TRY(coeff_to_extended_cols(adv, B.adv_cosets, A));
         CQ_TRY(fork.end());
       }
       if (random_late) CQ_TRY(finish_random_poly());  // queued behind the launch above
@@ -1075,7 +1095,7 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, const uint64_
     for (size_t st = 0; st < S; st++)
       if (!tr.write_point(r2[st])) return c->fail(CQ_ERR_TRANSCRIPT, "permutation product commitment is the identity");
     // z -> coefficients (permutation/prover.rs:179), in place
-    if (S) CQ_TRY(domain_lagrange_to_coeff(dom, B.z, B.z, (uint32_t)S, n, n));
+    if (S) CQ_TRY(lagrange_to_coeff_cols(B.z, B.z, S));
     for (size_t l = 0; l < PL; l++) {
       if (!tr.write_point(r2[S + l])) return c->fail(CQ_ERR_TRANSCRIPT, "lookup product commitment is the identity");
       // a', s', z -> coefficients (lookup/prover.rs:133, 285), in place (three consecutive vectors)
@@ -1107,8 +1127,8 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, const uint64_
   {
     if (general) {
       // advice / instance cosets (:317-335), permutation product cosets (permutation/prover.rs:182)
-      if (I && !(L || PL)) CQ_TRY(domain_coeff_to_extended(dom, B.inst_coeff, B.inst_cosets, (uint32_t)I, n, ext));  // no round 1
-      if (S) CQ_TRY(domain_coeff_to_extended(dom, B.z, B.z_cosets, (uint32_t)S, n, ext));
+      if (I && !(L || PL)) CQ_TRY(coeff_to_extended_cols(B.inst_coeff, B.inst_cosets, I));  // no round 1
+      if (S) CQ_TRY(coeff_to_extended_cols(B.z, B.z_cosets, S));
       const uint32_t rot_scale = 1u << (dom->extended_k - dom->k);
       if (pk->num_gate_polys) {  // custom gates (:348-365)
         GateEvalArgs ga;

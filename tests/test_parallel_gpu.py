@@ -57,9 +57,13 @@ rank, world = dist.get_rank(), dist.get_world_size()
 ctx = Context(0)
 wl = ShaCqWorkload(ctx, 12, pairs=2)          # same seed on every rank: same pk, same witness
 single = wl.prove(seed=9)
-wl.pk.set_sharding(rank, world)
+# MSMs by point range only (every rank still transforms every column) ...
+wl.pk.set_sharding(rank, world, columns=False)
+assert wl.prove(seed=9) == single, "sharded proof differs from the single-GPU proof"
+# ... and with the column transforms split by owner, the transformed columns broadcast (gloo through the host hooks)
+wl.pk.set_sharding(rank, world, columns=True)
 sharded = wl.prove(seed=9)
-assert sharded == single, "sharded proof differs from the single-GPU proof"
+assert sharded == single, "column-sharded proof differs from the single-GPU proof"
 # The random polynomial is committed with round 2 or in a launch of its own, by a timing-dependent choice that the ranks
 # must make together (one launch more = one all-gather more): pin it differently per rank, then both ways.
 for late in (("1", "0"), ("0", "1"), ("1", "1"), ("0", "0")):
@@ -74,8 +78,9 @@ sys.stdout.write("rank %%d ok %%s\n" %% (rank, hashlib.sha256(single).hexdigest(
 
 
 def test_sharded_create_proof_two_ranks_one_gpu(tmp_path):
-    """cq_pk_set_sharding: every commitment is split by point range across 2 ranks, partials are
-    all-gathered and summed; the proof bytes equal the unsharded ones on both ranks."""
+    """cq_pk_set_sharding / cq_pk_set_column_sharding: every commitment is split by point range across 2 ranks (window
+    tables for the rank's slices only), partials are all-gathered and summed; independent column transforms are split
+    by owner and broadcast; the proof bytes equal the unsharded ones on both ranks."""
     script = tmp_path / "shard_worker.py"
     script.write_text(SHARD_WORKER % {"root": ROOT})
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
@@ -84,3 +89,60 @@ def test_sharded_create_proof_two_ranks_one_gpu(tmp_path):
                        capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert r.stdout.count("rank ") == 2 and r.stdout.count(" ok") == 2, r.stdout  # both ranks finished (lines may interleave)
+
+
+PLONK_SHARD_WORKER = r'''
+import os, sys
+sys.path.insert(0, %(root)r)
+import torch.distributed as dist
+from sha2_on_cq_halo2_amd import Context
+from sha2_on_cq_halo2_amd.sha_circuit import ShaPlonkWorkload
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+ctx = Context(0)
+wl = ShaPlonkWorkload(ctx, 11, pairs=3)   # gates + permutation: advice / z cosets are column-sharded too; 3 lookups over 2 ranks: uneven
+for opener in ("gwc", "shplonk"):
+    wl.pk.set_opener(opener)
+    wl.pk.set_sharding(0, 1)
+    single = wl.prove(seed=4)
+    wl.pk.set_sharding(rank, world, columns=True)
+    assert wl.prove(seed=4) == single, opener
+dist.barrier(); dist.destroy_process_group(); ctx.close()
+sys.stdout.write("rank %%d ok\n" %% rank); sys.stdout.flush()
+'''
+
+
+def test_sharded_general_circuit_two_ranks_one_gpu(tmp_path):
+    """The general-PLONK path (gates, permutation, both openers) under MSM + column sharding, 2 ranks over gloo."""
+    script = tmp_path / "plonk_shard_worker.py"
+    script.write_text(PLONK_SHARD_WORKER % {"root": ROOT})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29649", str(script)],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert r.stdout.count("rank ") == 2 and r.stdout.count(" ok") == 2, r.stdout
+
+
+def test_rccl_path_single_rank(ctx):
+    """The RCCL transport itself, on the one GPU this box has: a one-rank communicator, the collective self-check
+    (ncclAllGather + grouped ncclBroadcasts on device buffers), and a proof in single-rank sharded mode -- every
+    collective of the sharded prover is issued through RCCL -- byte-equal to the plain proof."""
+    from sha2_on_cq_halo2_amd.api import rccl_unique_id
+    from sha2_on_cq_halo2_amd.sha_circuit import ShaCqWorkload
+
+    wl = ShaCqWorkload(ctx, 12, pairs=2)
+    plain = wl.prove(seed=9)
+    ctx.comm_init_rccl(0, 1, rccl_unique_id())
+    try:
+        ctx.comm_selftest()
+        wl.pk.set_sharding(0, 1, transport="rccl")
+        for late in ("0", "1"):
+            os.environ["CQ_RANDOM_LATE"] = late
+            assert wl.prove(seed=9) == plain
+    finally:
+        os.environ.pop("CQ_RANDOM_LATE", None)
+        ctx.comm_destroy()
+        wl.pk.set_sharding(0, 1)
+    assert wl.prove(seed=9) == plain
+    wl.close()
