@@ -395,6 +395,33 @@ typedef int (*cq_phase_fn)(void* user, uint32_t phase, const uint64_t* challenge
 int cq_create_proof_phases(cq_pk* pk, uint64_t* const* advice_dev, const uint64_t* const* instances,
                            const size_t* instance_lens, cq_phase_fn phase_fn, void* phase_user, cq_rng_next_u64 rng,
                            void* rng_state, uint8_t* proof, size_t proof_cap, size_t* proof_len);
+/* ---- the CQ sub-arguments on their own (for a host that keeps its own create_proof and swaps in only these) ---------
+ * Shapes: L = lookups of `pk`, n = 2^k, N = table size, ext = 2^extended_k; lookups in cs.static_lookups order.
+ *
+ * static_lookup::Argument::commit (plonk/static_lookup/prover.rs:51-183), called at plonk/prover.rs:512-522: evaluates
+ * the lookup inputs over the Lagrange basis, compresses them with theta into f (:108-116), maps every usable row to its
+ * table index and counts the multiplicities m (:122-160; CQ_ERR_LOOKUP as the reference's errors), commits both.
+ *   advice_dev:   num_advice DEVICE columns of n elements, blinding rows included (f is committed over all n rows)
+ *   instance_dev: num_instance device columns (NULL without instance columns); challenges: num_challenges x 4 limbs, HOST
+ *   f_dev:  L x n elements out (Lagrange values of f);  m_dev: L x N uint32 out (m_sparse, dense)
+ *   commitments: HOST, L x 2 affine points (8 limbs each): f_cm, m_cm per lookup -- the order they are written (:175-176) */
+int cq_cq_round1_dev(cq_pk* pk, const uint64_t* const* advice_dev, const uint64_t* const* instance_dev, const uint64_t* challenges,
+                     const uint64_t theta[4], uint64_t* f_dev, uint32_t* m_dev, uint64_t* commitments);
+/* static_lookup::Committed::commit_log_derivatives (:187-342), called at plonk/prover.rs:572-575: A_i = m_i / (t_i + beta)
+ * and its three commitments over the table SRS / cached quotients (:224-257), B = 1 / (f + beta), b = iNTT(B) (:261-276),
+ * b_0 = (b - b(0)) / X, its commitment and the degree-bound commitment p (:279-313), a(0) (:318-324), f in coefficient
+ * form (:326-334).
+ *   f_dev, m_dev: as left by cq_cq_round1_dev;  b_coeff_dev, f_coeff_dev: L x n elements out (b_0 is b_coeff + 1, n - 1 long)
+ *   commitments: HOST, L x 5 affine points: a, q_a, a_0, b_0, p per lookup (write order :306-313); a_at_zero: HOST, L x 4 limbs */
+int cq_cq_round2_dev(cq_pk* pk, const uint64_t* f_dev, const uint32_t* m_dev, const uint64_t theta[4], const uint64_t beta[4],
+                     uint64_t* b_coeff_dev, uint64_t* f_coeff_dev, uint64_t* commitments, uint64_t* a_at_zero);
+/* The static-lookup part of Evaluator::evaluate_h (plonk/evaluation.rs:533-548; called at plonk/prover.rs:606-624):
+ * h <- h * y + (b (f l_active_row + beta) - 1) per lookup on the extended coset, starting from h_in_dev (the gate /
+ * permutation / legacy-lookup terms folded so far; NULL = zero); b and f are taken in coefficient form and extended here
+ * (:535-536).  divide_by_vanishing != 0 also applies EvaluationDomain::divide_by_vanishing_poly (poly/domain.rs:319-338,
+ * what vanishing::Argument::construct does next, vanishing/prover.rs:84).  h_out_dev: ext elements (may alias h_in_dev). */
+int cq_quotient_dev(cq_pk* pk, const uint64_t* b_coeff_dev, const uint64_t* f_coeff_dev, const uint64_t y[4], const uint64_t beta[4],
+                    const uint64_t* h_in_dev, int divide_by_vanishing, uint64_t* h_out_dev);
 /* The verifying-key commitments the prover's key implies: commit_lagrange of every fixed column
  * (keygen.rs:247-250) and of every permutation polynomial (permutation/keygen.rs:115-149), as affine
  * points (num_fixed x 8 and num_perm_columns x 8 words). */

@@ -134,6 +134,9 @@ def _declare(lib):  # noqa: F811
     lib.cq_create_proof_host.argtypes = [vp, vp, vp, vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
     lib.cq_create_proof_instances.argtypes = [vp, vp, C.c_int, vp, vp, vp, vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
     lib.cq_pk_vk_commitments.argtypes = [vp, vp, vp]
+    lib.cq_cq_round1_dev.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.cq_cq_round2_dev.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.cq_quotient_dev.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int, vp]
     lib.cq_g_to_lagrange_dev.argtypes = [vp, vp, C.c_uint32, vp]
     lib.cq_params_downsize.argtypes = [vp, C.c_uint32, C.POINTER(vp)]
     lib.cq_static_table_new_fk.argtypes = [vp, C.c_size_t, vp, vp, C.POINTER(vp)]

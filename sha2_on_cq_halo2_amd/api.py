@@ -619,6 +619,8 @@ class ProvingKey(_Handle):
                                             num_selectors, 1 if checked else 0, C.byref(h)))
         self.h = h
         self.num_advice = num_advice
+        self._num_lookups = len(lookups)
+        self._table_size = table_cfg.size if table_cfg is not None else 0
         self.usable_rows = ctx.lib.cq_pk_usable_rows(h)
         self.proof_size = ctx.lib.cq_pk_proof_size(h)
         ctx._children.add(self)
@@ -723,6 +725,58 @@ class ProvingKey(_Handle):
     def create_proof_dev(self, advice_ptrs, rng_words=None, seed=None, instances=None, opaque_rng=False) -> bytes:
         fn, st = self._rng(rng_words, seed, opaque_rng)
         return self._run(self.ctx.lib.cq_create_proof, list(advice_ptrs), fn, st, instances, on_device=True)
+
+
+def _pk_shape(self):
+    L = len(self.cs.static_lookups) if self.cs is not None else self._num_lookups
+    return L, 1 << self.k, self._table_size
+
+
+def _pk_cq_round1(self, advice_ptrs, theta, instance_ptrs=None, challenges=None):
+    """`static_lookup::Argument::commit` (static_lookup/prover.rs:51-183) on its own (cq_cq_round1_dev): returns
+    (f DevBuf [L x n], m DevBuf [L x N uint32], commitments uint64[L, 2, 8] = (f_cm, m_cm) per lookup)."""
+    L, n, N = _pk_shape(self)
+    ctx = self.ctx
+    f, m = ctx.alloc(max(L * n * 32, 32)), ctx.alloc(max(L * N * 4, 32))
+    arr = (C.c_void_p * max(len(advice_ptrs), 1))(*advice_ptrs)
+    iarr = (C.c_void_p * max(len(instance_ptrs or []), 1))(*(instance_ptrs or [])) if instance_ptrs else None
+    ch = np.ascontiguousarray(challenges, dtype=np.uint64) if challenges is not None else None
+    th = np.ascontiguousarray(theta, dtype=np.uint64).reshape(4)
+    cm = np.zeros((max(L, 1), 2, 8), dtype=np.uint64)
+    ctx._chk(ctx.lib.cq_cq_round1_dev(self.h, arr, iarr, ch.ctypes.data if ch is not None else None, th.ctypes.data, f.ptr, m.ptr,
+                                      cm.ctypes.data))
+    return f, m, cm[:L]
+
+
+def _pk_cq_round2(self, f: DevBuf, m: DevBuf, theta, beta):
+    """`Committed::commit_log_derivatives` (static_lookup/prover.rs:187-342) on its own (cq_cq_round2_dev): returns
+    (b_coeff DevBuf, f_coeff DevBuf, commitments uint64[L, 5, 8] = (a, q_a, a_0, b_0, p), a_at_zero uint64[L, 4])."""
+    L, n, _ = _pk_shape(self)
+    ctx = self.ctx
+    b, fc = ctx.alloc(max(L * n * 32, 32)), ctx.alloc(max(L * n * 32, 32))
+    th = np.ascontiguousarray(theta, dtype=np.uint64).reshape(4)
+    be = np.ascontiguousarray(beta, dtype=np.uint64).reshape(4)
+    cm = np.zeros((max(L, 1), 5, 8), dtype=np.uint64)
+    a0 = np.zeros((max(L, 1), 4), dtype=np.uint64)
+    ctx._chk(ctx.lib.cq_cq_round2_dev(self.h, f.ptr, m.ptr, th.ctypes.data, be.ctypes.data, b.ptr, fc.ptr, cm.ctypes.data, a0.ctypes.data))
+    return b, fc, cm[:L], a0[:L]
+
+
+def _pk_cq_quotient(self, b_coeff: DevBuf, f_coeff: DevBuf, y, beta, h_in: DevBuf = None, divide: bool = True, ext: int = None) -> DevBuf:
+    """The static-lookup terms of `Evaluator::evaluate_h` (evaluation.rs:533-548), optionally followed by
+    `divide_by_vanishing_poly` (domain.rs:319-338) (cq_quotient_dev); `ext` = 2^extended_k elements come back."""
+    ctx = self.ctx
+    out = ctx.alloc(ext * 32)
+    yy = np.ascontiguousarray(y, dtype=np.uint64).reshape(4)
+    be = np.ascontiguousarray(beta, dtype=np.uint64).reshape(4)
+    ctx._chk(ctx.lib.cq_quotient_dev(self.h, b_coeff.ptr, f_coeff.ptr, yy.ctypes.data, be.ctypes.data, h_in.ptr if h_in else None,
+                                     1 if divide else 0, out.ptr))
+    return out
+
+
+ProvingKey.cq_round1 = _pk_cq_round1
+ProvingKey.cq_round2 = _pk_cq_round2
+ProvingKey.cq_quotient = _pk_cq_quotient
 
 
 def _ctx_msm_precompute(self, bases_ptr: int, n: int):

@@ -209,7 +209,7 @@ __global__ __launch_bounds__(256) void cq_quotient_kernel(CqQuotientArgs args, u
     const Fr b = ld(args.b[l] + i), f = ld(args.f[l] + i);
     acc = acc * args.y + (b * (f * la + args.beta) - one);
   }
-  acc = acc * ld(args.t_evals + (i & (args.t_len - 1)));
+  if (args.t_len) acc = acc * ld(args.t_evals + (i & (args.t_len - 1)));  // t_len = 0: evaluate_h alone, no division
   st(h + i, acc);
 }
 
