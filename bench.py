@@ -101,8 +101,11 @@ def main():
     ctx.profile_read(PROF_MSM_ENTRIES)
     barrier()
     t0 = time.perf_counter()
+    step_ms = []
     for i in range(args.steps):
-        proof = step(i)
+        ts = time.perf_counter()
+        proof = step(i)  # returns with the proof bytes on the host: every step ends synchronised
+        step_ms.append((time.perf_counter() - ts) * 1e3)
     barrier()
     elapsed = time.perf_counter() - t0
     acc_ms, acc_calls = ctx.profile_read(PROF_MSM_ACCUMULATE)
@@ -144,6 +147,7 @@ def main():
                             f"replicas x{world} (one independent proof per GPU, no collective)"),
         },
         "proof_wall_s": elapsed / args.steps,
+        "step_ms_this_rank": {"min": min(step_ms), "median": sorted(step_ms)[len(step_ms) // 2], "max": max(step_ms)},
         "proofs_per_s": args.steps * proofs / elapsed,
         # `value` counts every scalar the reference's create_proof would hand to best_multiexp, including the 8n advice
         # scalars of this witness (<= 24-bit limbs on 9.4 % of the rows) and the 4n of the f commitments (derived by
@@ -263,6 +267,7 @@ def _finish_line(out, ctx, wl, args, k, acc_ms, acc_calls, ntt_ms, ntt_calls, ms
         if world == 1 and not args.no_generic_rng:
             leg("generic_rng", lambda: generic_rng(wl, max(3, min(args.steps, 10))))
         if world == 1 and not args.no_in_flight:
+            leg("batched", lambda: batched(ctx, wl, max(12, args.steps)))
             leg("two_in_flight", lambda: two_in_flight(ctx, wl, local_rank, max(10, args.steps)))
         if world == 1 and not args.no_plonk_variant:
             leg("plonk_variant", lambda: plonk_variant(ctx, wl, max(2, min(args.steps, 5))))
@@ -291,6 +296,34 @@ def modmul_peak(ctx):
         _MODMUL_PEAK.append(lanes * iters / (time.perf_counter() - t0))
         buf.free()
     return _MODMUL_PEAK[0]
+
+
+def batched(ctx, wl, count):
+    """Secondary figure (not `value`): BASELINE configs[4]'s shape on one GPU -- `count` independent instances of the
+    circuit through cq_create_proof_batch (independent witnesses, transcripts and RNG streams; the library keeps up to
+    `lanes` of them in flight, each on a stream and host thread of its own)."""
+    import torch
+
+    host = [c.download((wl.n, 4)) for c in wl.cols]
+    cols = []
+    for _ in range(count):  # every instance gets a witness of its own in HBM (the same SHA trace: what is timed is proving)
+        cols.append([ctx.to_device(h) for h in host])
+    ptrs = [[c.ptr for c in mine] for mine in cols]
+    res = {"instances": count}
+    single = wl.pk.create_proof_dev(ptrs[0], seed=500)
+    for lanes in (2, 3, 4):
+        wl.pk.create_proof_batch(ptrs[:lanes], [1 + i for i in range(lanes)], lanes=lanes)  # warm the lanes (twiddles, arenas)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        proofs = wl.pk.create_proof_batch(ptrs, [500 + i for i in range(count)], lanes=lanes)
+        dt = time.perf_counter() - t0
+        res[f"lanes_{lanes}"] = {"proofs_per_s": count / dt, "ms_per_proof_effective": dt / count * 1e3,
+                                 "mscalar_per_s": count * wl.msm_scalars_per_proof() / dt / 1e6,
+                                 "first_proof_equals_single": proofs[0] == single}
+    for mine in cols:
+        for b in mine:
+            b.free()
+    return res
 
 
 def two_in_flight(ctx, wl, device, reps):

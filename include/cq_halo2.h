@@ -375,6 +375,15 @@ size_t cq_pk_proof_size(const cq_pk* pk);
  * The proof (cq_pk_proof_size bytes) is written to `proof`. */
 int cq_create_proof(cq_pk* pk, const uint64_t* const* advice_dev, cq_rng_next_u64 rng, void* rng_state,
                     uint8_t* proof, size_t proof_cap, size_t* proof_len);
+/* `count` independent proofs of the circuit (BASELINE configs[4]: batches of instances): advice_dev[i] = the num_advice
+ * device columns of instance i, rng_states[i] its RNG state (one `rng` function for all), proofs[i] / proof_lens[i] its
+ * output (proof_cap bytes each).  The proofs are the ones cq_create_proof gives for the same (witness, RNG) one at a
+ * time; here up to `lanes` (0 = 3) of them are in flight on the GPU at once, each on a library-owned stream and host
+ * thread, so that one proof's latency-bound stretches are filled by another's kernels.  For circuits without instance
+ * columns and with a single phase.  (Set GPU_MAX_HW_QUEUES >= 8 in the environment: HIP multiplexes a process's
+ * streams onto 4 hardware queues by default and every lane uses three.) */
+int cq_create_proof_batch(cq_pk* pk, size_t count, const uint64_t* const* const* advice_dev, cq_rng_next_u64 rng,
+                          void* const* rng_states, uint8_t* const* proofs, size_t proof_cap, size_t* proof_lens, uint32_t lanes);
 /* Same with host-resident advice columns (uploaded first). */
 int cq_create_proof_host(cq_pk* pk, const uint64_t* const* advice, cq_rng_next_u64 rng, void* rng_state,
                          uint8_t* proof, size_t proof_cap, size_t* proof_len);

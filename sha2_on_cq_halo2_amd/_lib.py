@@ -131,6 +131,7 @@ def _declare(lib):  # noqa: F811
     lib.cq_pk_proof_size.restype = C.c_size_t
     lib.cq_pk_proof_size.argtypes = [vp]
     lib.cq_create_proof.argtypes = [vp, vp, vp, vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
+    lib.cq_create_proof_batch.argtypes = [vp, C.c_size_t, vp, vp, vp, vp, C.c_size_t, vp, C.c_uint32]
     lib.cq_create_proof_host.argtypes = [vp, vp, vp, vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
     lib.cq_create_proof_instances.argtypes = [vp, vp, C.c_int, vp, vp, vp, vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
     lib.cq_pk_vk_commitments.argtypes = [vp, vp, vp]

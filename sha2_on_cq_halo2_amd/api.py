@@ -774,6 +774,27 @@ def _pk_cq_quotient(self, b_coeff: DevBuf, f_coeff: DevBuf, y, beta, h_in: DevBu
     return out
 
 
+def _pk_create_proof_batch(self, advice_ptr_lists, seeds, lanes: int = 0, opaque_rng: bool = False):
+    """cq_create_proof_batch: one proof per entry of `advice_ptr_lists` (each a list of num_advice device pointers), blinded
+    from xoshiro256** streams seeded with `seeds[i]`; returns the list of proofs."""
+    lib = self.ctx.lib
+    B = len(advice_ptr_lists)
+    assert len(seeds) == B
+    cols = [(C.c_void_p * max(len(p), 1))(*p) for p in advice_ptr_lists]
+    adv = (C.c_void_p * max(B, 1))(*[C.cast(c, C.c_void_p) for c in cols])
+    states = [(C.c_uint64 * 4)() for _ in range(B)]
+    for st, sd in zip(states, seeds):
+        lib.cq_xoshiro256ss_seed(sd, st)
+    st_arr = (C.c_void_p * max(B, 1))(*[C.cast(s_, C.c_void_p) for s_ in states])
+    bufs = [(C.c_uint8 * self.proof_size)() for _ in range(B)]
+    out = (C.c_void_p * max(B, 1))(*[C.cast(b, C.c_void_p) for b in bufs])
+    lens = (C.c_size_t * max(B, 1))()
+    fn = C.cast(lib.cq_opaque_rng_next_u64 if opaque_rng else lib.cq_xoshiro256ss_next_u64, C.c_void_p)
+    self.ctx._chk(lib.cq_create_proof_batch(self.h, B, adv, fn, st_arr, out, self.proof_size, lens, lanes))
+    return [bytes(bufs[i][: lens[i]]) for i in range(B)]
+
+
+ProvingKey.create_proof_batch = _pk_create_proof_batch
 ProvingKey.cq_round1 = _pk_cq_round1
 ProvingKey.cq_round2 = _pk_cq_round2
 ProvingKey.cq_quotient = _pk_cq_quotient

@@ -51,6 +51,8 @@ int cq_ctx_create(int device, void* hip_stream, cq_ctx** out) {
 void cq_ctx_destroy(cq_ctx* c) {
   if (!c) return;
   hipSetDevice(c->device);
+  for (cq_ctx* lane : c->lanes) cq_ctx_destroy(lane);
+  c->lanes.clear();
   hipStreamSynchronize(c->stream);
   if (c->aux_stream) hipStreamSynchronize(c->aux_stream);
   c->ntt_cache.clear();

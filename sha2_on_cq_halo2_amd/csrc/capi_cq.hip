@@ -1,6 +1,10 @@
 // C ABI: CQ table objects, proving key, create_proof, SHA witness fill, harness RNGs.
 #include <algorithm>
+#include <atomic>
 #include <cstring>
+#include <mutex>
+#include <string>
+#include <thread>
 #include <vector>
 #include "cq.hpp"
 #include "xoshiro.hpp"
@@ -828,6 +832,86 @@ int cq_create_proof_instances(cq_pk* pk, const uint64_t* const* advice, int advi
                               size_t proof_cap, size_t* proof_len) {
   return advice_on_device ? create_proof_any(pk, advice, instances, instance_lens, rng, rng_state, proof, proof_cap, proof_len)
                           : create_proof_host_any(pk, advice, instances, instance_lens, rng, rng_state, proof, proof_cap, proof_len);
+}
+
+// Several instances of one circuit (independent witnesses, independent transcripts and RNG streams; the reference's
+// `circuits: &[ConcreteCircuit]`, plonk/prover.rs:419-463, proves them under ONE transcript and asserts a single circuit,
+// :413-417, so a batch here means independent proofs).  The proofs run on `lanes` contexts of their own on the same GPU,
+// one host thread each: while one proof sits in the latency-bound tail of an MSM launch or waits for its host (transcript,
+// normalisation), the others' kernels fill the chip -- BASELINE configs[4].  Byte for byte the proofs cq_create_proof
+// gives one at a time.
+int cq_create_proof_batch(cq_pk* pk, size_t count, const uint64_t* const* const* advice_dev, cq_rng_next_u64 rng,
+                          void* const* rng_states, uint8_t* const* proofs, size_t proof_cap, size_t* proof_lens, uint32_t lanes) {
+  if (!pk || (count && (!advice_dev || !rng || !rng_states || !proofs || !proof_lens))) return CQ_ERR_ARG;
+  cq_ctx* c = pk->ctx;
+  if (pk->num_instance || pk->num_phases > 1) return c->fail(CQ_ERR_ARG, "create_proof_batch: circuits with instance columns or several phases go through cq_create_proof_instances / _phases");
+  if (pk->sharded()) return c->fail(CQ_ERR_ARG, "create_proof_batch: the key is sharded across ranks");
+  if (!count) return CQ_OK;
+  CQ_HIP(c, hipSetDevice(c->device));
+  if (lanes == 0) lanes = 3;
+  lanes = (uint32_t)std::min<size_t>(lanes, count);
+  while (c->lanes.size() < lanes) {
+    cq_ctx* lane = nullptr;
+    int rc = cq_ctx_create(c->device, nullptr, &lane);
+    if (rc != CQ_OK) return c->fail(rc, "create_proof_batch: lane context");
+    lane->parent = c;
+    c->lanes.push_back(lane);
+  }
+  CQ_HIP(c, hipStreamSynchronize(c->stream));  // whatever filled the witnesses on the caller's stream is done
+  std::atomic<size_t> next{0};
+  std::atomic<int> first_rc{CQ_OK};
+  std::mutex err_mu;
+  std::string err;
+  auto worker = [&](uint32_t li) {
+    cq_ctx* lc = c->lanes[li];
+    if (hipSetDevice(lc->device) != hipSuccess) {
+      first_rc.store(CQ_ERR_HIP);
+      return;
+    }
+    // the key as this lane sees it: same device data, this lane's context (stream, scratch, twiddle cache)
+    cq_pk lane_pk = *pk;
+    cq_domain lane_dom = *pk->domain;
+    lane_dom.ctx = lc;
+    lane_pk.ctx = lc;
+    lane_pk.domain = &lane_dom;
+    for (;;) {
+      const size_t i = next.fetch_add(1);
+      if (i >= count || first_rc.load() != CQ_OK) break;
+      std::vector<uint8_t> out;
+      int rc = create_proof_dev(&lane_pk, advice_dev[i], nullptr, nullptr, nullptr, nullptr, rng, rng_states[i], out);
+      if (rc == CQ_OK && rng == cq_buffer_rng_next_u64 && ((cq_buffer_rng*)rng_states[i])->overrun) {
+        rc = CQ_ERR_ARG;
+        lc->err = "create_proof: the pre-drawn RNG stream ran out (blinding would be zero)";
+      }
+      if (rc == CQ_OK && out.size() > proof_cap) {
+        rc = CQ_ERR_ARG;
+        lc->err = "proof buffer too small";
+      }
+      if (rc != CQ_OK) {
+        std::lock_guard<std::mutex> lk(err_mu);
+        if (first_rc.load() == CQ_OK) {
+          first_rc.store(rc);
+          err = "proof " + std::to_string(i) + ": " + lc->err;
+        }
+        break;
+      }
+      memcpy(proofs[i], out.data(), out.size());
+      proof_lens[i] = out.size();
+    }
+    hipStreamSynchronize(lc->stream);
+  };
+  std::vector<std::thread> th;
+  for (uint32_t li = 1; li < lanes; li++) {
+    try {
+      th.emplace_back(worker, li);
+    } catch (...) {  // no thread to be had: the remaining lanes' share falls to the ones that run
+      break;
+    }
+  }
+  worker(0);
+  for (auto& t : th) t.join();
+  if (first_rc.load() != CQ_OK) return c->fail(first_rc.load(), err);
+  return CQ_OK;
 }
 
 // fixed_commitments (keygen.rs:247-250) and permutation::VerifyingKey::commitments (permutation/keygen.rs:115-149)

@@ -28,7 +28,13 @@ struct cq_ctx {
   struct MsmTable { const void* bases; size_t n; uint32_t c; void* table; };
   std::vector<MsmTable> msm_tables;
   // `bases` may point anywhere inside a registered array (a rank's slice of the SRS); *offset = first point
+  // Lanes: contexts of their own (stream, scratch, twiddle cache) on the same GPU, owned by `parent`, on which
+  // cq_create_proof_batch proves several instances of one key at a time.  A lane resolves window tables (read-only)
+  // and worker threads through its parent.
+  cq_ctx* parent = nullptr;
+  std::vector<cq_ctx*> lanes;
   const MsmTable* find_msm_table(const void* bases, size_t len, size_t* offset = nullptr) const {
+    if (parent) return parent->find_msm_table(bases, len, offset);
     for (auto& t : msm_tables) {
       const char* b0 = (const char*)t.bases;
       const char* b = (const char*)bases;
@@ -138,6 +144,7 @@ struct cq_ctx {
   // worker threads for the host-side glue (hostpool.hpp); CQ_HOST_THREADS overrides the count (0 = none)
   std::unique_ptr<cq::HostPool> pool_;
   cq::HostPool& pool() {
+    if (parent) return parent->pool();
     if (!pool_) {
       unsigned hw = std::thread::hardware_concurrency();
       unsigned w = hw > 3 ? (hw - 2 < 6 ? hw - 2 : 6) : 0;

@@ -143,3 +143,37 @@ def test_opaque_caller_rng_gives_the_same_proof(ctx):
     assert wl.pk.create_proof_dev(ptrs, seed=21, opaque_rng=True) == ref
     wl.pk.set_rng_fill(None)
     assert wl.pk.create_proof_dev(ptrs, seed=22, opaque_rng=True) != ref
+
+
+@pytest.mark.parametrize("lanes", [1, 3])
+def test_batched_proofs_equal_single_proofs(ctx, lanes):
+    """cq_create_proof_batch: B independent instances (different witnesses, different RNG seeds) proven `lanes` at a
+    time on library-owned streams / threads give, byte for byte, the proofs cq_create_proof gives one at a time."""
+    from sha2_on_cq_halo2_amd.sha_circuit import ShaCqWorkload, sha256_trace_words
+
+    wl = ShaCqWorkload(ctx, 10, pairs=2)
+    n = 1 << 10
+    B_ = 5
+    witnesses, singles = [], []
+    base = [c.download((n, 4)) for c in wl.cols]
+    for i in range(B_):
+        cols = []
+        for j, b in enumerate(base):  # instance i: the base witness with rows rotated inside the usable range (still in the tables)
+            a = b.copy()
+            u = wl.pk.usable_rows
+            a[:u] = np.roll(b[:u], 7 * i + j // 2 * 0, axis=0)
+            cols.append(ctx.to_device(a))
+        witnesses.append(cols)
+        singles.append(wl.pk.create_proof_dev([c.ptr for c in cols], seed=100 + i))
+    assert len(set(singles)) == B_
+    got = wl.pk.create_proof_batch([[c.ptr for c in cols] for cols in witnesses], [100 + i for i in range(B_)], lanes=lanes)
+    assert got == singles
+    # an error in one instance (a value outside the table) fails the call
+    from sha2_on_cq_halo2_amd import CqError
+
+    bad = base[0].copy()
+    bad[3] = B.to_mont_limbs([4097])[0]
+    witnesses[2][0].upload(bad)
+    with pytest.raises(CqError) as e:
+        wl.pk.create_proof_batch([[c.ptr for c in cols] for cols in witnesses], [100 + i for i in range(B_)], lanes=lanes)
+    assert e.value.code == -4
