@@ -66,6 +66,11 @@ int cq_ctx_create(int device, void* hip_stream, cq_ctx** out);
 void cq_ctx_destroy(cq_ctx* ctx);
 const char* cq_last_error(const cq_ctx* ctx);
 int cq_ctx_sync(cq_ctx* ctx);
+/* hipGraph replay of the MSM pipeline (BASELINE configs[4]: "hipGraph-captured rounds"): with `on` != 0 the kernel
+ * sequences before and after the accumulate kernel of every MSM launch (sort + plan: ~12 launches; combine + bucket
+ * reduction: ~6) are captured once per launch shape and replayed with one hipGraphLaunch each.  Same results; off by
+ * default because on ROCm 7.2 it measured no faster than the plain launches. */
+int cq_ctx_set_hip_graphs(cq_ctx* ctx, int on);
 /* RCCL communicator of the context (one process per GPU, xGMI within a node): rank 0 draws an id with
  * cq_rccl_unique_id and hands it to the other ranks by whatever means the application has (a torch.distributed
  * broadcast, MPI, a file); every rank then calls cq_ctx_comm_init_rccl -- collectively, it blocks until all have.  The

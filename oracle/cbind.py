@@ -45,6 +45,10 @@ def lib() -> C.CDLL:
         _lib.cqo_distribute_powers.argtypes = [vp, C.c_size_t, vp, vp]
         _lib.cqo_mul_periodic.argtypes = [vp, C.c_size_t, vp, C.c_size_t]
         _lib.cqo_cq_quotient_term.argtypes = [vp, vp, vp, vp, C.c_size_t, vp, vp]
+        _lib.cqo_pairing_product.restype = C.c_int
+        _lib.cqo_pairing_product.argtypes = [vp, vp, C.c_size_t, vp]
+        _lib.cqo_g2_mul.restype = C.c_int
+        _lib.cqo_g2_mul.argtypes = [vp, vp]
         _lib.cqo_num_threads.restype = C.c_int
         _lib.cqo_set_num_threads.argtypes = [C.c_int]
     return _lib
@@ -165,3 +169,26 @@ def create_proof(k, num_advice, lookups, table_values, table_qs, g, g_lagrange, 
     if rc != 0:
         raise RuntimeError(f"cqo_create_proof failed: {rc}")
     return bytes(proof[: plen.value])
+
+
+def pairing_product(g1_points, g2_scalars, want_value: bool = False):
+    """prod_i e(P_i, [k_i]_2) with one final exponentiation (cq_oracle.c, the pairing section): `g1_points` affine
+    (x, y) canonical ints or None, `g2_scalars` ints.  Returns True iff the product is one; with want_value also the
+    12 coefficients of the value (canonical ints, the basis of oracle/pairing.py's FQ12)."""
+    from . import bn254 as B
+
+    pts = np.zeros((len(g1_points), 8), dtype=np.uint64)
+    for i, pt in enumerate(g1_points):
+        if pt is not None:
+            pts[i] = B.points_to_mont_limbs([pt])[0]
+    ks = np.zeros((len(g2_scalars), 4), dtype=np.uint64)
+    for i, k in enumerate(g2_scalars):
+        k %= B.R_MOD
+        ks[i] = [(k >> (64 * j)) & 0xFFFFFFFFFFFFFFFF for j in range(4)]
+    out = np.zeros((12, 4), dtype=np.uint64)
+    ok = bool(lib().cqo_pairing_product(pts.ctypes.data, ks.ctypes.data, len(g1_points), out.ctypes.data))
+    if not want_value:
+        return ok
+    rinv = pow(1 << 256, -1, B.Q_MOD)
+    vals = [sum(int(out[c, j]) << (64 * j) for j in range(4)) * rinv % B.Q_MOD for c in range(12)]
+    return ok, vals

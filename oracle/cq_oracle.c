@@ -1070,3 +1070,315 @@ int cqo_create_proof(uint32_t k, uint32_t num_advice, uint32_t num_lookups, cons
   free(random_poly); free(h); free(adv_evals); free(h_poly); free(b0_polys); free(dom.t_evaluations);
   return 0;
 }
+
+/* ================================================================================================
+ * BN254 optimal ate pairing -- the acceptance oracle's closing equations with REAL pairings at any k
+ * (plonk/verifier.rs, static_lookup/verifier.rs:138-177, gwc/verifier.rs:76-128 end in pairing
+ * checks over halo2curves::bn256::Bn256, arithmetic/curves/src/bn256/engine.rs).
+ *
+ * This restates the PAIRING, in the formulation oracle/pairing.py already pins against the reference's constants
+ * and the properties its tests assert (engine.rs:662-762): Fq2 = Fq[i]/(i^2+1); Fq12 = Fq[w]/(w^12 - 18 w^6 + 82)
+ * with i = w^6 - 9 (xi = 9 + i = w^6); G2 untwisted into E(Fq12) by (x, y) -> (x w^2, y w^3); Miller loop over
+ * 6x+2, x = BN_X (engine.rs:18), plus the two Frobenius lines (engine.rs:430-441); final exponentiation as the plain
+ * power (q^12 - 1)/r.  Not the reference's tower arithmetic -- every use is "product of pairings == 1", invariant
+ * under the normalisation -- and not fast (about 20 ms per Miller loop), but ~100x the Python restatement, which
+ * tests/test_oracle_pairing.py compares it with value for value.
+ * ============================================================================================== */
+typedef struct { fe c[12]; } fq12;
+typedef struct { fe a, b; } fq2; /* a + b i */
+
+static fq12 fq12_zero(void) { fq12 r; memset(&r, 0, sizeof r); return r; }
+static fq12 fq12_one(void) { fq12 r = fq12_zero(); r.c[0] = f_one(Q); return r; }
+static int fq12_eq(const fq12* x, const fq12* y) { return memcmp(x, y, sizeof *x) == 0; } /* canonical Montgomery limbs */
+static int fq12_is_zero(const fq12* x) { fq12 z = fq12_zero(); return fq12_eq(x, &z); }
+static fq12 fq12_add(const fq12* x, const fq12* y) { fq12 r; for (int i = 0; i < 12; i++) r.c[i] = f_add(Q, x->c[i], y->c[i]); return r; }
+static fq12 fq12_sub(const fq12* x, const fq12* y) { fq12 r; for (int i = 0; i < 12; i++) r.c[i] = f_sub(Q, x->c[i], y->c[i]); return r; }
+static fq12 fq12_neg(const fq12* x) { fq12 r; for (int i = 0; i < 12; i++) r.c[i] = f_neg(Q, x->c[i]); return r; }
+static fq12 fq12_from_fq(fe v) { fq12 r = fq12_zero(); r.c[0] = v; return r; }
+/* schoolbook product, then w^e = 18 w^(e-6) - 82 w^(e-12) from the top down */
+static fq12 fq12_mul(const fq12* x, const fq12* y) {
+  fe b[23];
+  for (int i = 0; i < 23; i++) b[i] = f_zero();
+  for (int i = 0; i < 12; i++) {
+    if (f_is_zero(x->c[i])) continue;
+    for (int j = 0; j < 12; j++) b[i + j] = f_add(Q, b[i + j], f_mul(Q, x->c[i], y->c[j]));
+  }
+  const fe c18 = f_from_u64(Q, 18), c82 = f_from_u64(Q, 82);
+  for (int e = 22; e >= 12; e--) {
+    if (f_is_zero(b[e])) continue;
+    b[e - 6] = f_add(Q, b[e - 6], f_mul(Q, b[e], c18));
+    b[e - 12] = f_sub(Q, b[e - 12], f_mul(Q, b[e], c82));
+  }
+  fq12 r;
+  memcpy(r.c, b, sizeof r.c);
+  return r;
+}
+static fq12 fq12_pow(const fq12* x, const uint64_t* e, int words) {
+  fq12 acc = fq12_one();
+  int started = 0;
+  for (int w = words - 1; w >= 0; w--)
+    for (int bit = 63; bit >= 0; bit--) {
+      if (started) acc = fq12_mul(&acc, &acc);
+      if ((e[w] >> bit) & 1) {
+        acc = fq12_mul(&acc, x);
+        started = 1;
+      }
+    }
+  return acc;
+}
+/* inverse: the multiplication-by-x map is linear over Fq; solve M v = 1 by Gauss-Jordan (12 x 12) */
+static fq12 fq12_inv(const fq12* x) {
+  fe m[12][13];
+  fq12 col = *x; /* x * w^j */
+  fq12 wj = fq12_zero();
+  wj.c[1] = f_one(Q);
+  for (int j = 0; j < 12; j++) {
+    for (int i = 0; i < 12; i++) m[i][j] = col.c[i];
+    col = fq12_mul(&col, &wj);
+  }
+  for (int i = 0; i < 12; i++) m[i][12] = i == 0 ? f_one(Q) : f_zero();
+  for (int p = 0; p < 12; p++) {
+    int piv = p;
+    while (piv < 12 && f_is_zero(m[piv][p])) piv++;
+    if (piv == 12) return fq12_zero(); /* not invertible (x = 0) */
+    if (piv != p)
+      for (int j = 0; j < 13; j++) { fe t = m[p][j]; m[p][j] = m[piv][j]; m[piv][j] = t; }
+    const fe inv = f_inv(Q, m[p][p]);
+    for (int j = p; j < 13; j++) m[p][j] = f_mul(Q, m[p][j], inv);
+    for (int i = 0; i < 12; i++) {
+      if (i == p || f_is_zero(m[i][p])) continue;
+      const fe fct = m[i][p];
+      for (int j = p; j < 13; j++) m[i][j] = f_sub(Q, m[i][j], f_mul(Q, fct, m[p][j]));
+    }
+  }
+  fq12 r;
+  for (int i = 0; i < 12; i++) r.c[i] = m[i][12];
+  return r;
+}
+
+/* ---- Fq2 and G2 = E'(Fq2): y^2 = x^3 + 3/(9+i) (bn256/curve.rs:85-129) ---- */
+static fq2 fq2_add(fq2 x, fq2 y) { fq2 r = {f_add(Q, x.a, y.a), f_add(Q, x.b, y.b)}; return r; }
+static fq2 fq2_sub(fq2 x, fq2 y) { fq2 r = {f_sub(Q, x.a, y.a), f_sub(Q, x.b, y.b)}; return r; }
+static fq2 fq2_mul(fq2 x, fq2 y) {
+  fq2 r = {f_sub(Q, f_mul(Q, x.a, y.a), f_mul(Q, x.b, y.b)), f_add(Q, f_mul(Q, x.a, y.b), f_mul(Q, x.b, y.a))};
+  return r;
+}
+static fq2 fq2_inv(fq2 x) { /* conj / norm */
+  const fe nrm = f_inv(Q, f_add(Q, f_sqr(Q, x.a), f_sqr(Q, x.b)));
+  fq2 r = {f_mul(Q, x.a, nrm), f_neg(Q, f_mul(Q, x.b, nrm))};
+  return r;
+}
+static int fq2_eq(fq2 x, fq2 y) { return f_eq(x.a, y.a) && f_eq(x.b, y.b); }
+typedef struct { fq2 x, y; int inf; } g2aff;
+static const uint64_t G2_GEN_RAW[4][4] = { /* curve.rs:100-129, canonical limbs: x.c0, x.c1, y.c0, y.c1 */
+    {0x46DEBD5CD992F6EDull, 0x674322D4F75EDADDull, 0x426A00665E5C4479ull, 0x1800DEEF121F1E76ull},
+    {0x97E485B7AEF312C2ull, 0xF1AA493335A9E712ull, 0x7260BFB731FB5D25ull, 0x198E9393920D483Aull},
+    {0x4CE6CC0166FA7DAAull, 0xE3D1E7690C43D37Bull, 0x4AAB71808DCB408Full, 0x12C85EA5DB8C6DEBull},
+    {0x55ACDADCD122975Bull, 0xBC4B313370B38EF3ull, 0xEC9E99AD690C3395ull, 0x090689D0585FF075ull}};
+static fe fq_from_canonical(const uint64_t l[4]) { fe a, r2; memcpy(a.l, l, 32); memcpy(r2.l, FQ.r2, 32); return f_mul(Q, a, r2); }
+static g2aff g2_generator(void) {
+  g2aff g;
+  g.x.a = fq_from_canonical(G2_GEN_RAW[0]); g.x.b = fq_from_canonical(G2_GEN_RAW[1]);
+  g.y.a = fq_from_canonical(G2_GEN_RAW[2]); g.y.b = fq_from_canonical(G2_GEN_RAW[3]);
+  g.inf = 0;
+  return g;
+}
+static g2aff g2_double(g2aff p) {
+  if (p.inf) return p;
+  const fq2 x2 = fq2_mul(p.x, p.x);
+  const fq2 m = fq2_mul(fq2_add(fq2_add(x2, x2), x2), fq2_inv(fq2_add(p.y, p.y)));
+  g2aff r;
+  r.x = fq2_sub(fq2_mul(m, m), fq2_add(p.x, p.x));
+  r.y = fq2_sub(fq2_mul(m, fq2_sub(p.x, r.x)), p.y);
+  r.inf = 0;
+  return r;
+}
+static g2aff g2_add(g2aff p, g2aff q) {
+  if (p.inf) return q;
+  if (q.inf) return p;
+  if (fq2_eq(p.x, q.x)) {
+    if (fq2_eq(p.y, q.y)) return g2_double(p);
+    g2aff o = p; o.inf = 1; return o;
+  }
+  const fq2 m = fq2_mul(fq2_sub(q.y, p.y), fq2_inv(fq2_sub(q.x, p.x)));
+  g2aff r;
+  r.x = fq2_sub(fq2_sub(fq2_mul(m, m), p.x), q.x);
+  r.y = fq2_sub(fq2_mul(m, fq2_sub(p.x, r.x)), p.y);
+  r.inf = 0;
+  return r;
+}
+/* [k]_2, k canonical (kzg/commitment.rs:253-256 computes its G2 elements this way) */
+static g2aff g2_mul_gen(const uint64_t k[4]) {
+  g2aff acc = g2_generator(), base = acc;
+  acc.inf = 1;
+  for (int w = 0; w < 4; w++)
+    for (int b = 0; b < 64; b++) {
+      if ((k[w] >> b) & 1) acc = g2_add(acc, base);
+      base = g2_double(base);
+    }
+  return acc;
+}
+
+/* ---- E(Fq12), affine; `inf` marks the identity ---- */
+typedef struct { fq12 x, y; int inf; } e12;
+/* (x, y) -> (x w^2, y w^3), Fq2 embedded through i = w^6 - 9 */
+static e12 twist(g2aff p) {
+  e12 r;
+  r.inf = p.inf;
+  r.x = fq12_zero(); r.y = fq12_zero();
+  if (p.inf) return r;
+  const fe nine = f_from_u64(Q, 9);
+  /* x = (xa - 9 xb) + xb w^6, times w^2 */
+  r.x.c[2] = f_sub(Q, p.x.a, f_mul(Q, nine, p.x.b));
+  r.x.c[8] = p.x.b;
+  r.y.c[3] = f_sub(Q, p.y.a, f_mul(Q, nine, p.y.b));
+  r.y.c[9] = p.y.b;
+  return r;
+}
+/* one Miller step: line through r and s (tangent when equal) evaluated at (xt, yt), and r <- r + s; the slope's
+ * inversion is shared by the line and the point */
+static fq12 line_and_add(e12* r, const e12* s, const fq12* xt, const fq12* yt) {
+  fq12 m;
+  if (!fq12_eq(&r->x, &s->x)) {
+    fq12 dy = fq12_sub(&s->y, &r->y), dx = fq12_sub(&s->x, &r->x), dxi = fq12_inv(&dx);
+    m = fq12_mul(&dy, &dxi);
+  } else if (fq12_eq(&r->y, &s->y)) {
+    fq12 x2 = fq12_mul(&r->x, &r->x), x3 = fq12_add(&x2, &x2);
+    x3 = fq12_add(&x3, &x2);
+    fq12 y2 = fq12_add(&r->y, &r->y), y2i = fq12_inv(&y2);
+    m = fq12_mul(&x3, &y2i);
+  } else { /* vertical line: xt - x1; the sum is the identity */
+    fq12 l = fq12_sub(xt, &r->x);
+    r->inf = 1;
+    return l;
+  }
+  fq12 t1 = fq12_sub(xt, &r->x), t2 = fq12_sub(yt, &r->y);
+  fq12 l = fq12_mul(&m, &t1);
+  l = fq12_sub(&l, &t2);
+  fq12 nx = fq12_mul(&m, &m);
+  nx = fq12_sub(&nx, &r->x);
+  nx = fq12_sub(&nx, &s->x);
+  fq12 t3 = fq12_sub(&r->x, &nx), ny = fq12_mul(&m, &t3);
+  ny = fq12_sub(&ny, &r->y);
+  r->x = nx;
+  r->y = ny;
+  return l;
+}
+static const uint64_t ATE_LOOP[2] = {0x9d797039be763ba8ull, 0x1ull}; /* 6 * 4965661367192848881 + 2 = 29793968203157093288 */
+static fq12 miller_loop(g2aff q2, const aff* p1) {
+  if (q2.inf || aff_is_id(p1)) return fq12_one();
+  const e12 qq = twist(q2);
+  const fq12 xt = fq12_from_fq(p1->x), yt = fq12_from_fq(p1->y);
+  e12 r = qq;
+  fq12 f = fq12_one();
+  for (int i = 63; i >= 0; i--) { /* bit 64 is the leading one */
+    f = fq12_mul(&f, &f);
+    fq12 l = line_and_add(&r, &r, &xt, &yt);
+    f = fq12_mul(&f, &l);
+    if ((ATE_LOOP[0] >> i) & 1) {
+      l = line_and_add(&r, &qq, &xt, &yt);
+      f = fq12_mul(&f, &l);
+    }
+  }
+  /* Q1 = frobenius(Q), -Q2 = -frobenius^2(Q) as points of E(Fq12): coordinate-wise q-th powers */
+  e12 q1, nq2;
+  q1.inf = nq2.inf = 0;
+  q1.x = fq12_pow(&qq.x, FQ.mod, 4);
+  q1.y = fq12_pow(&qq.y, FQ.mod, 4);
+  nq2.x = fq12_pow(&q1.x, FQ.mod, 4);
+  nq2.y = fq12_pow(&q1.y, FQ.mod, 4);
+  nq2.y = fq12_neg(&nq2.y);
+  fq12 l = line_and_add(&r, &q1, &xt, &yt);
+  f = fq12_mul(&f, &l);
+  e12 r2 = r;
+  l = line_and_add(&r2, &nq2, &xt, &yt);
+  f = fq12_mul(&f, &l);
+  return f;
+}
+/* (q^12 - 1) / r as 64-bit words, least significant first: computed once by long arithmetic */
+static uint64_t FINAL_EXP[48];
+static int FINAL_EXP_WORDS = 0;
+static void final_exp_init(void) {
+  if (FINAL_EXP_WORDS) return;
+  /* q^12 by repeated multiplication on a 48-word integer */
+  uint64_t acc[49] = {1}, tmp[49];
+  for (int it = 0; it < 12; it++) {
+    memset(tmp, 0, sizeof tmp);
+    for (int i = 0; i < 48; i++) {
+      if (!acc[i]) continue;
+      uint64_t carry = 0;
+      for (int j = 0; j < 4 && i + j < 49; j++) {
+        u128 t = (u128)acc[i] * FQ.mod[j] + tmp[i + j] + carry;
+        tmp[i + j] = (uint64_t)t;
+        carry = (uint64_t)(t >> 64);
+      }
+      for (int j = i + 4; carry && j < 49; j++) {
+        u128 t = (u128)tmp[j] + carry;
+        tmp[j] = (uint64_t)t;
+        carry = (uint64_t)(t >> 64);
+      }
+    }
+    memcpy(acc, tmp, sizeof acc);
+  }
+  /* minus one (q^12 is odd), then long division by r, most significant word first */
+  acc[0] -= 1;
+  uint64_t quo[48];
+  uint64_t rem[5] = {0, 0, 0, 0, 0};
+  for (int w = 47; w >= 0; w--)
+    for (int b = 63; b >= 0; b--) {
+      /* rem = rem * 2 + bit */
+      uint64_t c = (acc[w] >> b) & 1;
+      for (int i = 0; i < 5; i++) { uint64_t n = (rem[i] << 1) | c; c = rem[i] >> 63; rem[i] = n; }
+      /* if rem >= r: rem -= r, quotient bit 1 */
+      int ge = rem[4] != 0;
+      if (!ge) {
+        ge = 1;
+        for (int i = 3; i >= 0; i--)
+          if (rem[i] != FR.mod[i]) { ge = rem[i] > FR.mod[i]; break; }
+      }
+      if (ge) {
+        uint64_t borrow = 0;
+        for (int i = 0; i < 4; i++) {
+          u128 t = (u128)rem[i] - FR.mod[i] - borrow;
+          rem[i] = (uint64_t)t;
+          borrow = (uint64_t)(t >> 64) & 1;
+        }
+        rem[4] -= borrow;
+        quo[w] = (b == 63 ? 0 : quo[w]) | ((uint64_t)1 << b);
+      } else if (b == 63) {
+        quo[w] = 0;
+      }
+    }
+  memcpy(FINAL_EXP, quo, sizeof quo);
+  FINAL_EXP_WORDS = 48;
+}
+static fq12 final_exponentiation(const fq12* f) {
+  final_exp_init();
+  return fq12_pow(f, FINAL_EXP, FINAL_EXP_WORDS);
+}
+
+/* e(P_i, [k_i]_2) for i < m, multiplied together, after ONE final exponentiation (`multi_miller_loop`,
+ * engine.rs:571-640): g1_affine = m x 8 Montgomery limbs ((0,0) = identity), g2_scalars = m x 4 canonical limbs.
+ * out12 (optional): the 12 coefficients of the result, Montgomery limbs.  Returns 1 iff the product is one. */
+int cqo_pairing_product(const uint64_t* g1_affine, const uint64_t* g2_scalars, size_t m, uint64_t* out12) {
+  fq12 f = fq12_one();
+  fq12* parts = (fq12*)malloc(sizeof(fq12) * (m ? m : 1));
+#pragma omp parallel for schedule(dynamic)
+  for (size_t i = 0; i < m; i++) {
+    aff p;
+    memcpy(&p, g1_affine + 8 * i, sizeof p);
+    parts[i] = miller_loop(g2_mul_gen(g2_scalars + 4 * i), &p);
+  }
+  for (size_t i = 0; i < m; i++) f = fq12_mul(&f, &parts[i]);
+  free(parts);
+  const fq12 r = final_exponentiation(&f), one = fq12_one();
+  if (out12) memcpy(out12, r.c, sizeof r.c);
+  return fq12_eq(&r, &one) && !fq12_is_zero(&f);
+}
+/* [k]_2 in affine coordinates (x.c0, x.c1, y.c0, y.c1: 4 x 4 Montgomery limbs); returns 0 for the identity */
+int cqo_g2_mul(const uint64_t k[4], uint64_t out[16]) {
+  const g2aff p = g2_mul_gen(k);
+  if (p.inf) { memset(out, 0, 128); return 0; }
+  memcpy(out, p.x.a.l, 32); memcpy(out + 4, p.x.b.l, 32); memcpy(out + 8, p.y.a.l, 32); memcpy(out + 12, p.y.b.l, 32);
+  return 1;
+}

@@ -107,11 +107,15 @@ class _FinalChecks:
     of oracle/pairing.py and the G2 elements a setup would publish ([1]_2, [s]_2, [T(s)]_2, [Z_V(s)]_2,
     [s^bound]_2; kzg/commitment.rs:253-256, static_lookup.rs:150-160)."""
 
-    def __init__(self, pairing: bool):
+    def __init__(self, pairing):
         self.pairing = pairing
         self._g2 = {}
 
     def holds(self, pairs) -> bool:
+        if self.pairing == "c":  # the same equations through the C restatement of the pairing (cq_oracle.c): any k in seconds
+            from . import cbind as OC
+
+            return OC.pairing_product([jac_to_affine(J) for J, _ in pairs], [k % P for _, k in pairs])
         if not self.pairing:
             acc = JAC_ID
             for J, k in pairs:
@@ -165,7 +169,9 @@ def verify_proof(proof: bytes, circuit, vk_repr: int, s: int, tables: dict, tabl
     srs_g1_len: the `srs_g1_len` handed to `StaticTableValues::commit` (static_lookup.rs:149).
     instances: the public inputs per instance column; fixed_commitments / perm_commitments: the
     verifying key's `fixed_commitments` and `permutation.commitments` (affine points).
-    pairing: check the closing equations with real pairings (slow; see _FinalChecks) instead of in G1.
+    pairing: check the closing equations with real pairings instead of in G1 (see _FinalChecks): True = the Python
+    restatement (oracle/pairing.py, smallest proofs only), "c" = the C restatement (oracle/cq_oracle.c), value-for-value
+    equal to the Python one and fast enough for any k.
     """
     cs = circuit
     dom = EvaluationDomain(cs.degree(), cs.k)

@@ -53,6 +53,7 @@ def _declare(lib):
     lib.cq_ctx_destroy.argtypes = [vp]
     lib.cq_ctx_create.argtypes = [C.c_int, vp, C.POINTER(vp)]
     lib.cq_ctx_sync.argtypes = [vp]
+    lib.cq_ctx_set_hip_graphs.argtypes = [vp, C.c_int]
     lib.cq_dev_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
     lib.cq_dev_free.argtypes = [vp, vp]
     lib.cq_dev_upload.argtypes = [vp, vp, vp, C.c_size_t]

@@ -947,6 +947,7 @@ def _ctx_comm_destroy(self):
     self._chk(self.lib.cq_ctx_comm_destroy(self.h))
 
 
+Context.set_hip_graphs = lambda self, on: self._chk(self.lib.cq_ctx_set_hip_graphs(self.h, 1 if on else 0))
 Context.comm_init_rccl = _ctx_comm_init_rccl
 Context.comm_init_from_torch = _ctx_comm_init_from_torch
 Context.comm_destroy = _ctx_comm_destroy

@@ -63,6 +63,7 @@ void cq_ctx_destroy(cq_ctx* c) {
   if (c->pinned_small) hipHostFree(c->pinned_small);
   cq::comm_rccl_destroy(c);
   if (c->pinned_comm) hipHostFree(c->pinned_comm);
+  for (auto& g : c->graphs) hipGraphExecDestroy(g.exec);
   if (c->prof_entries) hipHostFree(c->prof_entries);
   if (c->copy_done) hipEventDestroy(c->copy_done);
   if (c->copy_stream) hipStreamDestroy(c->copy_stream);
@@ -94,6 +95,12 @@ int cq_ctx_comm_selftest(cq_ctx* c) {
 int cq_ctx_comm_destroy(cq_ctx* c) {
   if (!c) return CQ_ERR_ARG;
   cq::comm_rccl_destroy(c);
+  return CQ_OK;
+}
+
+int cq_ctx_set_hip_graphs(cq_ctx* c, int on) {
+  if (!c) return CQ_ERR_ARG;
+  c->graphs_on = on ? 1 : 0;
   return CQ_OK;
 }
 

@@ -64,6 +64,21 @@ static __device__ __forceinline__ XYZZ29 load_xyzz29(const XYZZ* p) {
   ld8(&p->zzz, w); r.zzz = Fq29::unpack(w);
   return r;
 }
+// the same in two steps, so that a serial sum can have the next operand's 128 bytes in flight while it adds the current one
+struct XYZZRaw {
+  uint32_t w[32];
+};
+static __device__ __forceinline__ XYZZRaw load_xyzz_raw(const XYZZ* p) {
+  XYZZRaw r;
+  ld8(&p->x, r.w);
+  ld8(&p->y, r.w + 8);
+  ld8(&p->zz, r.w + 16);
+  ld8(&p->zzz, r.w + 24);
+  return r;
+}
+static __device__ __forceinline__ XYZZ29 unpack_xyzz29(const XYZZRaw& r) {
+  return {Fq29::unpack(r.w), Fq29::unpack(r.w + 8), Fq29::unpack(r.w + 16), Fq29::unpack(r.w + 24)};
+}
 static __device__ __forceinline__ void store_xyzz29(XYZZ* p, const XYZZ29& v) {
   uint32_t w[8];
   const Fq29 xr = v.x.reduced();  // < 2 p

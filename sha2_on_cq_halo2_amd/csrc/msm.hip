@@ -31,6 +31,7 @@
 //   6. host      : table mode returns one Jacobian point per MSM; plain mode W window sums per MSM, folded by a
 //                  Horner over windows (c doublings each) on the host.
 #include <algorithm>
+#include <cstdlib>
 #include "msm.hpp"
 #include "curve29.hpp"
 #include "ctx.hpp"
@@ -597,8 +598,14 @@ __global__ __launch_bounds__(256) void msm_combine_level_kernel(
     if (!__any(mine)) return;  // wave-uniform
     const uint32_t lo = mine ? off_prev[g] : 0;
     XYZZ29 acc = XYZZ29::identity();
-    if (mine)
-      for (uint32_t e = sub; e < tp; e += Q) xyzz29_add(acc, load_xyzz29(prev + lo + e));
+    if (mine && sub < tp) {  // the next partial sum is on its way while the current one is added
+      XYZZRaw nxt = load_xyzz_raw(prev + lo + sub);
+      for (uint32_t e = sub; e < tp; e += Q) {
+        const XYZZ29 cur = unpack_xyzz29(nxt);
+        if (e + Q < tp) nxt = load_xyzz_raw(prev + lo + e + Q);
+        xyzz29_add(acc, cur);
+      }
+    }
 #pragma unroll 1
     for (int delta = Q / 2; delta >= 1; delta >>= 1) {
       XYZZ29 o = xyzz29_shfl_down(acc, delta);  // all lanes take part in the shuffle
@@ -840,12 +847,9 @@ int msm_run(cq_ctx* ctx, const Fr* const* scalars_host_ptrs, const G1Affine* con
         }
     srcv.s[i] = alias[i];
   }
-  msm_set_ptrs_kernel<<<1, 64, 0, s>>>(sp, bp, stv, lnv, srcv, (const void**)d_scalars, batch);
   const uint64_t* d_strides = (const uint64_t*)((const void**)d_scalars + 2 * batch);
   const uint64_t* d_lens = (const uint64_t*)((const void**)d_scalars + 3 * batch);
   const uint64_t* d_src = (const uint64_t*)((const void**)d_scalars + 4 * batch);
-  // counts and buckets (identity = all zero) are adjacent: one memset
-  if (hipMemsetAsync(counts, 0, L.zero_end - L.off_counts, s) != hipSuccess) return -1;
   // Sub-list length of the accumulate level, from the expected load of a bucket (entries of the launch's longest
   // MSM / buckets).  Short lists keep a k = 18 launch (272 entries per bucket) parallel and balanced; with thousands
   // of entries per bucket there are lanes to spare, and the partial sums per bucket must stay few: past MSM_SHORT of
@@ -853,8 +857,19 @@ int msm_run(cq_ctx* ctx, const Fr* const* scalars_host_ptrs, const G1Affine* con
   // 32) cost 17 ms of a 133 ms proof.  (The workspace is sized for MSM_S1, the smallest value.)
   uint64_t load = 0;
   for (uint32_t i = 0; i < batch; i++) load = std::max<uint64_t>(load, (uint64_t)lens[i] * W / (L.Wb * M));
+  // (Longer sub-lists for the very large launches -- fewer partial sums for the combine, 2.6 ms of a k = 20 proof -- were
+  // swept at k = 20 and k = 22, 32..384 entries: the accumulate kernel loses what the combine gains, within 1 %.)
   const uint32_t s1 = load <= MSM_S1_BIG_LOAD ? MSM_S1 : std::max<uint32_t>(MSM_S1_BIG, (uint32_t)((load + MSM_PARTIALS_TARGET - 1) / MSM_PARTIALS_TARGET));
   const uint32_t* off0 = off;
+  // The launch in three segments: front (pointer tables, sort, plan), the accumulate kernel, tail (combine levels, bucket
+  // reduction).  Front and tail are a dozen and half a dozen small kernels whose arguments depend only on the launch's
+  // shape and buffers -- the same proof after proof for a given key -- so each is captured once as a hipGraph and replayed
+  // with a single hipGraphLaunch (BASELINE configs[4]: "hipGraph-captured rounds"); the accumulate kernel stays a plain
+  // launch between them so that the profiling events and the side-stream hand-over (msm_tail_event) bracket it.
+  auto front = [&]() -> int {
+  msm_set_ptrs_kernel<<<1, 64, 0, s>>>(sp, bp, stv, lnv, srcv, (const void**)d_scalars, batch);
+  // counts and buckets (identity = all zero) are adjacent: one memset
+  if (hipMemsetAsync(counts, 0, L.zero_end - L.off_counts, s) != hipSuccess) return -1;
   if (L.part_sort) {
     const uint32_t P = batch * L.npart;
     uint2* part_buf = (uint2*)(ws + L.off_ranks);
@@ -884,6 +899,17 @@ int msm_run(cq_ctx* ctx, const Fr* const* scalars_host_ptrs, const G1Affine* con
     msm_scan_apply_kernel<<<L.nblk, 256, 0, s>>>(counts, Bt, L.nseq, s1, blocksums, off, tk);
     msm_scatter_kernel<<<dim3((n + 255) / 256, batch), 256, 0, s>>>(d_scalars, d_lens, n, c, W, pre ? 1u : 0u, ranks, off0, sorted);
   }
+  return 0;
+  };
+  // everything the captured kernels' arguments are made of
+  std::vector<uint64_t> sig{(uint64_t)(uintptr_t)workspace, (uint64_t)(uintptr_t)window_sums_dev, n, c, batch, pre ? 1u : 0u, s1};
+  for (uint32_t i = 0; i < batch; i++) {
+    sig.push_back((uint64_t)(uintptr_t)scalars_host_ptrs[i]);
+    sig.push_back((uint64_t)(uintptr_t)bases_host_ptrs[i]);
+    sig.push_back((uint64_t)lens[i]);
+    sig.push_back(pre ? (uint64_t)table_strides[i] : 0);
+  }
+  if (ctx->run_graph(sig, 0, front) != 0) return -1;
   if (ctx->prof_on && ctx->prof_entries && ctx->prof_entries_n < cq_ctx::PROF_COUNTERS)
     (void)hipMemcpyAsync(ctx->prof_entries + ctx->prof_entries_n++, off0 + Bt, sizeof(uint32_t), hipMemcpyDeviceToHost, s);
   hipEvent_t pe = ctx->prof_begin(CQ_PROF_MSM_ACCUMULATE);
@@ -894,6 +920,7 @@ int msm_run(cq_ctx* ctx, const Fr* const* scalars_host_ptrs, const G1Affine* con
     (void)hipEventRecord(ctx->msm_tail_event, s);
     ctx->msm_tail_seq++;
   }
+  auto tail = [&]() -> int {
   for (uint32_t k = 1; k < L.levels; k++) {
     const uint32_t* t_prev = tk + (size_t)(k - 1) * Bt;
     const uint32_t* off_prev = off + (size_t)k * (Bt + 1);
@@ -915,6 +942,9 @@ int msm_run(cq_ctx* ctx, const Fr* const* scalars_host_ptrs, const G1Affine* con
   else
     msm_rowcol_kernel<16><<<dim3((L.rows + L.cols + 3) / 4, sets), 64, 0, s>>>(buckets, M, L.rows, L.cols, pairs);
   msm_weighted_kernel<<<MSM_SET_POINTS * sets, 64, 0, s>>>(pairs, L.rows, L.cols, window_sums_dev);
+  return 0;
+  };
+  if (ctx->run_graph(sig, 1, tail) != 0) return -1;
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

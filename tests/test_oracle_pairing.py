@@ -54,3 +54,42 @@ def test_my_test_shape_accepted_with_real_pairings():
         pass
     sh = CP.create_proof(params, pk, [[30, 6], [15, 3]], B.Xoshiro256ss(7), opener="shplonk")
     assert CV.verify_proof(sh.proof, circ, 424242, s, TV, 16, 16, opener="shplonk", pairing=True)
+
+
+def test_c_pairing_equals_the_python_restatement():
+    """oracle/cq_oracle.c's pairing section against oracle/pairing.py: the same Gt VALUES (coefficient for coefficient
+    in the Fq[w]/(w^12 - 18 w^6 + 82) basis) for random points, bilinearity and the product-is-one check through C, the
+    identity cases, and [k]_2 itself."""
+    import numpy as np
+
+    from oracle import cbind as OC
+
+    rng = B.Xoshiro256ss(0xC0DE)
+    for _ in range(2):
+        ka, kb = B.fr_random(rng), B.fr_random(rng)
+        ok, val = OC.pairing_product([_g1(ka)], [kb], want_value=True)
+        assert not ok and val == PR.pairing(_g1(ka), PR.g2_mul(kb)).c
+    # e(aP, bQ) e(-abP, Q) = 1; one unit off is not
+    a, b = B.fr_random(rng), B.fr_random(rng)
+    assert OC.pairing_product([_g1(a), _g1(-a * b)], [b, 1])
+    assert not OC.pairing_product([_g1(a), _g1(-a * b + 1)], [b, 1])
+    assert OC.pairing_product([None, _g1(3)], [5, 0])  # identities on either side contribute 1
+    out = np.zeros(16, dtype=np.uint64)
+    k = np.array([(b >> (64 * j)) & 0xFFFFFFFFFFFFFFFF for j in range(4)], dtype=np.uint64)
+    assert OC.lib().cqo_g2_mul(k.ctypes.data, out.ctypes.data) == 1
+    x, y = PR.g2_mul(b)
+    rinv = pow(1 << 256, -1, B.Q_MOD)
+    got = [sum(int(out[4 * c + j]) << (64 * j) for j in range(4)) * rinv % B.Q_MOD for c in range(4)]
+    assert got == [x.c[0], x.c[1], y.c[0], y.c[1]]
+
+
+def test_my_test_shape_accepted_with_c_pairings():
+    s, params, circ, pk, tsrs, tabs = _my_test_env()
+    tr = CP.create_proof(params, pk, [[30, 6], [15, 3]], B.Xoshiro256ss(7))
+    assert CV.verify_proof(tr.proof, circ, 424242, s, TV, 16, 16, pairing="c")
+    bad = bytearray(tr.proof)
+    bad[200] ^= 1
+    try:
+        assert not CV.verify_proof(bytes(bad), circ, 424242, s, TV, 16, 16, pairing="c")
+    except ValueError:
+        pass

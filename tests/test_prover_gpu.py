@@ -177,3 +177,27 @@ def test_batched_proofs_equal_single_proofs(ctx, lanes):
     with pytest.raises(CqError) as e:
         wl.pk.create_proof_batch([[c.ptr for c in cols] for cols in witnesses], [100 + i for i in range(B_)], lanes=lanes)
     assert e.value.code == -4
+
+
+def test_hip_graph_replay_gives_the_same_proofs(ctx):
+    """cq_ctx_set_hip_graphs: the MSM launches' kernel sequences captured as hipGraphs and replayed (first proof: capture,
+    later proofs: replay; another witness and seed through the same graphs) give the bytes of the plain launches."""
+    from sha2_on_cq_halo2_amd.sha_circuit import ShaCqWorkload
+
+    wl = ShaCqWorkload(ctx, 12, pairs=2)
+    plain = [wl.prove(seed=s) for s in (1, 2)]
+    ctx.set_hip_graphs(True)
+    try:
+        assert [wl.prove(seed=s) for s in (1, 2, 1)] == plain + plain[:1]
+        n = 1 << 12
+        col = wl.cols[0].download((n, 4))
+        col[5], col[9] = col[9].copy(), col[5].copy()  # another witness through the captured graphs
+        col1 = wl.cols[1].download((n, 4))
+        col1[5], col1[9] = col1[9].copy(), col1[5].copy()
+        wl.cols[0].upload(col)
+        wl.cols[1].upload(col1)
+        g = wl.prove(seed=1)
+    finally:
+        ctx.set_hip_graphs(False)
+    assert g == wl.prove(seed=1) and g != plain[0]
+    wl.close()

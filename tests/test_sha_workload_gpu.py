@@ -86,11 +86,11 @@ def test_proof_bytes_equal_c_reference_restatement(ctx, k, pairs):
     assert len(proof) == wl.pk.proof_size
 
 
-def _verify_workload_proof(wl, proof, seed_s):
+def _verify_workload_proof(wl, proof, seed_s, pairing=False):
     N = wl.cfg.size
     tv = {"dense": list(range(N)), "spread": [_spread(i) for i in range(N)]}
     circ = CP.CqCircuit(wl.k, 2 * wl.pairs, [[(2 * p, "dense"), (2 * p + 1, "spread")] for p in range(wl.pairs)])
-    return CV.verify_proof(proof, circ, 0xC0FFEE + wl.k, seed_s, tv, N, 1 << wl.k)
+    return CV.verify_proof(proof, circ, 0xC0FFEE + wl.k, seed_s, tv, N, 1 << wl.k, pairing=pairing)
 
 
 def test_k14_proof_is_accepted(ctx):
@@ -101,10 +101,13 @@ def test_k14_proof_is_accepted(ctx):
     proof = wl.prove(seed=3)
     s = (seed * 0x9E3779B97F4A7C15 + 12345) % B.R_MOD
     assert _verify_workload_proof(wl, proof, s)
+    # ... and with REAL pairings: the GWC opening and the three CQ equations of every lookup (7 pairing terms per lookup,
+    # static_lookup/verifier.rs:138-177) through the C restatement of the BN254 pairing
+    assert _verify_workload_proof(wl, proof, s, pairing="c")
     bad = bytearray(proof)
     bad[-1] ^= 0x01
     try:
-        assert not _verify_workload_proof(wl, bytes(bad), s)
+        assert not _verify_workload_proof(wl, bytes(bad), s, pairing="c")
     except ValueError:
         pass
 
@@ -122,6 +125,7 @@ def test_k18_proof_is_accepted_and_deterministic(ctx):
     assert p1 == p2 and p1 != p3
     s = (seed * 0x9E3779B97F4A7C15 + 12345) % B.R_MOD
     assert _verify_workload_proof(wl, p1, s)
+    assert _verify_workload_proof(wl, p1, s, pairing="c")  # real pairings at the BASELINE size
 
 
 @pytest.mark.parametrize("k", [20, 22])
