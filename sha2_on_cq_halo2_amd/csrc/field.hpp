@@ -361,10 +361,10 @@ struct Fp {
       CQ_UNROLL for (int i = 0; i < 7; i++) x[i] = (x[i] >> 1) | (x[i + 1] << 31);
       x[7] = (x[7] >> 1) | (top << 31);
     };
-    auto geq = [](const uint32_t* a, const uint32_t* b) {
-      for (int i = 7; i >= 0; i--)
-        if (a[i] != b[i]) return a[i] > b[i];
-      return true;
+    auto geq = [](const uint32_t* a, const uint32_t* b) {  // borrow-free form: no data-dependent indexing (registers, not scratch)
+      uint64_t br = 0;
+      CQ_UNROLL for (int i = 0; i < 8; i++) br = (((uint64_t)a[i] - b[i] - br) >> 32) & 1;
+      return br == 0;
     };
     auto sub_into = [](uint32_t* a, const uint32_t* b) -> uint32_t {  // a -= b, returns the borrow
       uint64_t br = 0;
@@ -397,8 +397,8 @@ struct Fp {
       }
     }
     Fp y;
-    const uint32_t* r = is_one(u) ? x1 : x2;
-    CQ_UNROLL for (int i = 0; i < 8; i++) y.v.l[i] = r[i];
+    const bool from_u = is_one(u);  // (selected by value: a pointer to one of two local arrays would put both in scratch memory)
+    CQ_UNROLL for (int i = 0; i < 8; i++) y.v.l[i] = from_u ? x1[i] : x2[i];
     return y * r3();
   }
 };

@@ -41,8 +41,10 @@ __global__ void fr_powers_kernel(Fr* out, Fr base, uint64_t step, uint32_t count
 // product per pass, at the STORE: times the next pass's twiddle (or 1) between passes -- so the scratch holds values
 // below 2 p, packed -- and times the output factor in the last pass, where the constant is the factor's R = 2^256
 // limbs, which turns R' form into the caller's R form in the same product.  The first pass converts on load the
-// same way (times 2^266, or z 2^266 for the coset shift).  Results are the same field elements as before, stored
-// canonically.
+// same way (times z 2^266) only when it has a coset shift to apply; otherwise it does not touch the input: the limbs of
+// a R = 2^256 value a R ARE the R' = 2^261 value of a / 32, the whole transform is linear, and the missing factor 32 is
+// folded into the last pass's output constant on the host (ntt_run) -- one product per element and transform less.
+// Results are the same field elements as before, stored canonically.
 static __device__ __forceinline__ Fr29 lds_load29(const uint32_t* sm, uint32_t E, uint32_t i) {
   Fr29 r;
   CQ_UNROLL for (int l = 0; l < 9; l++) r.a[l] = sm[l * E + i];
@@ -101,13 +103,21 @@ static __device__ __forceinline__ uint32_t bitrev(uint32_t x, uint32_t bits) {
   return bits ? (__brev(x) >> (32 - bits)) : 0;
 }
 
+// DEG / LOG_T != 0: the pass's shape is a compile-time constant (the shapes the BASELINE sizes use are instantiated:
+// the butterfly levels unroll, the level's bound K p and every LDS offset become immediates); 0: read from the arguments.
+template <uint32_t DEG, uint32_t LOG_T>
 __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(NttPassArgs a) {
   extern __shared__ uint32_t smem29[];
-  const uint32_t D = 1u << a.deg;
-  const uint32_t T = 1u << a.log_t;
+  constexpr bool DYN = DEG == 0;
+  const uint32_t deg = DYN ? a.deg : DEG, log_t = DYN ? a.log_t : LOG_T;
+  const uint32_t D = 1u << deg;
+  const uint32_t T = 1u << log_t;
   const uint32_t E = D * T;
+  uint32_t* const tw29 = smem29 + 9 * E;  // the pass's D / 2 butterfly roots, unpacked: nine planes of D / 2 words
+  uint32_t* const cl29 = tw29 + 9 * (D / 2 + 1);  // per-residue (g mod 3) constants of the load, then of the store: 2 x 3 x 9
+  uint32_t* const cs29 = cl29 + 27;               // words (in LDS: as private arrays indexed by g mod 3 they lived in scratch)
   const uint32_t n = 1u << a.log_n;
-  const uint32_t t = n >> a.deg;
+  const uint32_t t = n >> deg;
   const uint32_t p = 1u << a.lgp;
   const uint32_t tile = blockIdx.x;
   const uint32_t batch = blockIdx.y;
@@ -119,41 +129,54 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(NttPassArgs a) {
   // ---- load tile: element (row i, col c) <- in[index0 + c + i*t] ----
   // first pass: R form -> R' form (times 2^266), with the coset factor zeta^(g mod 3) folded into the constant;
   // later passes: the previous pass already applied this pass's twiddle and left R' values below 2 p
-  Fr29 cload[3];
-  if (first) {
-    cload[0] = const29(CONSTS29<FrP>.from256);
-    if (a.flags & NTT_IN_COSET) {
-      const Fr29 k271 = const29(CONSTS29<FrP>.c271);
-      cload[1] = Fr29::mul(Fr29::unpack(a.in_coset[0].v.l), k271);  // z 2^266, < 2 p
-      cload[2] = Fr29::mul(Fr29::unpack(a.in_coset[1].v.l), k271);
-    } else {
-      cload[1] = cload[2] = cload[0];
-    }
+  const bool load_mul = first && (a.flags & NTT_IN_COSET);
+  if (load_mul && threadIdx.x < 3) {
+    Fr29 cl = const29(CONSTS29<FrP>.from256);
+    if (threadIdx.x) cl = Fr29::mul(Fr29::unpack(a.in_coset[threadIdx.x - 1].v.l), const29(CONSTS29<FrP>.c271));  // z 2^266, < 2 p
+    CQ_UNROLL for (int l = 0; l < 9; l++) cl29[threadIdx.x * 9 + l] = cl.a[l];
+  }
+  if (last && threadIdx.x >= 64 && threadIdx.x < 67) {
+    // R' -> R with the output factor: the constant is the factor's own R = 2^256 limbs (1 -> R mod p)
+    const uint32_t m = threadIdx.x - 64;
+    const Fr one = Fr::one();
+    const uint32_t* src = (a.flags & NTT_OUT_MUL) ? ((a.flags & NTT_OUT_COSET) ? a.out_mul[m].v.l : a.out_mul[0].v.l) : one.v.l;
+    const Fr29 cm = Fr29::unpack(src);
+    CQ_UNROLL for (int l = 0; l < 9; l++) cs29[m * 9 + l] = cm.a[l];
+  }
+  if (load_mul) __syncthreads();
+  const uint32_t half = D >> 1;
+  for (uint32_t j = threadIdx.x; j < half; j += NTT_THREADS) {  // roots (w_n^(n / D))^j, j < D / 2 (canonical, K = 1)
+    const Fr29 w = g_load29(a.pq + ((size_t)j << a.pq_shift));
+    CQ_UNROLL for (int l = 0; l < 9; l++) tw29[l * half + j] = w.a[l];
   }
   for (uint32_t e = threadIdx.x; e < E; e += NTT_THREADS) {
     const uint32_t c = e & (T - 1);
-    const uint32_t i = e >> a.log_t;
+    const uint32_t i = e >> log_t;
     const uint32_t g = index0 + c + i * t;
     Fr29 x = Fr29::zero();
     if (g < a.in_len) {
-      x = g_load29(in + g);
-      if (first) {
-        const uint32_t m = (a.flags & NTT_IN_COSET) ? g % 3 : 0;
-        x = Fr29::mul(x, m == 0 ? cload[0] : (m == 1 ? cload[1] : cload[2]));  // 1 * 2
-      }
+      x = g_load29(in + g);  // without a coset shift: canonical limbs read as the R' value of a / 32 (< p)
+      if (load_mul) x = Fr29::mul(x, lds_load29(cl29 + (g % 3) * 9, 1, 0));  // 1 * 2
     }
     lds_store29(smem29, E, i * T + c, x);
   }
   __syncthreads();
 
   // ---- 2^deg-point DIF in LDS, all T columns at once ----
-  const uint32_t half = D >> 1;
-  for (uint32_t rnd = 0; rnd < a.deg; rnd++) {
+#pragma unroll
+  for (uint32_t rnd = 0; rnd < (DYN ? 6u : DEG); rnd++) {
+    if (DYN && rnd >= deg) break;
     const uint32_t bit = half >> rnd;
+    // Work item w -> (butterfly b, column c) with the butterfly's root index di = b mod bit in the HIGH bits of w: the
+    // items of a wave then share di, and the waves with di = 0 (root 1: half the butterflies of the second-to-last level,
+    // a quarter of the one before, ...) skip the product instead of paying for it through divergence -- about one of the
+    // pass's six levels of products in all.
+    const uint32_t lg_rest = rnd;  // log2(half / bit): the bits of b above di
     for (uint32_t w = threadIdx.x; w < half * T; w += NTT_THREADS) {
       const uint32_t c = w & (T - 1);
-      const uint32_t b = w >> a.log_t;
-      const uint32_t di = b & (bit - 1);
+      const uint32_t wb = w >> log_t;
+      const uint32_t di = wb >> lg_rest;
+      const uint32_t b = ((wb & ((1u << lg_rest) - 1u)) * bit) | di;
       const uint32_t i0 = (b << 1) - di;
       const uint32_t i1 = i0 + bit;
       const Fr29 u = lds_load29(smem29, E, i0 * T + c);
@@ -161,7 +184,7 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(NttPassArgs a) {
       Fr29 s = u + v;  // < 2 B_r p
       s.normalise();
       Fr29 d = sub_level(u, v, rnd);  // < 2 B_r p
-      if (di) d = Fr29::mul(d, g_load29(a.pq + ((size_t)(di << rnd) << a.pq_shift)));  // 2 B_r * 1 <= 128
+      if (di) d = Fr29::mul(d, lds_load29(tw29, half, di << rnd));  // 2 B_r * 1 <= 128
       lds_store29(smem29, E, i0 * T + c, s);
       lds_store29(smem29, E, i1 * T + c, d);
     }
@@ -169,34 +192,19 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(NttPassArgs a) {
   }
 
   // ---- store: output digit i' (bit-reversed LDS row) -> out[((index-k)<<deg) + k + i'*p], through one product ----
-  Fr29 cstore[3];
-  if (last) {
-    // R' -> R with the output factor: the constant is the factor's own R = 2^256 limbs (1 -> R mod p)
-    if (a.flags & NTT_OUT_MUL) {
-      cstore[0] = Fr29::unpack(a.out_mul[0].v.l);
-      if (a.flags & NTT_OUT_COSET) {
-        cstore[1] = Fr29::unpack(a.out_mul[1].v.l);
-        cstore[2] = Fr29::unpack(a.out_mul[2].v.l);
-      } else {
-        cstore[1] = cstore[2] = cstore[0];
-      }
-    } else {
-      cstore[0] = cstore[1] = cstore[2] = Fr29::unpack(Fr::one().v.l);
-    }
-  }
-  const uint32_t lgp2 = a.lgp + a.deg;          // the next pass: p' = 2^lgp2, t' = n >> next_deg
+  const uint32_t lgp2 = a.lgp + deg;            // the next pass: p' = 2^lgp2, t' = n >> next_deg
   const uint32_t log_t2 = a.log_n - a.next_deg;
   for (uint32_t e = threadIdx.x; e < E; e += NTT_THREADS) {
     const uint32_t c = e & (T - 1);
-    const uint32_t i = e >> a.log_t;
+    const uint32_t i = e >> log_t;
     const uint32_t index = index0 + c;
     const uint32_t k = index & (p - 1);
-    const uint32_t g = ((index - k) << a.deg) + k + i * p;
+    const uint32_t g = ((index - k) << deg) + k + i * p;
     if (g >= a.out_len) continue;
-    const Fr29 x = lds_load29(smem29, E, bitrev(i, a.deg) * T + c);  // < 128 p
+    const Fr29 x = lds_load29(smem29, E, bitrev(i, deg) * T + c);  // < 128 p
     if (last) {
       const uint32_t m = (a.flags & NTT_OUT_COSET) ? g % 3 : 0;
-      g_store29(out + g, Fr29::mul(x, m == 0 ? cstore[0] : (m == 1 ? cstore[1] : cstore[2])), true);
+      g_store29(out + g, Fr29::mul(x, lds_load29(cs29 + m * 9, 1, 0)), true);
       continue;
     }
     // twiddle of the next pass for the element it will read at g: row i2 = g / t', index2 = g mod t',
@@ -310,21 +318,26 @@ int ntt_run(const NttTables& tb, const Fr* in, Fr* out, Fr* scratch, const NttIo
     }
     if (last) {
       a.out_len = io.out_len;
-      if (io.out_mul) {
+      // a transform without a coset shift on its way in ran on a / 32 (see "arithmetic of the passes")
+      const Fr fix = io.in_coset ? Fr::one() : Fr::from_u64(32);
+      if (io.out_mul || !io.in_coset) {
         a.flags |= NTT_OUT_MUL;
-        a.out_mul[0] = io.out_mul_v[0];
-        if (io.out_coset) {
+        a.out_mul[0] = (io.out_mul ? io.out_mul_v[0] : Fr::one()) * fix;
+        if (io.out_mul && io.out_coset) {
           a.flags |= NTT_OUT_COSET;
-          a.out_mul[1] = io.out_mul_v[1];
-          a.out_mul[2] = io.out_mul_v[2];
+          a.out_mul[1] = io.out_mul_v[1] * fix;
+          a.out_mul[2] = io.out_mul_v[2] * fix;
         }
       }
     }
     const uint32_t T = 1u << log_t;
     dim3 grid(t / T, io.batch);
-    const size_t lds = (size_t)(T << degs[ps]) * 36;  // nine 32-bit limb planes
+    const size_t lds = ((size_t)(T << degs[ps]) + ((size_t)1 << degs[ps]) / 2 + 1) * 36 + 54 * 4;  // nine 32-bit limb planes: tile + roots; constants
     hipEvent_t pe = io.prof ? io.prof->prof_begin(CQ_PROF_NTT_PASS) : nullptr;
-    ntt_pass_kernel<<<grid, NTT_THREADS, lds, stream>>>(a);
+    if (degs[ps] == 6 && log_t == 4) ntt_pass_kernel<6, 4><<<grid, NTT_THREADS, lds, stream>>>(a);
+    else if (degs[ps] == 5 && log_t == 5) ntt_pass_kernel<5, 5><<<grid, NTT_THREADS, lds, stream>>>(a);
+    else if (degs[ps] == 4 && log_t == 6) ntt_pass_kernel<4, 6><<<grid, NTT_THREADS, lds, stream>>>(a);
+    else ntt_pass_kernel<0, 0><<<grid, NTT_THREADS, lds, stream>>>(a);
     if (io.prof) io.prof->prof_end(pe);
     src = dst;
     lgp += degs[ps];

@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256) void kate_fill_kernel(const Fr* __restrict__ a
 // strided (coalesced) elements.  Each lane keeps its elements in registers, parks the running prefix products in
 // the output array, the lane totals are scanned in LDS (prefix and suffix), lane 0 inverts the block total, and
 // every lane unwinds its own elements: ~5 products per element + one inversion per 4096 elements.
-constexpr int BI_PER_LANE = 16;
+constexpr int BI_PER_LANE = 16;  // (4 -- four workgroups per CU -- was tried: 290 -> 334 us at 2^20 elements; the lone-lane inversions, now four per CU, are what the kernel waits for)
 static __device__ __forceinline__ void bi_put(uint4* lo, uint4* hi, uint32_t t, const Fr& v) {
   lo[t] = make_uint4(v.v.l[0], v.v.l[1], v.v.l[2], v.v.l[3]);
   hi[t] = make_uint4(v.v.l[4], v.v.l[5], v.v.l[6], v.v.l[7]);
