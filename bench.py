@@ -36,8 +36,8 @@ MSM_BYTES_PER_SCALAR = 96  # 32 B scalar + 64 B affine base
 NTT_BYTES_PER_ELEM = 64  # read once + write once
 CPU_BASELINE_K = 18  # the metric's own configuration, proven once by the CPU restatement (~30 s on 16 threads)
 CPU_BASELINE_SMALL_K = 16  # kept beside it: BASELINE configs[1] (16 SHA blocks)
-PMC_TRAFFIC_FILE = "profiles/r01_pmc_traffic_k18_proof.json"
-PMC_SQ_FILE = "profiles/r01_pmc_sq_accumulate_k18.json"
+PMC_TRAFFIC_FILE = "profiles/r02_pmc_traffic_k18_proof.json"
+PMC_SQ_FILE = "profiles/r02_pmc_sq_accumulate_k18.json"
 
 
 def main():
@@ -245,7 +245,7 @@ def _finish_line(out, ctx, wl, args, k, acc_ms, acc_calls, ntt_ms, ntt_calls, ms
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": ntt_ach / HBM_PEAK_GBS,
-            "traffic": pmc_traffic("ntt_pass_kernel") if k == 18 else None,
+            "traffic": pmc_traffic("ntt_pass_kernel<6u, 4u>") if k == 18 else None,  # the 2^18 transform's passes
             "traffic_source": f"{PMC_TRAFFIC_FILE} (committed rocprofv3 --pmc pass, not this run)" if k == 18 else None,
             "error": sa_error,
             "launches": int(sa_calls),
@@ -402,7 +402,11 @@ def pmc_traffic(kernel):
     path = os.path.join(ROOT, PMC_TRAFFIC_FILE)
     try:
         with open(path) as f:
-            return json.load(f)["cq::" + kernel]["hbm_bytes_per_launch_raw"]
+            d = json.load(f)
+        for key in ("cq::" + kernel, "void cq::" + kernel):
+            if key in d:
+                return d[key]["hbm_bytes_per_launch_raw"]
+        return None
     except Exception:
         return None
 

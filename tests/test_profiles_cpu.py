@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_pmc_summaries_parse():
     t = bench.pmc_traffic("msm_accumulate_kernel")
     assert t is not None and t > 1e8  # hundreds of MB per launch
-    assert bench.pmc_traffic("ntt_pass_kernel") > 1e7
+    assert bench.pmc_traffic("ntt_pass_kernel<6u, 4u>") > 1e7
     u = bench.pmc_valu_issue()
     assert u is not None and 0.5 < u <= 1.0
 
