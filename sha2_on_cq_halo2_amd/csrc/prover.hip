@@ -17,6 +17,7 @@
 #include <array>
 #include <atomic>
 #include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <thread>
@@ -166,8 +167,21 @@ struct Commit {
   int end(std::vector<G1Affine>& out) {
     cq_ctx* c = pk->ctx;
     std::vector<uint64_t> jac(count * 12);
+    static const bool trace_host = getenv("CQ_TRACE_HOST") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
+    if (trace_host) hipStreamSynchronize(c->stream);
+    const auto t1 = std::chrono::steady_clock::now();
     int rc = msm_multi_end(c, pend, jac.data());
     if (rc != CQ_OK) return rc;
+    const auto t2 = std::chrono::steady_clock::now();
+    struct Report {
+      bool on; std::chrono::steady_clock::time_point a, b, c_;
+      ~Report() {
+        if (on) fprintf(stderr, "[cq host]   commit end: wait %.1f us, fold %.1f us, exchange + normalise %.1f us\n",
+                        std::chrono::duration<double, std::micro>(b - a).count(), std::chrono::duration<double, std::micro>(c_ - b).count(),
+                        std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - c_).count());
+      }
+    } report{trace_host, t0, t1, t2};
     std::vector<G1Jac> j(count);
     if (pk->sharded()) {
       // all-gather of count x 96 B per rank, then the local EC sum (not an RCCL reduction op)
@@ -485,6 +499,12 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, const uint64_
   hipStream_t s = c->stream;
   Rng rng{rng_next, rng_state, pk->rng_fill, &c->pool()};
   Transcript tr;
+  // CQ_TRACE_HOST=1: microseconds since the start of the proof at the host's milestones, on stderr (development aid)
+  static const bool trace_host = getenv("CQ_TRACE_HOST") != nullptr;
+  const auto t_start = std::chrono::steady_clock::now();
+  auto mark = [&](const char* what) {
+    if (trace_host) fprintf(stderr, "[cq host] %8.1f us  %s\n", std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_start).count(), what);
+  };
 
   // ---- carve the arena --------------------------------------------------------------------------
   void* arena_v;
@@ -762,9 +782,11 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, const uint64_
     drawer.start(c, &rng, (uint64_t*)pin, rng_dev, 8 * n);
     }
     // batch_normalize (:363-366), write (:370-374)
+    mark("advice launch queued");
     if (!sc.empty()) {
       std::vector<G1Affine> pts;
       CQ_TRY(adv_cm.end(pts));
+      mark("advice commitments on the host");
       if (early_m) CQ_TRY(lookup_error());
       for (size_t j = 0; j < AC; j++)
         if (!tr.write_point(pts[j])) return c->fail(CQ_ERR_TRANSCRIPT, "advice commitment is the identity");
@@ -779,6 +801,7 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, const uint64_
   }
   if (NC) CQ_HIP(c, hipMemcpyAsync(B.challenges, user_challenges.data(), NC * sizeof(Fr), hipMemcpyHostToDevice, s));
   const Fr theta = tr.squeeze();  // :472
+  mark("theta");
 
   // ---- legacy lookups: commit_permuted (lookup/prover.rs:57-160) ---------------------------------------------
   auto plk_buf = [&](size_t l, int which) { return B.plk + (l * 5 + which) * n; };  // 0 A, 1 S, 2 a', 3 s', 4 z
@@ -916,6 +939,7 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, const uint64_
       if (!tr.write_point(early_m ? m_commitments[l] : cm[m_first + l])) return c->fail(CQ_ERR_TRANSCRIPT, "m commitment is the identity");
     }
   }
+  mark("round 1 written");
   const Fr beta = tr.squeeze();   // prover.rs:529
   const Fr gamma = tr.squeeze();  // :532
   const Fr beta_inv = beta.inv();
@@ -1085,7 +1109,9 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, const uint64_
         CQ_TRY(fork.end());
       }
       if (random_late) CQ_TRY(finish_random_poly());  // queued behind the launch above
+      mark("round 2 queued");
       CQ_TRY(r2cm.end(r2));
+      mark("round 2 commitments on the host");
       if (random_late) {
         std::vector<G1Affine> rc;
         CQ_TRY(commit_batch(pk, {random_poly}, {pk->params->g}, n, rc));
@@ -1118,6 +1144,7 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, const uint64_
   // ---- vanishing::Argument::commit (vanishing/prover.rs:37-65): drawn and committed above ---------
   if (!tr.write_point(random_cm)) return c->fail(CQ_ERR_TRANSCRIPT, "random poly commitment is the identity");
   const Fr y = tr.squeeze();  // prover.rs:584
+  mark("y");
 
   // advice polys (lagrange_to_coeff, :587-603) and the cosets of advice / instance / b / f were computed on the side
   // stream under the round-1 and round-2 launches
@@ -1241,6 +1268,7 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, const uint64_
       if (!tr.write_point(p)) return c->fail(CQ_ERR_TRANSCRIPT, "h piece commitment is the identity");
   }
   const Fr x = tr.squeeze();  // prover.rs:629
+  mark("x");
   const Fr xn = x.pow_u64(n);
 
   // ---- evaluations (prover.rs:654-719) and opening queries (:721-773) ------------------------------------
@@ -1522,6 +1550,7 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, const uint64_
     for (auto& w : o)
       if (!tr.write_point(w)) return c->fail(CQ_ERR_TRANSCRIPT, "opening witness commitment is the identity");
   }
+  mark("done");
   proof_out.swap(tr.proof);
   return CQ_OK;
 }
