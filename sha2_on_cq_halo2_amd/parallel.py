@@ -1,11 +1,14 @@
 """Multi-GPU sharding of the commitment path (one process per GPU, torch.distributed; the "nccl"
 backend is RCCL over xGMI on ROCm, "gloo" in the CPU tests).
 
-The path shards without any data-path collective along two axes:
-  * independent proofs / independent columns -> `column_owner`;
+The path shards along two axes; the prover's own sharding lives in the library
+(`ProvingKey.set_sharding`: cq_pk_set_sharding / cq_pk_set_column_sharding, csrc/comm.hip), this module holds the same
+rules for host code and tests:
   * the (scalar, base) index range of ONE multiexp -> `shard_range` + `sharded_multiexp`, whose only
     exchange is an all-gather of one 96-byte Jacobian partial per rank followed by a local EC sum
-    (EC addition is not a reduction op RCCL offers, so "all-reduce" = all-gather + local sum).
+    (EC addition is not a reduction op RCCL offers, so "all-reduce" = all-gather + local sum);
+  * a batch of independent column transforms -> `column_owner`: contiguous ranges of columns per rank (the same
+    `shard_range` over the batch), outputs broadcast from their owner.
 `backend` is any object with `best_multiexp(coeffs, bases) -> uint64[12]` and
 `g1_sum(points uint64[m,12]) -> uint64[12]`; in production that is `GpuBackend(Context)`.
 """
@@ -23,9 +26,14 @@ def shard_range(n: int, rank: int, world: int):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def column_owner(column: int, world: int) -> int:
-    """Round-robin owner of an independent column transform / commitment."""
-    return column % world
+def column_owner(column: int, batch: int, world: int) -> int:
+    """Owner rank of column `column` of a batch of `batch` independent column transforms: the rank whose
+    `shard_range(batch, rank, world)` holds it (what `sharded_transform` in csrc/prover.hip uses)."""
+    for r in range(world):
+        lo, hi = shard_range(batch, r, world)
+        if lo <= column < hi:
+            return r
+    raise IndexError(column)
 
 
 class GpuBackend:

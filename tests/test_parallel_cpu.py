@@ -39,7 +39,7 @@ for n in (1, 2, 7, 200):
 t = torch.tensor([1.0 + rank], dtype=torch.float64)
 dist.all_reduce(t, op=dist.ReduceOp.MAX)
 assert float(t.item()) == float(world)
-assert [column_owner(c, world) for c in range(4)] == [c %% world for c in range(4)]
+assert [column_owner(c, 8, world) for c in range(8)] == [0, 0, 0, 0, 1, 1, 1, 1] and [column_owner(c, 3, world) for c in range(3)] == [0, 0, 1]
 dist.barrier()
 dist.destroy_process_group()
 sys.stdout.write("rank %%d ok\n" %% rank); sys.stdout.flush()
