@@ -764,7 +764,7 @@ MsmLayout::MsmLayout(uint32_t n_, uint32_t c_, uint32_t batch_, bool pre_) : n(n
   Bt = batch * B;
   levels = 1;
   {
-    uint64_t cap = MSM_S1;
+    uint64_t cap = msm_small_launch_s1((uint64_t)batch * W * n);
     const uint64_t maxlist = pre ? (uint64_t)n * W : n;  // longest possible bucket list
     while (cap < maxlist) { cap *= MSM_S2; levels++; }
   }
@@ -793,7 +793,8 @@ MsmLayout::MsmLayout(uint32_t n_, uint32_t c_, uint32_t batch_, bool pre_) : n(n
   // partial sums: level 1 has at most ceil(E/S1) + Bt sub-lists; level k >= 2 only reserves slots for lists of more
   // than MSM_SHORT_MIN items, so at most items/S2 + items/SHORT_MIN + 1 sub-lists
   for (uint32_t k = 0; k < 8; k++) tmax[k] = 0;
-  tmax[0] = (E + MSM_S1 - 1) / MSM_S1 + Bt;
+  const uint32_t s1_min = msm_small_launch_s1(E);  // MSM_S1 unless the launch is small (msm.hpp)
+  tmax[0] = (E + s1_min - 1) / s1_min + Bt;
   for (uint32_t k = 1; k < levels; k++) tmax[k] = tmax[k - 1] / MSM_S2 + tmax[k - 1] / MSM_SHORT_MIN + 1;
   off_part[0] = o;
   o = up(o + (size_t)tmax[0] * sizeof(XYZZ));
@@ -859,7 +860,8 @@ int msm_run(cq_ctx* ctx, const Fr* const* scalars_host_ptrs, const G1Affine* con
   for (uint32_t i = 0; i < batch; i++) load = std::max<uint64_t>(load, (uint64_t)lens[i] * W / (L.Wb * M));
   // (Longer sub-lists for the very large launches -- fewer partial sums for the combine, 2.6 ms of a k = 20 proof -- were
   // swept at k = 20 and k = 22, 32..384 entries: the accumulate kernel loses what the combine gains, within 1 %.)
-  const uint32_t s1 = load <= MSM_S1_BIG_LOAD ? MSM_S1 : std::max<uint32_t>(MSM_S1_BIG, (uint32_t)((load + MSM_PARTIALS_TARGET - 1) / MSM_PARTIALS_TARGET));
+  const uint32_t s1 = load <= MSM_S1_BIG_LOAD ? msm_small_launch_s1((uint64_t)batch * W * n)
+                                              : std::max<uint32_t>(MSM_S1_BIG, (uint32_t)((load + MSM_PARTIALS_TARGET - 1) / MSM_PARTIALS_TARGET));
   const uint32_t* off0 = off;
   // The launch in three segments: front (pointer tables, sort, plan), the accumulate kernel, tail (combine levels, bucket
   // reduction).  Front and tail are a dozen and half a dozen small kernels whose arguments depend only on the launch's

@@ -27,6 +27,17 @@ constexpr uint32_t MSM_S1_BIG_LOAD = CQ_MSM_S1_BIG_LOAD;
 #endif
 constexpr uint32_t MSM_PARTIALS_TARGET = CQ_MSM_PARTIALS_TARGET;  // partial sums per bucket aimed at under heavy load (< MSM_SHORT)
 static_assert(MSM_S1_BIG >= MSM_S1, "the workspace is sized for MSM_S1");
+// Small launches (fewer than MSM_SMALL_LANES sub-lists of MSM_S1 entries): shorter sub-lists, down to MSM_S1_MIN, so that
+// the accumulate kernel -- a chain of dependent additions per lane, ~7 us each -- has a lane per few entries instead of
+// 17-24 of them on a fraction of the SIMDs (k = 14: one 16 384-term MSM was 140 us of pure latency).  A function of the
+// launch's entry BOUND (batch x windows x n), so that the workspace layout and the launch agree.
+constexpr uint32_t MSM_S1_MIN = 4;
+constexpr uint64_t MSM_SMALL_LANES = 65536;
+inline uint32_t msm_small_launch_s1(uint64_t entry_bound) {
+  if (entry_bound >= (uint64_t)MSM_S1 * MSM_SMALL_LANES) return MSM_S1;
+  const uint64_t s = entry_bound / MSM_SMALL_LANES;
+  return (uint32_t)(s < MSM_S1_MIN ? MSM_S1_MIN : s);
+}
 constexpr uint32_t MSM_S2 = 64;         // max partial sums summed by one wave (levels >= 2): one load per lane, six shuffle levels
 constexpr uint32_t MSM_SHORT = 64;       // level >= 2 lists up to this long are summed by a lane group when the launch is throughput-bound
 constexpr uint32_t MSM_SHORT_MIN = 16;   // ... and lists up to this long always; the ones in between go to a wave each when they are few
