@@ -174,10 +174,14 @@ constexpr uint32_t PART_THREADS = 256, PART_PER_LANE = 16, PART_TILE = PART_THRE
 constexpr uint32_t PART_SPLIT = 8;  // workgroups per partition in the bucket passes
 static_assert(PART_MAX == 128 && PART_BUCKETS == 128 && PART_MAX <= DIGITS_LDS_THREADS && PART_BUCKETS <= PART_THREADS, "one thread per histogram bin; wave0_scan128");
 
+// CW != 0: the window width and count are compile-time constants (the tables' c = 15, 17 windows): the digit loop unrolls,
+// every limb index of the canonical scalar is an immediate (with a run-time window index the limbs sat in scratch memory)
+template <uint32_t CW, uint32_t NW>
 __global__ __launch_bounds__(DIGITS_LDS_THREADS) void msm_part_hist_kernel(const Fr* const* __restrict__ scalars,
-                                                                           const uint64_t* __restrict__ lens, uint32_t c, uint32_t nwin,
+                                                                           const uint64_t* __restrict__ lens, uint32_t c_, uint32_t nwin_,
                                                                            uint32_t npart, uint32_t per_lane, uint32_t* __restrict__ psize) {
   __shared__ uint32_t hist[PART_MAX];
+  const uint32_t c = CW ? CW : c_, nwin = CW ? NW : nwin_;
   const uint32_t m = blockIdx.y, t = threadIdx.x;
   const uint32_t len = (uint32_t)lens[m];
   const uint32_t base = blockIdx.x * DIGITS_LDS_THREADS * per_lane;
@@ -189,7 +193,9 @@ __global__ __launch_bounds__(DIGITS_LDS_THREADS) void msm_part_hist_kernel(const
     if (i >= len) continue;
     const U256 v = scalars[m][i].to_canonical();
     uint32_t carry = 0, neg;
-    for (uint32_t w = 0; w < nwin; w++) {
+#pragma unroll
+    for (uint32_t w = 0; w < (CW ? NW : 32u); w++) {
+      if (!CW && w >= nwin) break;
       const uint32_t d = signed_digit(v, w, c, carry, neg);
       if (d) atomicAdd(&hist[(d - 1) >> PART_BITS], 1u);
     }
@@ -240,12 +246,15 @@ static __device__ __forceinline__ void wave0_scan128(const uint32_t* __restrict_
 // copy of runs (~34 entries = 272 B per partition) instead of one uncoalesced 8-byte store per entry (which kept the
 // per-CU memory pipeline, not HBM, busy for 0.5 ms on a 21-MSM launch).
 constexpr uint32_t PSC_THREADS = 256, PSC_MAX_WIN = 17;
+template <uint32_t CW, uint32_t NW>
 __global__ __launch_bounds__(PSC_THREADS) void msm_part_scatter_kernel(const Fr* const* __restrict__ scalars,
-                                                                       const uint64_t* __restrict__ lens, uint32_t c, uint32_t nwin,
+                                                                       const uint64_t* __restrict__ lens, uint32_t c_, uint32_t nwin_,
                                                                        uint32_t npart, const uint32_t* __restrict__ poff,
-                                                                       uint32_t* __restrict__ pcursor, uint2* __restrict__ part_buf) {
+                                                                       uint32_t* __restrict__ pcursor, uint32_t* __restrict__ part_pay,
+                                                                       uint8_t* __restrict__ part_low) {
   __shared__ uint2 stage[PSC_THREADS * PSC_MAX_WIN];
   __shared__ uint32_t hist[PART_MAX], lstart[PART_MAX], gbase[PART_MAX];
+  const uint32_t c = CW ? CW : c_, nwin = CW ? NW : nwin_;
   const uint32_t m = blockIdx.y, t = threadIdx.x;
   const uint32_t len = (uint32_t)lens[m];
   const uint32_t i = blockIdx.x * PSC_THREADS + t;
@@ -255,11 +264,19 @@ __global__ __launch_bounds__(PSC_THREADS) void msm_part_scatter_kernel(const Fr*
   if (i < len) v = scalars[m][i].to_canonical();
   else for (int q = 0; q < 8; q++) v.l[q] = 0;  // zero scalar: no non-zero digit
   __syncthreads();
+  // the digits once, kept for the placement below: |digit| - 1 in the low half, the sign in bit 31, 0xffffffff = zero digit
+  uint32_t dg[CW ? NW : PSC_MAX_WIN];
   {
     uint32_t carry = 0, neg;
-    for (uint32_t w = 0; w < nwin; w++) {
+#pragma unroll
+    for (uint32_t w = 0; w < (CW ? NW : PSC_MAX_WIN); w++) {
+      dg[w] = 0xffffffffu;
+      if (!CW && w >= nwin) continue;
       const uint32_t d = signed_digit(v, w, c, carry, neg);
-      if (d) atomicAdd(&hist[(d - 1) >> PART_BITS], 1u);
+      if (d) {
+        dg[w] = (d - 1) | (neg << 31);
+        atomicAdd(&hist[(d - 1) >> PART_BITS], 1u);
+      }
     }
   }
   __syncthreads();
@@ -273,26 +290,28 @@ __global__ __launch_bounds__(PSC_THREADS) void msm_part_scatter_kernel(const Fr*
   __syncthreads();
   if (t < PART_MAX) hist[t] = 0;
   __syncthreads();
-  {
-    uint32_t carry = 0, neg;
-    for (uint32_t w = 0; w < nwin; w++) {
-      const uint32_t d = signed_digit(v, w, c, carry, neg);
-      if (!d) continue;
-      const uint32_t pt = (d - 1) >> PART_BITS;
-      // entry: point index (26 bits) | window << 26 | sign << 31, and the bucket inside the MSM
-      stage[lstart[pt] + atomicAdd(&hist[pt], 1u)] = make_uint2(i | (w << 26) | (neg << 31), d - 1);
-    }
+#pragma unroll
+  for (uint32_t w = 0; w < (CW ? NW : PSC_MAX_WIN); w++) {
+    if (dg[w] == 0xffffffffu) continue;
+    const uint32_t bk = dg[w] & 0x7fffffffu;
+    const uint32_t pt = bk >> PART_BITS;
+    // entry: point index (26 bits) | window << 26 | sign << 31, and the bucket inside the MSM
+    stage[lstart[pt] + atomicAdd(&hist[pt], 1u)] = make_uint2(i | (w << 26) | (dg[w] & 0x80000000u), bk);
   }
   __syncthreads();
+  // 5 bytes per entry leave the chunk: the payload and, in a byte array of its own, the bucket inside the partition (the
+  // bucket-count pass then reads one byte per entry, the placement pass five, instead of eight each)
   for (uint32_t j = t; j < total; j += PSC_THREADS) {
     const uint2 e = stage[j];
     const uint32_t pt = e.y >> PART_BITS;
-    part_buf[gbase[pt] + (j - lstart[pt])] = e;
+    const uint32_t dst = gbase[pt] + (j - lstart[pt]);
+    part_pay[dst] = e.x;
+    part_low[dst] = (uint8_t)(e.y & (PART_BUCKETS - 1));
   }
 }
 
 // partition pid = msm * npart + p owns the flat buckets [pid << PART_BITS, (pid + 1) << PART_BITS)
-__global__ __launch_bounds__(PART_THREADS) void msm_bucket_count_kernel(const uint2* __restrict__ part_buf, const uint32_t* __restrict__ poff,
+__global__ __launch_bounds__(PART_THREADS) void msm_bucket_count_kernel(const uint8_t* __restrict__ part_low, const uint32_t* __restrict__ poff,
                                                                         uint32_t* __restrict__ counts) {
   __shared__ uint32_t hist[PART_BUCKETS];
   const uint32_t pid = blockIdx.x, t = threadIdx.x;
@@ -300,8 +319,7 @@ __global__ __launch_bounds__(PART_THREADS) void msm_bucket_count_kernel(const ui
   if (lo + blockIdx.y * PART_THREADS >= hi) return;  // block-uniform
   if (t < PART_BUCKETS) hist[t] = 0;
   __syncthreads();
-  for (uint32_t e = lo + blockIdx.y * PART_THREADS + t; e < hi; e += PART_SPLIT * PART_THREADS)
-    atomicAdd(&hist[part_buf[e].y & (PART_BUCKETS - 1)], 1u);
+  for (uint32_t e = lo + blockIdx.y * PART_THREADS + t; e < hi; e += PART_SPLIT * PART_THREADS) atomicAdd(&hist[part_low[e]], 1u);
   __syncthreads();
   if (t < PART_BUCKETS && hist[t]) atomicAdd(&counts[(pid << PART_BITS) + t], hist[t]);
 }
@@ -315,7 +333,8 @@ __global__ __launch_bounds__(256) void msm_alias_counts_kernel(uint32_t* __restr
 
 // Same idea one level down: a tile's entries are sorted by bucket in LDS, then copied out run by run (~32 entries =
 // one 128-byte line per bucket and tile).
-__global__ __launch_bounds__(PART_THREADS) void msm_bucket_place_kernel(const uint2* __restrict__ part_buf, const uint32_t* __restrict__ poff,
+__global__ __launch_bounds__(PART_THREADS) void msm_bucket_place_kernel(const uint32_t* __restrict__ part_pay, const uint8_t* __restrict__ part_low,
+                                                                        const uint32_t* __restrict__ poff,
                                                                         const uint32_t* __restrict__ off0, uint32_t* __restrict__ cursor,
                                                                         uint32_t* __restrict__ sorted) {
   __shared__ uint32_t hist[PART_BUCKETS], lstart[PART_BUCKETS], base[PART_BUCKETS];
@@ -333,8 +352,8 @@ __global__ __launch_bounds__(PART_THREADS) void msm_bucket_place_kernel(const ui
     for (uint32_t k = 0; k < PART_PER_LANE; k++) {
       const uint32_t e = tlo + k * PART_THREADS + t;
       if (e < thi) {
-        ent[k] = part_buf[e];
-        atomicAdd(&hist[ent[k].y & (PART_BUCKETS - 1)], 1u);
+        ent[k] = make_uint2(part_pay[e], part_low[e]);
+        atomicAdd(&hist[ent[k].y], 1u);
       }
     }
     __syncthreads();
@@ -350,7 +369,7 @@ __global__ __launch_bounds__(PART_THREADS) void msm_bucket_place_kernel(const ui
     for (uint32_t k = 0; k < PART_PER_LANE; k++) {
       const uint32_t e = tlo + k * PART_THREADS + t;
       if (e < thi) {
-        const uint32_t b = ent[k].y & (PART_BUCKETS - 1);
+        const uint32_t b = ent[k].y;
         const uint32_t lp = lstart[b] + atomicAdd(&hist[b], 1u);
         spay[lp] = ent[k].x;
         sbkt[lp] = (uint8_t)b;
@@ -779,7 +798,7 @@ MsmLayout::MsmLayout(uint32_t n_, uint32_t c_, uint32_t batch_, bool pre_) : n(n
   // table mode: (payload, bucket) pairs of the partition pass; plain mode: one rank per entry
   part_sort = pre && M <= DIGITS_LDS_MAX_M && M >= PART_BUCKETS && W <= PSC_MAX_WIN;
   npart = part_sort ? M >> PART_BITS : 0;
-  off_ranks = o;   o = up(o + (size_t)E * (part_sort ? sizeof(uint2) : sizeof(uint32_t)));
+  off_ranks = o;   o = up(o + (size_t)E * (part_sort ? 5 : sizeof(uint32_t)));  // table mode: E payloads, then E bucket bytes
   off_poff = o;    o = up(o + ((size_t)batch * npart + 1) * sizeof(uint32_t));
   off_counts = o;  o = up(o + (size_t)Bt * sizeof(uint32_t));
   off_cursor = o;  o = up(o + (part_sort ? (size_t)Bt : 0) * sizeof(uint32_t));        // per-bucket fill cursors
@@ -874,7 +893,8 @@ int msm_run(cq_ctx* ctx, const Fr* const* scalars_host_ptrs, const G1Affine* con
   if (hipMemsetAsync(counts, 0, L.zero_end - L.off_counts, s) != hipSuccess) return -1;
   if (L.part_sort) {
     const uint32_t P = batch * L.npart;
-    uint2* part_buf = (uint2*)(ws + L.off_ranks);
+    uint32_t* part_pay = (uint32_t*)(ws + L.off_ranks);
+    uint8_t* part_low = (uint8_t*)(part_pay + (size_t)batch * W * n);
     uint32_t* poff = (uint32_t*)(ws + L.off_poff);
     uint32_t* cursor = (uint32_t*)(ws + L.off_cursor);
     uint32_t* psize = (uint32_t*)(ws + L.off_psize);
@@ -883,17 +903,18 @@ int msm_run(cq_ctx* ctx, const Fr* const* scalars_host_ptrs, const G1Affine* con
     // latency-bound there), DIGITS_LDS_PER_LANE in a large one (fewer device atomics: 128 per workgroup)
     const uint32_t per_lane = (uint64_t)n * batch <= (1u << 21) ? 2u : DIGITS_LDS_PER_LANE;
     const uint32_t hist_chunk = DIGITS_LDS_THREADS * per_lane;
-    msm_part_hist_kernel<<<dim3((n + hist_chunk - 1) / hist_chunk, batch), DIGITS_LDS_THREADS, 0, s>>>(d_scalars, d_lens, c, W, L.npart,
-                                                                                                    per_lane, psize);
+    const bool fixed = c == MSM_TABLE_C && W == 17;
+    if (fixed) msm_part_hist_kernel<MSM_TABLE_C, 17><<<dim3((n + hist_chunk - 1) / hist_chunk, batch), DIGITS_LDS_THREADS, 0, s>>>(d_scalars, d_lens, c, W, L.npart, per_lane, psize);
+    else msm_part_hist_kernel<0, 0><<<dim3((n + hist_chunk - 1) / hist_chunk, batch), DIGITS_LDS_THREADS, 0, s>>>(d_scalars, d_lens, c, W, L.npart, per_lane, psize);
     msm_part_scan_kernel<<<1, 1024, 0, s>>>(psize, P, poff);
-    msm_part_scatter_kernel<<<dim3((n + PSC_THREADS - 1) / PSC_THREADS, batch), PSC_THREADS, 0, s>>>(d_scalars, d_lens, c, W, L.npart, poff, pcursor,
-                                                                                                     part_buf);
-    msm_bucket_count_kernel<<<dim3(P, PART_SPLIT), PART_THREADS, 0, s>>>(part_buf, poff, counts);
+    if (fixed) msm_part_scatter_kernel<MSM_TABLE_C, 17><<<dim3((n + PSC_THREADS - 1) / PSC_THREADS, batch), PSC_THREADS, 0, s>>>(d_scalars, d_lens, c, W, L.npart, poff, pcursor, part_pay, part_low);
+    else msm_part_scatter_kernel<0, 0><<<dim3((n + PSC_THREADS - 1) / PSC_THREADS, batch), PSC_THREADS, 0, s>>>(d_scalars, d_lens, c, W, L.npart, poff, pcursor, part_pay, part_low);
+    msm_bucket_count_kernel<<<dim3(P, PART_SPLIT), PART_THREADS, 0, s>>>(part_low, poff, counts);
     if (any_alias) msm_alias_counts_kernel<<<dim3((L.B + 255) / 256, batch), 256, 0, s>>>(counts, d_src, L.B);
     msm_scan_reduce_kernel<<<L.nblk, 256, 0, s>>>(counts, Bt, L.nseq, s1, blocksums);
     msm_scan_spine_kernel<<<1, 1024, 0, s>>>(blocksums, L.nblk, L.nseq);
     msm_scan_apply_kernel<<<L.nblk, 256, 0, s>>>(counts, Bt, L.nseq, s1, blocksums, off, tk);
-    msm_bucket_place_kernel<<<dim3(P, PART_SPLIT), PART_THREADS, 0, s>>>(part_buf, poff, off0, cursor, sorted);
+    msm_bucket_place_kernel<<<dim3(P, PART_SPLIT), PART_THREADS, 0, s>>>(part_pay, part_low, poff, off0, cursor, sorted);
   } else {
     msm_digits_kernel<<<dim3((n + 255) / 256, batch), 256, 0, s>>>(d_scalars, d_lens, n, c, W, pre ? 1u : 0u, ranks, counts);
     msm_scan_reduce_kernel<<<L.nblk, 256, 0, s>>>(counts, Bt, L.nseq, s1, blocksums);
