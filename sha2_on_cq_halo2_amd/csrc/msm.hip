@@ -154,9 +154,9 @@ __global__ __launch_bounds__(256) void msm_digits_kernel(const Fr* const* __rest
 //   a. part_hist    : per chunk of 2048 scalars, LDS histogram of the entries' PARTITION (bucket >> 7: 128
 //                     partitions of 128 buckets per MSM); one device atomic per (chunk, partition).
 //   b. part_scan    : exclusive scan of the partition sizes (<= 32 x 128 values, one block).
-//   c. part_scatter : same chunks; each reserves its range in every partition with one device atomic and writes
-//                     (payload, bucket) pairs there -- 128 open runs of ~270 entries per workgroup, which the
-//                     L2 merges into full lines.
+//   c. part_scatter : same chunks; each reserves its range in every partition with one device atomic and writes its
+//                     entries there as runs -- 4-byte payloads and, in a byte array of their own, the bucket inside the
+//                     partition (5 bytes per entry; the counting pass then reads one byte per entry).
 //   d. bucket_count : per partition, LDS histogram of its 128 buckets -> the global bucket counts (the plan's input).
 //   e. bucket_place : after the plan: per tile of 4096 entries of a partition, LDS histogram, one device atomic
 //                     per non-empty bucket to reserve the tile's run inside the bucket's list, entries written

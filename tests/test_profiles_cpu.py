@@ -17,7 +17,7 @@ def test_pmc_summaries_parse():
 
 
 def test_committed_bench_line_has_the_contract_fields():
-    with open(os.path.join(ROOT, "profiles", "r01_bench_create_proof_k18_line_unprofiled.json")) as f:
+    with open(os.path.join(ROOT, "profiles", "r02_bench_create_proof_k18_line_unprofiled.json")) as f:
         d = json.load(f)
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
@@ -29,3 +29,6 @@ def test_committed_bench_line_has_the_contract_fields():
     for key in ("value", "unit", "cores", "kind", "sample"):
         assert key in d["cpu_baseline"], key
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["proof_bytes_identical"] is True
+    assert d["cpu_baseline"]["k"] == 18 and d["cpu_baseline"]["sample_small"]["k"] == 16  # the metric's own configuration
+    assert d["roofline"]["bound"] == "valu" and "not this run" in d["roofline"]["traffic_source"]
+    assert "per_word_callback" in d["generic_rng"] and "unsharded" in d["config3_k20"] and "lanes_3" in d["batched"]
