@@ -858,6 +858,7 @@ int cq_create_proof_batch(cq_pk* pk, size_t count, const uint64_t* const* const*
     c->lanes.push_back(lane);
   }
   CQ_HIP(c, hipStreamSynchronize(c->stream));  // whatever filled the witnesses on the caller's stream is done
+  (void)c->pool();  // the lanes share the parent's worker threads: created here, before several threads would race to
   std::atomic<size_t> next{0};
   std::atomic<int> first_rc{CQ_OK};
   std::mutex err_mu;
