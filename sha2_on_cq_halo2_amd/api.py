@@ -962,8 +962,10 @@ def _pk_set_sharding(self, rank: int, world: int, group=None, device=None, trans
     (Context.comm_init_rccl / comm_init_from_torch first); "callback": torch.distributed collectives of `group` on host
     buffers (gloo on CPU tensors; with `device` the tensors travel through that device for the "nccl" backend)."""
     if world <= 1:
-        self._allgather_cb = self._bcast_cb = None
+        # (the column hook first: the library must not keep a pointer to a callback object that is about to be dropped)
+        self.ctx._chk(self.ctx.lib.cq_pk_set_column_sharding(self.h, 1 if columns else 0, None, None))
         self.ctx._chk(self.ctx.lib.cq_pk_set_sharding(self.h, 0, 1, None, None))
+        self._allgather_cb = self._bcast_cb = None
         return
     if transport == "rccl":
         self._allgather_cb = self._bcast_cb = None
