@@ -8,7 +8,10 @@ struct cq_ctx;
 
 namespace cq {
 
-constexpr uint32_t NTT_THREADS = 256;
+#ifndef CQ_NTT_THREADS
+#define CQ_NTT_THREADS 256
+#endif
+constexpr uint32_t NTT_THREADS = CQ_NTT_THREADS;
 #ifndef CQ_NTT_MAX_DEG
 #define CQ_NTT_MAX_DEG 6
 #endif
