@@ -132,6 +132,11 @@ int cq_msm_forget_dev(cq_ctx* ctx, const uint64_t* bases_dev);
 int cq_msm_set_precompute(cq_ctx* ctx, int on);
 /* Pippenger window width in bits (2..15), 0 = automatic.  Tuning knob; results do not depend on it. */
 int cq_msm_set_window(cq_ctx* ctx, uint32_t bits);
+/* Window width (8..20) of the per-window tables built from now on by cq_msm_precompute_dev, the params and key
+ * constructors; 0 = automatic (the first table built on the context decides: 15 bits up to 2^19 points, wider beyond).
+ * One width per context, because MSMs over different base arrays share launches only when their tables agree.
+ * Tuning knob; results do not depend on it. */
+int cq_msm_set_table_window(cq_ctx* ctx, uint32_t bits);
 
 /* eval_polynomial(poly, point)  arithmetic.rs:304-329 */
 int cq_eval_polynomial(cq_ctx* ctx, const uint64_t* poly, size_t n, const uint64_t point[4], uint64_t out[4]);

@@ -147,6 +147,12 @@ def _ctx_set_msm_window(self, bits: int):
     self._chk(self.lib.cq_msm_set_window(self.h, bits))
 
 
+def _ctx_set_msm_table_window(self, bits: int):
+    """Window width of the per-window tables built from now on (8..20, 0 = automatic); see cq_msm_set_table_window."""
+    self._chk(self.lib.cq_msm_set_table_window(self.h, bits))
+
+
+Context.set_msm_table_window = _ctx_set_msm_table_window
 Context.best_multiexp = _ctx_best_multiexp
 Context.best_multiexp_dev = _ctx_best_multiexp_dev
 Context.msm_batch_dev = _ctx_msm_batch_dev

@@ -11,6 +11,18 @@
 
 using namespace cq;
 
+uint32_t msm_table_window_bits(size_t n) {
+  if (const char* e = getenv("CQ_TABLE_C")) {
+    const long v = atol(e);
+    if (v >= (long)MSM_TABLE_C_MIN && v <= (long)MSM_TABLE_C_MAX) return (uint32_t)v;
+  }
+  // Measured on MI355X, whole proofs of the SHA-shaped circuit (tools/table_c_sweep.sh; ms at c = 15 / 16 / 17 / 18 / 20):
+  //   k = 18:  8.2 /  8.6 /  9.4 /  14.0 / 16.3      k = 20: 26.5 / 26.0 / 25.4 / 32.4 / 33.9      k = 22: 97.2 / 94.0 / 92.3 / 115 / 99
+  // 17 bits: 15 instead of 17 additions per scalar, 2^16 buckets per MSM that the two-pass sort still reaches with a byte
+  // per entry; beyond, the third sort pass and the 2^17..2^19-bucket reductions cost more than the additions saved.
+  return n >= ((size_t)1 << 20) ? 17u : MSM_TABLE_C;
+}
+
 static uint32_t pick_c(cq_ctx* c, uint32_t n) {
   if (c->msm_c) return c->msm_c;
   return msm_window_bits(n);
@@ -62,6 +74,7 @@ int msm_multi_begin(cq_ctx* c, const Fr* const* scalars, const G1Affine* const* 
     MsmLayout L(nmax, cb, batch, pre);
     ln.W = L.W;
     ln.Wb = L.Wb;
+    ln.M = L.M;
     ln.cols = L.cols;
     ln.slot = slots;
     slots += (size_t)MSM_SET_POINTS * batch * L.Wb;  // bit-plane sums of every bucket set
@@ -108,7 +121,7 @@ int msm_multi_end(cq_ctx* c, MsmPending& pend, uint64_t* out_jac) {
   for (auto& ln : pend.launches)
     for (uint32_t j = 0; j < ln.batch; j++) {
       items.push_back({&ln, j});
-      if (!ln.empty) sets += ln.pre ? 1 : ln.W;
+      if (!ln.empty) sets += ln.Wb;
     }
   const G1Jac* host = (const G1Jac*)pend.host;
   auto fold = [&](size_t i) {
@@ -120,7 +133,7 @@ int msm_multi_end(cq_ctx* c, MsmPending& pend, uint64_t* out_jac) {
       return;
     }
     const G1Jac* res = host + ln.slot;
-    G1Jac r = ln.pre ? msm_set_value(res + (size_t)MSM_SET_POINTS * j, ln.cols)
+    G1Jac r = ln.pre ? msm_fold_sets(res + (size_t)MSM_SET_POINTS * j * ln.Wb, ln.Wb, ln.M, ln.cols)
                      : msm_fold_windows(res + (size_t)MSM_SET_POINTS * j * ln.W, ln.W, ln.c, ln.cols);
     r.x.to_limbs64(o);
     r.y.to_limbs64(o + 4);
@@ -167,7 +180,9 @@ int msm_register_tables(cq_ctx* c, const G1Affine* bases, size_t n) {
     if (t && off == 0 && t->bases == bases) return CQ_OK;  // already registered (slices of it resolve to it too)
     if (t) return CQ_OK;
   }
-  const uint32_t cb = MSM_TABLE_C;
+  // one width per context (launches mix base arrays): the first registration decides unless the caller has
+  if (!c->msm_table_c) c->msm_table_c = msm_table_window_bits(n);
+  const uint32_t cb = c->msm_table_c;
   const uint32_t W = (255 + cb - 1) / cb;
   void* table = nullptr;
   if (hipMalloc(&table, (size_t)W * n * sizeof(G1Affine)) != hipSuccess) {
@@ -231,6 +246,12 @@ int cq_msm_forget_dev(cq_ctx* c, const uint64_t* bases_dev) {
 int cq_msm_set_precompute(cq_ctx* c, int on) {
   if (!c) return CQ_ERR_ARG;
   c->msm_precompute = on != 0;
+  return CQ_OK;
+}
+
+int cq_msm_set_table_window(cq_ctx* c, uint32_t bits) {
+  if (!c || (bits != 0 && (bits < MSM_TABLE_C_MIN || bits > MSM_TABLE_C_MAX))) return CQ_ERR_ARG;
+  c->msm_table_c = bits;
   return CQ_OK;
 }
 

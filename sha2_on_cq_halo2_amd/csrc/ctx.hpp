@@ -22,6 +22,7 @@ struct cq_ctx {
   void* pinned = nullptr;  // small pinned host staging buffer
   size_t pinned_bytes = 0;
   uint32_t msm_c = 0;  // 0 = automatic window size
+  uint32_t msm_table_c = 0;  // window width of the precomputed tables; 0 = decided by the first registration (msm.hpp)
   bool msm_precompute = true;  // build per-window tables for resident SRS arrays
   void* fb_table = nullptr;  // fixed-base table d*2^(8j)*G (setup.hip)
   // precomputed MSM window tables, keyed by the base array they were derived from

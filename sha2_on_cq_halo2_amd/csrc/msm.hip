@@ -168,20 +168,24 @@ constexpr uint32_t DIGITS_LDS_THREADS = CQ_PART_CHUNK_THREADS;
 constexpr uint32_t DIGITS_LDS_PER_LANE = 8;
 constexpr uint32_t DIGITS_LDS_CHUNK = DIGITS_LDS_THREADS * DIGITS_LDS_PER_LANE;
 constexpr uint32_t DIGITS_LDS_MAX_M = 1u << 14;
-constexpr uint32_t PART_BITS = 7, PART_BUCKETS = 1u << PART_BITS;  // buckets per partition
-constexpr uint32_t PART_MAX = DIGITS_LDS_MAX_M >> PART_BITS;          // partitions per MSM
+constexpr uint32_t PART_BITS = 7, PART_BUCKETS = 1u << PART_BITS;  // buckets per partition (c <= 15 and behind a refinement pass)
+constexpr uint32_t PART_BITS_WIDE = 8;                             // ... 256 of them for c = 16 and c = 17
+constexpr uint32_t PART_MAX = 256;                                 // partitions per MSM (128 up to c = 16, 256 for c = 17)
 constexpr uint32_t PART_THREADS = 256, PART_PER_LANE = 16, PART_TILE = PART_THREADS * PART_PER_LANE;
 constexpr uint32_t PART_SPLIT = 8;  // workgroups per partition in the bucket passes
-static_assert(PART_MAX == 128 && PART_BUCKETS == 128 && PART_MAX <= DIGITS_LDS_THREADS && PART_BUCKETS <= PART_THREADS, "one thread per histogram bin; wave0_scan128");
+static_assert(PART_MAX <= DIGITS_LDS_THREADS && (1u << PART_BITS_WIDE) <= PART_THREADS, "one thread per histogram bin");
 
 // CW != 0: the window width and count are compile-time constants (the tables' c = 15, 17 windows): the digit loop unrolls,
 // every limb index of the canonical scalar is an immediate (with a run-time window index the limbs sat in scratch memory)
+// `shift`: bucket -> partition of the first pass (PART_BITS up to c = 15; c - 8, i.e. always 128 partitions, beyond)
+static constexpr uint32_t part_shift_of(uint32_t c) { return c > 17 ? c - 8 : c > 15 ? PART_BITS_WIDE : PART_BITS; }
 template <uint32_t CW, uint32_t NW>
 __global__ __launch_bounds__(DIGITS_LDS_THREADS) void msm_part_hist_kernel(const Fr* const* __restrict__ scalars,
                                                                            const uint64_t* __restrict__ lens, uint32_t c_, uint32_t nwin_,
                                                                            uint32_t npart, uint32_t per_lane, uint32_t* __restrict__ psize) {
   __shared__ uint32_t hist[PART_MAX];
   const uint32_t c = CW ? CW : c_, nwin = CW ? NW : nwin_;
+  const uint32_t shift = part_shift_of(c);
   const uint32_t m = blockIdx.y, t = threadIdx.x;
   const uint32_t len = (uint32_t)lens[m];
   const uint32_t base = blockIdx.x * DIGITS_LDS_THREADS * per_lane;
@@ -197,7 +201,7 @@ __global__ __launch_bounds__(DIGITS_LDS_THREADS) void msm_part_hist_kernel(const
     for (uint32_t w = 0; w < (CW ? NW : 32u); w++) {
       if (!CW && w >= nwin) break;
       const uint32_t d = signed_digit(v, w, c, carry, neg);
-      if (d) atomicAdd(&hist[(d - 1) >> PART_BITS], 1u);
+      if (d) atomicAdd(&hist[(d - 1) >> shift], 1u);
     }
   }
   __syncthreads();
@@ -227,34 +231,50 @@ __global__ __launch_bounds__(1024) void msm_part_scan_kernel(const uint32_t* __r
   if (threadIdx.x == 1023) poff[P] = part[1023];
 }
 
-// exclusive scan of the PART_MAX (= 128) histogram bins by the first wave: lane l owns bins 2l and 2l + 1
-static __device__ __forceinline__ void wave0_scan128(const uint32_t* __restrict__ hist, uint32_t* __restrict__ start) {
+// exclusive scan of N (128 or 256) histogram bins by the first wave: lane l owns bins l * N/64 .. (l + 1) * N/64 - 1
+template <uint32_t N>
+static __device__ __forceinline__ void wave0_scan(const uint32_t* __restrict__ hist, uint32_t* __restrict__ start) {
+  constexpr uint32_t PER = N / 64;
   const uint32_t l = threadIdx.x;
   if (l >= 64) return;
-  const uint32_t a = hist[2 * l], b = hist[2 * l + 1];
-  uint32_t incl = a + b;
+  uint32_t v[PER], sum = 0;
+#pragma unroll
+  for (uint32_t k = 0; k < PER; k++) {
+    v[k] = hist[PER * l + k];
+    sum += v[k];
+  }
+  uint32_t incl = sum;
 #pragma unroll
   for (int d = 1; d < 64; d <<= 1) {
     const uint32_t o = __shfl_up(incl, d, 64);
     if ((int)l >= d) incl += o;
   }
-  start[2 * l] = incl - (a + b);
-  start[2 * l + 1] = incl - b;
+  uint32_t run = incl - sum;
+#pragma unroll
+  for (uint32_t k = 0; k < PER; k++) {
+    start[PER * l + k] = run;
+    run += v[k];
+  }
+}
+static __device__ __forceinline__ void wave0_scan128(const uint32_t* __restrict__ hist, uint32_t* __restrict__ start) {
+  wave0_scan<128>(hist, start);
 }
 
 // One scalar per lane; the chunk's entries are sorted by partition in LDS first, so that the write-out is a linear
 // copy of runs (~34 entries = 272 B per partition) instead of one uncoalesced 8-byte store per entry (which kept the
 // per-CU memory pipeline, not HBM, busy for 0.5 ms on a 21-MSM launch).
 constexpr uint32_t PSC_THREADS = 256, PSC_MAX_WIN = 17;
-template <uint32_t CW, uint32_t NW>
+// LowT: the bucket inside the partition -- a byte up to c = 15 (7 bits), 16 bits for the wider windows (c - 8 bits)
+template <uint32_t CW, uint32_t NW, typename LowT>
 __global__ __launch_bounds__(PSC_THREADS) void msm_part_scatter_kernel(const Fr* const* __restrict__ scalars,
                                                                        const uint64_t* __restrict__ lens, uint32_t c_, uint32_t nwin_,
                                                                        uint32_t npart, const uint32_t* __restrict__ poff,
                                                                        uint32_t* __restrict__ pcursor, uint32_t* __restrict__ part_pay,
-                                                                       uint8_t* __restrict__ part_low) {
-  __shared__ uint2 stage[PSC_THREADS * PSC_MAX_WIN];
+                                                                       LowT* __restrict__ part_low) {
+  __shared__ uint2 stage[PSC_THREADS * (CW ? NW : PSC_MAX_WIN)];
   __shared__ uint32_t hist[PART_MAX], lstart[PART_MAX], gbase[PART_MAX];
   const uint32_t c = CW ? CW : c_, nwin = CW ? NW : nwin_;
+  const uint32_t shift = part_shift_of(c);
   const uint32_t m = blockIdx.y, t = threadIdx.x;
   const uint32_t len = (uint32_t)lens[m];
   const uint32_t i = blockIdx.x * PSC_THREADS + t;
@@ -275,12 +295,12 @@ __global__ __launch_bounds__(PSC_THREADS) void msm_part_scatter_kernel(const Fr*
       const uint32_t d = signed_digit(v, w, c, carry, neg);
       if (d) {
         dg[w] = (d - 1) | (neg << 31);
-        atomicAdd(&hist[(d - 1) >> PART_BITS], 1u);
+        atomicAdd(&hist[(d - 1) >> shift], 1u);
       }
     }
   }
   __syncthreads();
-  wave0_scan128(hist, lstart);
+  wave0_scan<PART_MAX>(hist, lstart);
   if (t < npart) {
     const uint32_t h = hist[t];
     gbase[t] = h ? poff[m * npart + t] + atomicAdd(&pcursor[m * npart + t], h) : 0u;
@@ -294,7 +314,7 @@ __global__ __launch_bounds__(PSC_THREADS) void msm_part_scatter_kernel(const Fr*
   for (uint32_t w = 0; w < (CW ? NW : PSC_MAX_WIN); w++) {
     if (dg[w] == 0xffffffffu) continue;
     const uint32_t bk = dg[w] & 0x7fffffffu;
-    const uint32_t pt = bk >> PART_BITS;
+    const uint32_t pt = bk >> shift;
     // entry: point index (26 bits) | window << 26 | sign << 31, and the bucket inside the MSM
     stage[lstart[pt] + atomicAdd(&hist[pt], 1u)] = make_uint2(i | (w << 26) | (dg[w] & 0x80000000u), bk);
   }
@@ -303,25 +323,27 @@ __global__ __launch_bounds__(PSC_THREADS) void msm_part_scatter_kernel(const Fr*
   // bucket-count pass then reads one byte per entry, the placement pass five, instead of eight each)
   for (uint32_t j = t; j < total; j += PSC_THREADS) {
     const uint2 e = stage[j];
-    const uint32_t pt = e.y >> PART_BITS;
+    const uint32_t pt = e.y >> shift;
     const uint32_t dst = gbase[pt] + (j - lstart[pt]);
     part_pay[dst] = e.x;
-    part_low[dst] = (uint8_t)(e.y & (PART_BUCKETS - 1));
+    part_low[dst] = (LowT)(e.y & ((1u << shift) - 1u));
   }
 }
 
 // partition pid = msm * npart + p owns the flat buckets [pid << PART_BITS, (pid + 1) << PART_BITS)
+// (PB: bits of the bucket inside a partition, 7 or 8)
+template <uint32_t PB>
 __global__ __launch_bounds__(PART_THREADS) void msm_bucket_count_kernel(const uint8_t* __restrict__ part_low, const uint32_t* __restrict__ poff,
                                                                         uint32_t* __restrict__ counts) {
-  __shared__ uint32_t hist[PART_BUCKETS];
+  __shared__ uint32_t hist[1u << PB];
   const uint32_t pid = blockIdx.x, t = threadIdx.x;
   const uint32_t lo = poff[pid], hi = poff[pid + 1];
   if (lo + blockIdx.y * PART_THREADS >= hi) return;  // block-uniform
-  if (t < PART_BUCKETS) hist[t] = 0;
+  if (t < (1u << PB)) hist[t] = 0;
   __syncthreads();
-  for (uint32_t e = lo + blockIdx.y * PART_THREADS + t; e < hi; e += PART_SPLIT * PART_THREADS) atomicAdd(&hist[part_low[e]], 1u);
+  for (uint32_t e = lo + blockIdx.y * PART_THREADS + t; e < hi; e += gridDim.y * PART_THREADS) atomicAdd(&hist[part_low[e]], 1u);
   __syncthreads();
-  if (t < PART_BUCKETS && hist[t]) atomicAdd(&counts[(pid << PART_BITS) + t], hist[t]);
+  if (t < (1u << PB) && hist[t]) atomicAdd(&counts[(pid << PB) + t], hist[t]);
 }
 
 // an MSM that accumulates from another one's lists (same scalar vector) takes a copy of its bucket counts
@@ -333,19 +355,21 @@ __global__ __launch_bounds__(256) void msm_alias_counts_kernel(uint32_t* __restr
 
 // Same idea one level down: a tile's entries are sorted by bucket in LDS, then copied out run by run (~32 entries =
 // one 128-byte line per bucket and tile).
+template <uint32_t PB>
 __global__ __launch_bounds__(PART_THREADS) void msm_bucket_place_kernel(const uint32_t* __restrict__ part_pay, const uint8_t* __restrict__ part_low,
                                                                         const uint32_t* __restrict__ poff,
                                                                         const uint32_t* __restrict__ off0, uint32_t* __restrict__ cursor,
                                                                         uint32_t* __restrict__ sorted) {
-  __shared__ uint32_t hist[PART_BUCKETS], lstart[PART_BUCKETS], base[PART_BUCKETS];
+  constexpr uint32_t NB = 1u << PB;
+  __shared__ uint32_t hist[NB], lstart[NB], base[NB];
   __shared__ uint32_t spay[PART_TILE];
   __shared__ uint8_t sbkt[PART_TILE];
   const uint32_t pid = blockIdx.x, t = threadIdx.x;
   const uint32_t lo = poff[pid], hi = poff[pid + 1];
   const uint32_t ntiles = (hi - lo + PART_TILE - 1) / PART_TILE;
-  for (uint32_t tile = blockIdx.y; tile < ntiles; tile += PART_SPLIT) {  // block-uniform trip count
+  for (uint32_t tile = blockIdx.y; tile < ntiles; tile += gridDim.y) {  // block-uniform trip count
     const uint32_t tlo = lo + tile * PART_TILE, thi = min(hi, tlo + PART_TILE);
-    if (t < PART_BUCKETS) hist[t] = 0;
+    if (t < NB) hist[t] = 0;
     __syncthreads();
     uint2 ent[PART_PER_LANE];
 #pragma unroll
@@ -357,13 +381,13 @@ __global__ __launch_bounds__(PART_THREADS) void msm_bucket_place_kernel(const ui
       }
     }
     __syncthreads();
-    wave0_scan128(hist, lstart);
-    if (t < PART_BUCKETS) {
-      const uint32_t h = hist[t], g = (pid << PART_BITS) + t;
+    wave0_scan<NB>(hist, lstart);
+    if (t < NB) {
+      const uint32_t h = hist[t], g = (pid << PB) + t;
       base[t] = h ? off0[g] + atomicAdd(&cursor[g], h) : 0u;
     }
     __syncthreads();
-    if (t < PART_BUCKETS) hist[t] = 0;
+    if (t < NB) hist[t] = 0;
     __syncthreads();
 #pragma unroll
     for (uint32_t k = 0; k < PART_PER_LANE; k++) {
@@ -379,6 +403,87 @@ __global__ __launch_bounds__(PART_THREADS) void msm_bucket_place_kernel(const ui
     for (uint32_t j = t; j < thi - tlo; j += PART_THREADS) {
       const uint32_t b = sbkt[j];
       sorted[base[b] + (j - lstart[b])] = spay[j];
+    }
+    __syncthreads();
+  }
+}
+
+// Wide windows (c > 17, 2^(c-1) buckets per MSM): the first pass still cuts an MSM into 128 partitions -- now of
+// 2^(c-8) buckets -- and a REFINEMENT pass of the same shape as the two kernels above splits every such partition into
+// its 2^(c-15) final partitions of 128 buckets, which the kernels above then finish.  The few bins of a partition are
+// spread over 128 histogram cells (bin, thread mod R) so that the LDS atomics of a wave do not pile up on 2..32
+// addresses; cells of one bin are adjacent, so the LDS-sorted tile is still a sequence of per-bin runs.
+__global__ __launch_bounds__(PART_THREADS) void msm_refine_count_kernel(const uint16_t* __restrict__ low1, const uint32_t* __restrict__ poff1,
+                                                                        uint32_t bins_log, uint32_t* __restrict__ psize2) {
+  __shared__ uint32_t hist[PART_BUCKETS];
+  const uint32_t cp = blockIdx.x, t = threadIdx.x;
+  const uint32_t lo = poff1[cp], hi = poff1[cp + 1];
+  if (lo + blockIdx.y * PART_THREADS >= hi) return;  // block-uniform
+  const uint32_t rlog = PART_BITS - bins_log, rep = t & ((1u << rlog) - 1u);
+  if (t < PART_BUCKETS) hist[t] = 0;
+  __syncthreads();
+  for (uint32_t e = lo + blockIdx.y * PART_THREADS + t; e < hi; e += gridDim.y * PART_THREADS)
+    atomicAdd(&hist[((uint32_t)(low1[e] >> PART_BITS) << rlog) | rep], 1u);
+  __syncthreads();
+  if (t < (1u << bins_log)) {
+    uint32_t sum = 0;
+    for (uint32_t r = 0; r < (1u << rlog); r++) sum += hist[(t << rlog) + r];
+    if (sum) atomicAdd(&psize2[(cp << bins_log) + t], sum);
+  }
+}
+
+__global__ __launch_bounds__(PART_THREADS) void msm_refine_place_kernel(const uint32_t* __restrict__ pay1, const uint16_t* __restrict__ low1,
+                                                                        const uint32_t* __restrict__ poff1, uint32_t bins_log,
+                                                                        const uint32_t* __restrict__ poff2, uint32_t* __restrict__ cursor2,
+                                                                        uint32_t* __restrict__ pay2, uint8_t* __restrict__ low2) {
+  __shared__ uint32_t hist[PART_BUCKETS], lstart[PART_BUCKETS], base[PART_BUCKETS];
+  __shared__ uint32_t spay[PART_TILE];
+  __shared__ uint16_t slow[PART_TILE];
+  const uint32_t cp = blockIdx.x, t = threadIdx.x;
+  const uint32_t lo = poff1[cp], hi = poff1[cp + 1];
+  const uint32_t ntiles = (hi - lo + PART_TILE - 1) / PART_TILE;
+  const uint32_t bins = 1u << bins_log, rlog = PART_BITS - bins_log, rep = t & ((1u << rlog) - 1u);
+  for (uint32_t tile = blockIdx.y; tile < ntiles; tile += gridDim.y) {  // block-uniform trip count
+    const uint32_t tlo = lo + tile * PART_TILE, thi = min(hi, tlo + PART_TILE);
+    if (t < PART_BUCKETS) hist[t] = 0;
+    __syncthreads();
+    uint2 ent[PART_PER_LANE];
+#pragma unroll
+    for (uint32_t k = 0; k < PART_PER_LANE; k++) {
+      const uint32_t e = tlo + k * PART_THREADS + t;
+      if (e < thi) {
+        ent[k] = make_uint2(pay1[e], low1[e]);
+        atomicAdd(&hist[((ent[k].y >> PART_BITS) << rlog) | rep], 1u);
+      }
+    }
+    __syncthreads();
+    wave0_scan128(hist, lstart);
+    __syncthreads();
+    if (t < bins) {  // the tile's run inside final partition (cp, t)
+      const uint32_t first = lstart[t << rlog];
+      const uint32_t end = t + 1 < bins ? lstart[(t + 1) << rlog] : lstart[PART_BUCKETS - 1] + hist[PART_BUCKETS - 1];
+      const uint32_t f = (cp << bins_log) + t;
+      base[t] = end > first ? poff2[f] + atomicAdd(&cursor2[f], end - first) : 0u;
+    }
+    __syncthreads();
+    if (t < PART_BUCKETS) hist[t] = 0;
+    __syncthreads();
+#pragma unroll
+    for (uint32_t k = 0; k < PART_PER_LANE; k++) {
+      const uint32_t e = tlo + k * PART_THREADS + t;
+      if (e < thi) {
+        const uint32_t cell = ((ent[k].y >> PART_BITS) << rlog) | rep;
+        const uint32_t lp = lstart[cell] + atomicAdd(&hist[cell], 1u);
+        spay[lp] = ent[k].x;
+        slow[lp] = (uint16_t)ent[k].y;
+      }
+    }
+    __syncthreads();
+    for (uint32_t j = t; j < thi - tlo; j += PART_THREADS) {
+      const uint32_t l = slow[j], bin = l >> PART_BITS;
+      const uint32_t dst = base[bin] + (j - lstart[bin << rlog]);
+      pay2[dst] = spay[j];
+      low2[dst] = (uint8_t)(l & (PART_BUCKETS - 1));
     }
     __syncthreads();
   }
@@ -777,8 +882,10 @@ uint32_t msm_window_bits(uint32_t n) {
 
 MsmLayout::MsmLayout(uint32_t n_, uint32_t c_, uint32_t batch_, bool pre_) : n(n_), c(c_), batch(batch_), pre(pre_) {
   W = (255 + c - 1) / c;  // signed digits need W*c >= 255 for 254-bit scalars
-  M = 1u << (c - 1);
-  Wb = pre ? 1 : W;       // bucket sets per MSM: one when every window has its own precomputed table
+  // bucket sets per MSM: one per window in plain mode; with per-window tables every window feeds the same 2^(c-1)
+  // buckets, kept as sets of at most 2^14 for the reduction
+  M = pre && c > 15 ? 1u << 14 : 1u << (c - 1);
+  Wb = pre ? (1u << (c - 1)) / M : W;
   B = Wb * M;
   Bt = batch * B;
   levels = 1;
@@ -796,13 +903,20 @@ MsmLayout::MsmLayout(uint32_t n_, uint32_t c_, uint32_t batch_, bool pre_) : n(n
   size_t o = 0;
   off_ptrs = o;    o = up(o + (size_t)5 * batch * sizeof(void*));
   // table mode: (payload, bucket) pairs of the partition pass; plain mode: one rank per entry
-  part_sort = pre && M <= DIGITS_LDS_MAX_M && M >= PART_BUCKETS && W <= PSC_MAX_WIN;
-  npart = part_sort ? M >> PART_BITS : 0;
-  off_ranks = o;   o = up(o + (size_t)E * (part_sort ? 5 : sizeof(uint32_t)));  // table mode: E payloads, then E bucket bytes
+  part_sort = pre && B <= (DIGITS_LDS_MAX_M << (MSM_TABLE_C_MAX - 15)) && B >= PART_BUCKETS && W <= PSC_MAX_WIN;
+  mid = part_sort && c > 17;               // c = 16, 17: two passes with 256 buckets per partition
+  shift1 = part_shift_of(c);
+  npart = part_sort ? B >> shift1 : 0;     // partitions of the first pass (<= PART_MAX)
+  nfinal = part_sort ? (mid ? B >> PART_BITS : npart) : 0;  // partitions the bucket passes work on
+  // table mode: E payloads and E partition-local buckets (a byte each; with a refinement pass 16 bits, and a second pair
+  // of arrays for its output)
+  off_ranks = o;   o = up(o + (size_t)E * (part_sort ? (mid ? 11 : 5) : sizeof(uint32_t)));
   off_poff = o;    o = up(o + ((size_t)batch * npart + 1) * sizeof(uint32_t));
+  off_poff2 = o;   o = up(o + (mid ? (size_t)batch * nfinal + 1 : 0) * sizeof(uint32_t));
   off_counts = o;  o = up(o + (size_t)Bt * sizeof(uint32_t));
   off_cursor = o;  o = up(o + (part_sort ? (size_t)Bt : 0) * sizeof(uint32_t));        // per-bucket fill cursors
   off_psize = o;   o = up(o + (size_t)2 * batch * npart * sizeof(uint32_t));          // partition sizes, cursors
+  off_psize2 = o;  o = up(o + (mid ? (size_t)2 * batch * nfinal : 0) * sizeof(uint32_t));
   off_buckets = o; o = up(o + (size_t)Bt * sizeof(XYZZ));  // counts..buckets zeroed by one memset
   zero_end = o;
   off_blocksums = o; o = up(o + (size_t)nseq * nblk * sizeof(uint32_t));
@@ -879,8 +993,11 @@ int msm_run(cq_ctx* ctx, const Fr* const* scalars_host_ptrs, const G1Affine* con
   for (uint32_t i = 0; i < batch; i++) load = std::max<uint64_t>(load, (uint64_t)lens[i] * W / (L.Wb * M));
   // (Longer sub-lists for the very large launches -- fewer partial sums for the combine, 2.6 ms of a k = 20 proof -- were
   // swept at k = 20 and k = 22, 32..384 entries: the accumulate kernel loses what the combine gains, within 1 %.)
+  // (With several bucket sets per MSM -- wide table windows -- there are four or more times the buckets and a quarter of
+  // the partial sums per bucket keeps the lanes as many: k = 22 at c = 17, 91.8 -> 90.8 ms.)
+  const uint32_t partials = pre && L.Wb > 1 ? MSM_PARTIALS_TARGET / 4 : MSM_PARTIALS_TARGET;
   const uint32_t s1 = load <= MSM_S1_BIG_LOAD ? msm_small_launch_s1((uint64_t)batch * W * n)
-                                              : std::max<uint32_t>(MSM_S1_BIG, (uint32_t)((load + MSM_PARTIALS_TARGET - 1) / MSM_PARTIALS_TARGET));
+                                              : std::max<uint32_t>(MSM_S1_BIG, (uint32_t)((load + partials - 1) / partials));
   const uint32_t* off0 = off;
   // The launch in three segments: front (pointer tables, sort, plan), the accumulate kernel, tail (combine levels, bucket
   // reduction).  Front and tail are a dozen and half a dozen small kernels whose arguments depend only on the launch's
@@ -893,8 +1010,9 @@ int msm_run(cq_ctx* ctx, const Fr* const* scalars_host_ptrs, const G1Affine* con
   if (hipMemsetAsync(counts, 0, L.zero_end - L.off_counts, s) != hipSuccess) return -1;
   if (L.part_sort) {
     const uint32_t P = batch * L.npart;
+    const uint64_t E = (uint64_t)batch * W * n;
     uint32_t* part_pay = (uint32_t*)(ws + L.off_ranks);
-    uint8_t* part_low = (uint8_t*)(part_pay + (size_t)batch * W * n);
+    void* part_low = part_pay + E;  // u8 entries, or u16 ones followed by the refinement's output pair
     uint32_t* poff = (uint32_t*)(ws + L.off_poff);
     uint32_t* cursor = (uint32_t*)(ws + L.off_cursor);
     uint32_t* psize = (uint32_t*)(ws + L.off_psize);
@@ -903,18 +1021,58 @@ int msm_run(cq_ctx* ctx, const Fr* const* scalars_host_ptrs, const G1Affine* con
     // latency-bound there), DIGITS_LDS_PER_LANE in a large one (fewer device atomics: 128 per workgroup)
     const uint32_t per_lane = (uint64_t)n * batch <= (1u << 21) ? 2u : DIGITS_LDS_PER_LANE;
     const uint32_t hist_chunk = DIGITS_LDS_THREADS * per_lane;
-    const bool fixed = c == MSM_TABLE_C && W == 17;
-    if (fixed) msm_part_hist_kernel<MSM_TABLE_C, 17><<<dim3((n + hist_chunk - 1) / hist_chunk, batch), DIGITS_LDS_THREADS, 0, s>>>(d_scalars, d_lens, c, W, L.npart, per_lane, psize);
-    else msm_part_hist_kernel<0, 0><<<dim3((n + hist_chunk - 1) / hist_chunk, batch), DIGITS_LDS_THREADS, 0, s>>>(d_scalars, d_lens, c, W, L.npart, per_lane, psize);
-    msm_part_scan_kernel<<<1, 1024, 0, s>>>(psize, P, poff);
-    if (fixed) msm_part_scatter_kernel<MSM_TABLE_C, 17><<<dim3((n + PSC_THREADS - 1) / PSC_THREADS, batch), PSC_THREADS, 0, s>>>(d_scalars, d_lens, c, W, L.npart, poff, pcursor, part_pay, part_low);
-    else msm_part_scatter_kernel<0, 0><<<dim3((n + PSC_THREADS - 1) / PSC_THREADS, batch), PSC_THREADS, 0, s>>>(d_scalars, d_lens, c, W, L.npart, poff, pcursor, part_pay, part_low);
-    msm_bucket_count_kernel<<<dim3(P, PART_SPLIT), PART_THREADS, 0, s>>>(part_low, poff, counts);
+    const dim3 hgrid((n + hist_chunk - 1) / hist_chunk, batch), sgrid((n + PSC_THREADS - 1) / PSC_THREADS, batch);
+    // window width and count as compile-time constants for the table widths in use (see msm_part_hist_kernel)
+#define CQ_PART_PASS1(CW, NW, LOWT)                                                                                               \
+  do {                                                                                                                            \
+    msm_part_hist_kernel<CW, NW><<<hgrid, DIGITS_LDS_THREADS, 0, s>>>(d_scalars, d_lens, c, W, L.npart, per_lane, psize);          \
+    msm_part_scan_kernel<<<1, 1024, 0, s>>>(psize, P, poff);                                                                      \
+    msm_part_scatter_kernel<CW, NW, LOWT><<<sgrid, PSC_THREADS, 0, s>>>(d_scalars, d_lens, c, W, L.npart, poff, pcursor, part_pay, \
+                                                                        (LOWT*)part_low);                                         \
+  } while (0)
+    if (c == 15 && W == 17) CQ_PART_PASS1(15, 17, uint8_t);
+    else if (c == 16 && W == 16) CQ_PART_PASS1(16, 16, uint8_t);
+    else if (c == 17 && W == 15) CQ_PART_PASS1(17, 15, uint8_t);
+    else if (c == 18 && W == 15) CQ_PART_PASS1(18, 15, uint16_t);
+    else if (c == 19 && W == 14) CQ_PART_PASS1(19, 14, uint16_t);
+    else if (c == 20 && W == 13) CQ_PART_PASS1(20, 13, uint16_t);
+    else if (L.mid) CQ_PART_PASS1(0, 0, uint16_t);
+    else CQ_PART_PASS1(0, 0, uint8_t);
+#undef CQ_PART_PASS1
+    // workgroups per partition in the bucket passes: PART_SPLIT when partitions hold many tiles, one when they hold one
+    auto split_for = [&](uint32_t parts) {
+      const uint64_t tiles = (uint64_t)W * n * batch / ((uint64_t)parts * PART_TILE) + 1;
+      return (uint32_t)std::min<uint64_t>(PART_SPLIT, tiles);
+    };
+    const uint32_t* fpay = part_pay;
+    const uint8_t* flow = (const uint8_t*)part_low;
+    const uint32_t* fpoff = poff;
+    uint32_t F = P;
+    if (L.mid) {  // 128 partitions of 2^(c-8) buckets -> partitions of 128 buckets
+      const uint16_t* low1 = (const uint16_t*)part_low;
+      uint32_t* pay2 = (uint32_t*)(low1 + E);
+      uint8_t* low2 = (uint8_t*)(pay2 + E);
+      uint32_t* poff2 = (uint32_t*)(ws + L.off_poff2);
+      uint32_t* psize2 = (uint32_t*)(ws + L.off_psize2);
+      F = batch * L.nfinal;
+      const uint32_t bins_log = L.shift1 - PART_BITS;
+      msm_refine_count_kernel<<<dim3(P, PART_SPLIT), PART_THREADS, 0, s>>>(low1, poff, bins_log, psize2);
+      msm_part_scan_kernel<<<1, 1024, 0, s>>>(psize2, F, poff2);
+      msm_refine_place_kernel<<<dim3(P, PART_SPLIT), PART_THREADS, 0, s>>>(part_pay, low1, poff, bins_log, poff2, psize2 + F, pay2, low2);
+      fpay = pay2;
+      flow = low2;
+      fpoff = poff2;
+    }
+    const uint32_t split = split_for(F);
+    const bool wide = !L.mid && L.shift1 == PART_BITS_WIDE;  // 256 buckets per partition
+    if (wide) msm_bucket_count_kernel<PART_BITS_WIDE><<<dim3(F, split), PART_THREADS, 0, s>>>(flow, fpoff, counts);
+    else msm_bucket_count_kernel<PART_BITS><<<dim3(F, split), PART_THREADS, 0, s>>>(flow, fpoff, counts);
     if (any_alias) msm_alias_counts_kernel<<<dim3((L.B + 255) / 256, batch), 256, 0, s>>>(counts, d_src, L.B);
     msm_scan_reduce_kernel<<<L.nblk, 256, 0, s>>>(counts, Bt, L.nseq, s1, blocksums);
     msm_scan_spine_kernel<<<1, 1024, 0, s>>>(blocksums, L.nblk, L.nseq);
     msm_scan_apply_kernel<<<L.nblk, 256, 0, s>>>(counts, Bt, L.nseq, s1, blocksums, off, tk);
-    msm_bucket_place_kernel<<<dim3(P, PART_SPLIT), PART_THREADS, 0, s>>>(part_pay, part_low, poff, off0, cursor, sorted);
+    if (wide) msm_bucket_place_kernel<PART_BITS_WIDE><<<dim3(F, split), PART_THREADS, 0, s>>>(fpay, flow, fpoff, off0, cursor, sorted);
+    else msm_bucket_place_kernel<PART_BITS><<<dim3(F, split), PART_THREADS, 0, s>>>(fpay, flow, fpoff, off0, cursor, sorted);
   } else {
     msm_digits_kernel<<<dim3((n + 255) / 256, batch), 256, 0, s>>>(d_scalars, d_lens, n, c, W, pre ? 1u : 0u, ranks, counts);
     msm_scan_reduce_kernel<<<L.nblk, 256, 0, s>>>(counts, Bt, L.nseq, s1, blocksums);
@@ -980,6 +1138,20 @@ G1Jac msm_set_value(const G1Jac* planes, uint32_t cols) {
   }
   for (uint32_t l = cols; l > 1; l >>= 1) v = jac_dbl(v);
   return jac_add(jac_add(v, u), planes[14]);
+}
+
+G1Jac msm_fold_sets(const G1Jac* pairs, uint32_t Wb, uint32_t M, uint32_t cols) {
+  G1Jac acc = msm_set_value(pairs, cols);
+  if (Wb == 1) return acc;
+  // sum_s s * T_s by suffix sums (T_s: the set's plain total, its last point), then "* M" by doublings
+  G1Jac run = G1Jac::identity(), weighted = G1Jac::identity();
+  for (uint32_t s = Wb - 1; s >= 1; s--) {
+    run = jac_add(run, pairs[(size_t)MSM_SET_POINTS * s + MSM_SET_POINTS - 1]);
+    weighted = jac_add(weighted, run);
+    acc = jac_add(acc, msm_set_value(pairs + (size_t)MSM_SET_POINTS * s, cols));
+  }
+  for (uint32_t l = M; l > 1; l >>= 1) weighted = jac_dbl(weighted);
+  return jac_add(acc, weighted);
 }
 
 G1Jac msm_fold_windows(const G1Jac* pairs, uint32_t W, uint32_t c, uint32_t cols) {

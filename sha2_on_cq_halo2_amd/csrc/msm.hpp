@@ -57,11 +57,13 @@ struct MsmStrides {
 
 // Workspace carve-up for `batch` MSMs of n terms each with c-bit signed windows.
 struct MsmLayout {
-  uint32_t n, c, batch, W, Wb, M, B, Bt, levels, nseq, nblk, rows, cols, npart;
-  bool pre, part_sort;
+  // M: buckets per bucket SET (the reduction's rows x cols matrix), Wb: sets per MSM, B = Wb * M: buckets per MSM.
+  // Table mode has one set per MSM up to c = 15 (M = 2^(c-1)) and 2^(c-15) sets of 2^14 buckets for wider windows.
+  uint32_t n, c, batch, W, Wb, M, B, Bt, levels, nseq, nblk, rows, cols, npart, nfinal, shift1;
+  bool pre, part_sort, mid;
   uint64_t tmax[8];
-  size_t off_ptrs, off_ranks, off_poff, off_counts, off_cursor, off_psize, off_buckets, zero_end, off_blocksums, off_off, off_tk,
-      off_sorted, off_part[2], off_pairs, total;
+  size_t off_ptrs, off_ranks, off_poff, off_poff2, off_counts, off_cursor, off_psize, off_psize2, off_buckets, zero_end, off_blocksums,
+      off_off, off_tk, off_sorted, off_part[2], off_pairs, total;
   MsmLayout(uint32_t n_, uint32_t c_, uint32_t batch_, bool pre_ = false);
 };
 
@@ -78,6 +80,9 @@ int msm_precompute_tables(cq_ctx* ctx, const G1Affine* bases, uint32_t n, uint32
 // Host: value of one bucket set from its MSM_SET_POINTS points; sum_w 2^(c*w) * (value of set w) over W consecutive sets.
 G1Jac msm_set_value(const G1Jac* planes, uint32_t cols);
 G1Jac msm_fold_windows(const G1Jac* pairs, uint32_t W, uint32_t c, uint32_t cols);
+// Host, table mode with wide windows: the MSM's value from its Wb consecutive sets of M buckets each (set s holds the
+// buckets s * M + 1 .. (s + 1) * M):  sum_s ( value(set s) + s * M * total(set s) )
+G1Jac msm_fold_sets(const G1Jac* pairs, uint32_t Wb, uint32_t M, uint32_t cols);
 
 }  // namespace cq
 
@@ -93,7 +98,7 @@ int cq_msm_multi_v(cq_ctx* c, const cq::Fr* const* scalars, const cq::G1Affine* 
 struct MsmPending {
   struct Launch {
     size_t first = 0, slot = 0;
-    uint32_t batch = 0, c = 0, nmax = 0, W = 0, Wb = 0, cols = 0;
+    uint32_t batch = 0, c = 0, nmax = 0, W = 0, Wb = 0, M = 0, cols = 0;
     bool pre = false, empty = false;
   };
   std::vector<Launch> launches;
@@ -103,7 +108,11 @@ struct MsmPending {
 int msm_multi_begin(cq_ctx* c, const cq::Fr* const* scalars, const cq::G1Affine* const* bases, const size_t* lens, size_t count,
                     MsmPending& pend);
 int msm_multi_end(cq_ctx* c, MsmPending& pend, uint64_t* out_jac);
-constexpr uint32_t MSM_TABLE_C = 15;  // window width of every precomputed table (so launches can mix lengths)
+// Window width of the precomputed tables: one width per context, so that MSMs over different base arrays can share a
+// launch.  15 (17 windows, 2^14 buckets) up to 2^19 terms; wider from 2^20 on, where two or four fewer additions per
+// scalar outweigh the larger bucket reduction (msm_table_window_bits; cq_msm_set_table_window overrides).
+constexpr uint32_t MSM_TABLE_C = 15, MSM_TABLE_C_MIN = 8, MSM_TABLE_C_MAX = 20;
+uint32_t msm_table_window_bits(size_t n);
 
 int msm_register_tables(cq_ctx* c, const cq::G1Affine* bases, size_t n);
 void msm_unregister_tables(cq_ctx* c, const void* bases);

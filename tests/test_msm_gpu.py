@@ -169,6 +169,39 @@ def test_msm_batch_with_repeated_scalar_vector(ctx):
     assert np.array_equal(got[0], exp[0]) and np.array_equal(got[1], exp[1]) and np.array_equal(got[2], exp[0])
 
 
+@pytest.mark.parametrize("c", [8, 12, 14, 16, 17, 18, 19, 20])
+def test_msm_table_window_widths(ctx, c):
+    """Tables of other window widths than the default 15 (cq_msm_set_table_window): narrower ones have fewer partitions,
+    wider ones 2^(c-15) bucket sets per MSM and a refinement pass in the sort.  A launch of four MSMs (uniform scalars,
+    a 0/1 column, one repeated value, and the first vector again) over 70 001 points against the C oracle."""
+    from oracle import cbind as OC
+
+    n = 70001
+    pts = B.points_to_mont_limbs(random_points(2048, 300 + c))
+    pts = np.tile(pts, ((n + 2047) // 2048, 1))[:n]
+    rs = np.random.RandomState(c)
+    uni = rs.randint(0, 2**63, size=(n, 4), dtype=np.int64).astype(np.uint64)
+    uni[:, 3] &= np.uint64((1 << 60) - 1)
+    rng = B.Xoshiro256ss(c)
+    bits = B.to_mont_limbs([rng.next_u64() & 1 for _ in range(n)])
+    const = np.tile(B.to_mont_limbs([B.fr_random(rng)]), (n, 1))
+    vecs = [uni, bits, const]
+    dpts = ctx.to_device(pts)
+    ctx.set_msm_table_window(c)
+    try:
+        ctx.msm_precompute(dpts.ptr, n)
+    finally:
+        ctx.set_msm_table_window(0)
+    dev = [ctx.to_device(v) for v in vecs]
+    order = [0, 1, 2, 0]
+    res = ctx.msm_batch_dev([dev[i].ptr for i in order], dpts.ptr, n)
+    exp = [OC.g1_to_affine(OC.best_multiexp(v, pts)) for v in vecs]
+    for j, i in enumerate(order):
+        assert np.array_equal(OC.g1_to_affine(res[j]), exp[i]), "MSM %d differs from the oracle at c = %d" % (j, c)
+    m = n - 4099  # a prefix of the registered array
+    assert np.array_equal(OC.g1_to_affine(ctx.best_multiexp_dev(dev[0], dpts, m)), OC.g1_to_affine(OC.best_multiexp(uni[:m], pts[:m])))
+
+
 def test_msm_k18_round2_shaped_launch_matches_c_oracle(ctx):
     """One table-mode launch of the size a k = 18 proof really issues: 11 multiexps of 2^18 terms over a registered
     SRS array in ONE cq_msm_batch_dev call (~49 M sorted entries, equal sub-lists, shared lists for the repeated
