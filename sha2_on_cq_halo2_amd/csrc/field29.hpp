@@ -181,7 +181,33 @@ struct Fp29 {
     return r;
   }
   __device__ __forceinline__ Fp29 operator*(const Fp29& o) const { return mul(*this, o); }
-  __device__ __forceinline__ Fp29 sqr() const { return mul(*this, *this); }
+  // x^2: the 36 cross products once, against doubled limbs (45 multiplies instead of 81).  Limbs < 2^30 as for mul():
+  // a column holds at most 4 cross products < 2^61, a square < 2^60 and the reduction's 9 * 2^58 -- below 2^64.
+  __device__ __forceinline__ Fp29 sqr() const {
+#ifdef CQ_NO_SQR  // A/B knob (tools/ab_flags_stats.sh): accumulate kernel 1.10 -> 1.07 ms per k = 18 launch with the squaring
+    return mul(*this, *this);
+#endif
+    uint64_t c[18];
+    uint32_t d[9];
+    CQ_UNROLL for (int k = 0; k < 18; k++) c[k] = 0;
+    CQ_UNROLL for (int i = 0; i < 9; i++) d[i] = a[i] << 1;
+    CQ_UNROLL for (int i = 0; i < 9; i++) {
+      c[2 * i] += (uint64_t)a[i] * a[i];
+      CQ_UNROLL for (int j = i + 1; j < 9; j++) c[i + j] += (uint64_t)a[i] * d[j];
+    }
+    CQ_UNROLL for (int i = 0; i < 9; i++) {
+      const uint32_t m = ((uint32_t)c[i] * NINV) & M29;
+      CQ_UNROLL for (int j = 0; j < 9; j++) c[i + j] += (uint64_t)m * pl(j);
+      c[i + 1] += c[i] >> 29;
+    }
+    Fp29 r;
+    CQ_UNROLL for (int k = 0; k < 8; k++) {
+      r.a[k] = (uint32_t)c[9 + k] & M29;
+      c[10 + k] += c[9 + k] >> 29;
+    }
+    r.a[8] = (uint32_t)c[17];
+    return r;
+  }
 
   // limb-wise sum (no carries): limbs < 2^30 for two normalised operands
   __device__ __forceinline__ Fp29 operator+(const Fp29& o) const {
