@@ -441,6 +441,15 @@ int cq_cq_round2_dev(cq_pk* pk, const uint64_t* f_dev, const uint32_t* m_dev, co
  * what vanishing::Argument::construct does next, vanishing/prover.rs:84).  h_out_dev: ext elements (may alias h_in_dev). */
 int cq_quotient_dev(cq_pk* pk, const uint64_t* b_coeff_dev, const uint64_t* f_coeff_dev, const uint64_t y[4], const uint64_t beta[4],
                     const uint64_t* h_in_dev, int divide_by_vanishing, uint64_t* h_out_dev);
+/* permute_expression_pair of the legacy (halo2) lookup argument, plonk/lookup/prover.rs:400-502, without the blinding rows
+ * it appends (:486-497, the caller's RNG): the first `usable` rows of the compressed input expression sorted by canonical
+ * value, and the compressed table expression rearranged so that every first occurrence of an input value faces the same
+ * table value and the remaining table values fill the repeated rows the way the reference does (ascending values into
+ * descending rows).  All arrays: device, Montgomery-form field elements; the outputs hold `usable` elements and may not
+ * alias the inputs.  2^k >= usable is the domain size (sizes the sort).  CQ_ERR_LOOKUP when an input value is missing from
+ * the table (Error::ConstraintSystemFailure, :456-460). */
+int cq_permute_expression_pair_dev(cq_ctx* ctx, uint32_t k, uint32_t usable, const uint64_t* input_dev, const uint64_t* table_dev,
+                                   uint64_t* permuted_input_dev, uint64_t* permuted_table_dev);
 /* The verifying-key commitments the prover's key implies: commit_lagrange of every fixed column
  * (keygen.rs:247-250) and of every permutation polynomial (permutation/keygen.rs:115-149), as affine
  * points (num_fixed x 8 and num_perm_columns x 8 words). */

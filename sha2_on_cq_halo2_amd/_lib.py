@@ -70,6 +70,7 @@ def _declare_msm(lib):
     lib.cq_msm_batch_dev.argtypes = [vp, vp, vp, C.c_size_t, C.c_size_t, vp]
     lib.cq_msm_set_window.argtypes = [vp, C.c_uint32]
     lib.cq_msm_set_table_window.argtypes = [vp, C.c_uint32]
+    lib.cq_permute_expression_pair_dev.argtypes = [vp, C.c_uint32, C.c_uint32, vp, vp, vp, vp]
     lib.cq_params_create.argtypes = [vp, C.c_uint32, vp, vp, C.POINTER(vp)]
     lib.cq_params_destroy.restype = None
     lib.cq_params_destroy.argtypes = [vp]

@@ -152,7 +152,20 @@ def _ctx_set_msm_table_window(self, bits: int):
     self._chk(self.lib.cq_msm_set_table_window(self.h, bits))
 
 
+def _ctx_permute_expression_pair(self, k: int, input_values: np.ndarray, table_values: np.ndarray):
+    """`permute_expression_pair` (plonk/lookup/prover.rs:400-502) on the device, without the blinding rows: returns the
+    permuted input and table (Montgomery limbs, `usable` rows each).  Raises on an input value the table does not hold."""
+    a, t = _fr(input_values), _fr(table_values)
+    assert a.shape == t.shape
+    usable = a.shape[0]
+    da, dt = self.to_device(a), self.to_device(t)
+    oa, ot = self.alloc(usable * 32), self.alloc(usable * 32)
+    self._chk(self.lib.cq_permute_expression_pair_dev(self.h, k, usable, da.ptr, dt.ptr, oa.ptr, ot.ptr))
+    return oa.download((usable, 4), np.uint64), ot.download((usable, 4), np.uint64)
+
+
 Context.set_msm_table_window = _ctx_set_msm_table_window
+Context.permute_expression_pair = _ctx_permute_expression_pair
 Context.best_multiexp = _ctx_best_multiexp
 Context.best_multiexp_dev = _ctx_best_multiexp_dev
 Context.msm_batch_dev = _ctx_msm_batch_dev

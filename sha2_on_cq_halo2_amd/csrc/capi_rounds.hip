@@ -4,6 +4,7 @@
 //   cq_cq_round2_dev  = static_lookup::Committed::commit_log_derivatives (:187-342)
 //   cq_quotient_dev   = the static-lookup terms of Evaluator::evaluate_h (plonk/evaluation.rs:533-548), optionally followed
 //                       by EvaluationDomain::divide_by_vanishing_poly (poly/domain.rs:319-338)
+//   cq_permute_expression_pair_dev = permute_expression_pair of the legacy lookup argument (plonk/lookup/prover.rs:400-502)
 // They run the same kernels as cq_create_proof (prover.hip), without its cross-round overlap.
 #include <algorithm>
 #include <cstring>
@@ -245,6 +246,30 @@ int cq_quotient_dev(cq_pk* pk, const uint64_t* b_coeff_dev, const uint64_t* f_co
   qa.y = Fr::from_limbs64(y);
   qa.beta = Fr::from_limbs64(beta);
   return poly_cq_quotient(c, qa, (uint32_t)ext, (Fr*)h_out_dev);
+}
+
+/* permute_expression_pair (plonk/lookup/prover.rs:400-502) without its blinding rows: device sort and matching, lksort.hip */
+int cq_permute_expression_pair_dev(cq_ctx* c, uint32_t k, uint32_t usable, const uint64_t* input_dev, const uint64_t* table_dev,
+                                   uint64_t* permuted_input_dev, uint64_t* permuted_table_dev) {
+  if (!c || k > 28 || usable > (1u << k) || (usable && (!input_dev || !table_dev || !permuted_input_dev || !permuted_table_dev)))
+    return CQ_ERR_ARG;
+  CQ_HIP(c, hipSetDevice(c->device));
+  const size_t slot = ((size_t)1 << k) * 4;
+  void* scr;
+  CQ_TRY(c->ensure_scratch(7, 3 * slot * sizeof(uint64_t) + lookup_permute_scratch_bytes(k) + 64, &scr));
+  uint64_t* stage = (uint64_t*)scr;
+  void* lk_scratch = stage + 3 * slot;
+  uint32_t* status = (uint32_t*)((char*)lk_scratch + lookup_permute_scratch_bytes(k));
+  CQ_TRY(fr_to_canonical(c, (const Fr*)input_dev, usable, stage));
+  CQ_TRY(fr_to_canonical(c, (const Fr*)table_dev, usable, stage + slot));
+  CQ_TRY(lookup_permute_dev(c, stage, stage + slot, usable, k, stage + 2 * slot, lk_scratch, status));
+  CQ_TRY(fr_from_canonical(c, stage, usable, (Fr*)permuted_input_dev));
+  CQ_TRY(fr_from_canonical(c, stage + 2 * slot, usable, (Fr*)permuted_table_dev));
+  uint32_t st[3];
+  CQ_HIP(c, hipMemcpyAsync(st, status, sizeof(st), hipMemcpyDeviceToHost, c->stream));
+  CQ_HIP(c, hipStreamSynchronize(c->stream));
+  if (st[0] != 0 || st[1] != st[2]) return c->fail(CQ_ERR_LOOKUP, "lookup input not in table (Error::ConstraintSystemFailure)");
+  return CQ_OK;
 }
 
 }  // extern "C"

@@ -94,6 +94,10 @@ int lookup_numerators(cq_ctx* c, const Fr* cin, const Fr* ctab, const Fr& beta, 
 int lookup_h_terms(cq_ctx* c, const LookupHArgs& a, Fr* h);
 // Montgomery <-> canonical limbs (the host sorts canonical values, derive/field.rs `Ord`)
 int fr_to_canonical(cq_ctx* c, const Fr* in, uint32_t n, uint64_t* out);
+// permute_expression_pair on the device (lksort.hip)
+size_t lookup_permute_scratch_bytes(uint32_t k);
+int lookup_permute_dev(cq_ctx* c, uint64_t* in_canon, uint64_t* tab_canon, uint32_t u, uint32_t k, uint64_t* out_tab, void* scratch,
+                       uint32_t* status_dev);
 int fr_from_canonical(cq_ctx* c, const uint64_t* in, uint32_t n, Fr* out);
 
 }  // namespace cq

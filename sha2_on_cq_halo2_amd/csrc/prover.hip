@@ -427,53 +427,6 @@ int eval_many(cq_ctx* c, const std::vector<const Fr*>& ps, const std::vector<uin
   return CQ_OK;
 }
 
-// `permute_expression_pair` (plonk/lookup/prover.rs:400-502) on canonical values (4 x u64, little-endian limbs),
-// first `usable` rows.  The reference sorts with `Ord` on field elements (canonical big-endian comparison) and keeps
-// the unused table values in a BTreeMap; here: one sort of each side and a run-length walk.  Runs on the host.
-struct U256Less {
-  bool operator()(const std::array<uint64_t, 4>& a, const std::array<uint64_t, 4>& b) const {
-    for (int i = 3; i >= 0; i--)
-      if (a[i] != b[i]) return a[i] < b[i];
-    return false;
-  }
-};
-bool permute_expression_pair_host(std::vector<std::array<uint64_t, 4>>& input, std::vector<std::array<uint64_t, 4>>& table) {
-  const size_t usable = input.size();
-  std::sort(input.begin(), input.end(), U256Less());
-  std::vector<std::array<uint64_t, 4>> sorted_table(table);
-  std::sort(sorted_table.begin(), sorted_table.end(), U256Less());
-  // leftover_table_map: distinct values ascending with their multiplicities
-  std::vector<std::array<uint64_t, 4>> keys;
-  std::vector<uint32_t> counts;
-  for (size_t i = 0; i < usable; i++) {
-    if (i == 0 || sorted_table[i] != sorted_table[i - 1]) {
-      keys.push_back(sorted_table[i]);
-      counts.push_back(1);
-    } else {
-      counts.back()++;
-    }
-  }
-  std::vector<std::array<uint64_t, 4>> out(usable, std::array<uint64_t, 4>{0, 0, 0, 0});
-  std::vector<size_t> repeated;
-  for (size_t row = 0; row < usable; row++) {
-    if (row == 0 || input[row] != input[row - 1]) {
-      out[row] = input[row];
-      auto it = std::lower_bound(keys.begin(), keys.end(), input[row], U256Less());
-      if (it == keys.end() || *it != input[row] || counts[it - keys.begin()] == 0) return false;  // Error::ConstraintSystemFailure
-      counts[it - keys.begin()]--;
-    } else {
-      repeated.push_back(row);
-    }
-  }
-  for (size_t kq = 0; kq < keys.size(); kq++)
-    for (uint32_t q = 0; q < counts[kq]; q++) {
-      out[repeated.back()] = keys[kq];
-      repeated.pop_back();
-    }
-  table.swap(out);
-  return repeated.empty();
-}
-
 }  // namespace
 
 size_t prover_arena_elems(const cq_pk* pk) {
@@ -821,28 +774,30 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, const uint64_
     return gate_eval(c, ga, dst);
   };
   if (PL) {
+    // permute_expression_pair (lookup/prover.rs:400-502) on the device: canonical values, sorted and matched there
+    // (lksort.hip), back to Montgomery form; one status read-back per lookup
     void* stage_v;
-    CQ_TRY(c->ensure_scratch(7, (size_t)2 * u * 32 + 64, &stage_v));
+    const size_t slot = n * 4;  // u64 words of one array of 2^k canonical values
+    CQ_TRY(c->ensure_scratch(7, 3 * slot * sizeof(uint64_t) + lookup_permute_scratch_bytes(k) + 64, &stage_v));
     uint64_t* stage = (uint64_t*)stage_v;
-    std::vector<std::array<uint64_t, 4>> hin(u), htab(u);
+    void* lk_scratch = stage + 3 * slot;
+    uint32_t* lk_status = (uint32_t*)((char*)lk_scratch + lookup_permute_scratch_bytes(k));
+    uint32_t* lk_status_host = (uint32_t*)((char*)c->pinned_small + 16);  // beside the lookup error flag
     for (size_t l = 0; l < PL; l++) {
       const auto& lk = pk->legacy[l];
       CQ_TRY(lagrange_compress(pk->legacy_prog + lk.in_off, lk.width, theta, plk_buf(l, 0)));
       CQ_TRY(lagrange_compress(pk->legacy_prog + lk.tab_off, lk.width, theta, plk_buf(l, 1)));
-      // permute_expression_pair (:400-502): canonical values to the host, sorted there, back to Montgomery form
       CQ_TRY(fr_to_canonical(c, plk_buf(l, 0), u, stage));
-      CQ_TRY(fr_to_canonical(c, plk_buf(l, 1), u, stage + 4 * (size_t)u));
-      CQ_HIP(c, hipMemcpyAsync(hin.data(), stage, (size_t)u * 32, hipMemcpyDeviceToHost, s));
-      CQ_HIP(c, hipMemcpyAsync(htab.data(), stage + 4 * (size_t)u, (size_t)u * 32, hipMemcpyDeviceToHost, s));
-      CQ_HIP(c, hipStreamSynchronize(s));
-      if (!permute_expression_pair_host(hin, htab)) return c->fail(CQ_ERR_LOOKUP, "lookup input not in table (Error::ConstraintSystemFailure)");
-      CQ_HIP(c, hipMemcpyAsync(stage, hin.data(), (size_t)u * 32, hipMemcpyHostToDevice, s));
-      CQ_HIP(c, hipMemcpyAsync(stage + 4 * (size_t)u, htab.data(), (size_t)u * 32, hipMemcpyHostToDevice, s));
+      CQ_TRY(fr_to_canonical(c, plk_buf(l, 1), u, stage + slot));
+      CQ_TRY(lookup_permute_dev(c, stage, stage + slot, u, k, stage + 2 * slot, lk_scratch, lk_status));
+      CQ_HIP(c, hipMemcpyAsync(lk_status_host, lk_status, 3 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
       CQ_TRY(fr_from_canonical(c, stage, u, plk_buf(l, 2)));
-      CQ_TRY(fr_from_canonical(c, stage + 4 * (size_t)u, u, plk_buf(l, 3)));
+      CQ_TRY(fr_from_canonical(c, stage + 2 * slot, u, plk_buf(l, 3)));
       CQ_HIP(c, hipMemcpyAsync(plk_buf(l, 2) + u, plk_tails.data() + l * 2 * (bf + 1), (bf + 1) * sizeof(Fr), hipMemcpyHostToDevice, s));
       CQ_HIP(c, hipMemcpyAsync(plk_buf(l, 3) + u, plk_tails.data() + l * 2 * (bf + 1) + (bf + 1), (bf + 1) * sizeof(Fr), hipMemcpyHostToDevice, s));
-      CQ_HIP(c, hipStreamSynchronize(s));  // hin / htab are reused by the next lookup
+      CQ_HIP(c, hipStreamSynchronize(s));  // the staging arrays are reused by the next lookup
+      if (lk_status_host[0] != 0 || lk_status_host[1] != lk_status_host[2])
+        return c->fail(CQ_ERR_LOOKUP, "lookup input not in table (Error::ConstraintSystemFailure)");
     }
   }
 

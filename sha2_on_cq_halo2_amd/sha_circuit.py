@@ -181,6 +181,8 @@ class ShaPlonkWorkload(ShaCqWorkload):
     each row (gate `q * (a0 + 2^16 * a2 - w)`), `w2[r] = w[r+1]` (gate `q * (w2 - w@next)` and, for every row, a
     copy constraint (w2, r) == (w, r+1)); permutation over (w, w2) -> two product sets at degree 3."""
 
+    legacy_lookup = False  # class attribute: set before construction to add a halo2 (permutation-based) lookup as well
+
     def _make_pk(self, lookups):
         from . import plonk as GP
 
@@ -188,6 +190,7 @@ class ShaPlonkWorkload(ShaCqWorkload):
         cs = GP.ConstraintSystem()
         adv = [cs.advice_column() for _ in range(2 * pairs + 2)]
         q = cs.fixed_column()
+        tcol = cs.fixed_column() if self.legacy_lookup else None
         w, w2 = adv[2 * pairs], adv[2 * pairs + 1]
         cs.enable_equality(w)
         cs.enable_equality(w2)
@@ -196,6 +199,8 @@ class ShaPlonkWorkload(ShaCqWorkload):
         cs.create_gate("shift", [qe * (cs.query_advice(w2) - cs.query_advice(w, 1))])
         for lk in lookups:
             cs.lookup_static("limb", [(adv[c], t) for c, t in lk])
+        if tcol is not None:  # the first limb column against a fixed column holding 0 .. 4095 (plonk/lookup.rs, `lookup_any`)
+            cs.lookup("limb12", [(cs.query_advice(adv[0]), cs.query_fixed(tcol))])
         self.cs = cs
         u = n - (cs.blinding_factors() + 1)
         self.rows = u - 1  # gate / copy rows: w@next must stay inside the usable rows
@@ -208,8 +213,11 @@ class ShaPlonkWorkload(ShaCqWorkload):
         r = np.arange(self.rows, dtype=np.uint32)
         mapping[1, r, 0], mapping[1, r, 1] = 0, r + 1
         mapping[0, r + 1, 0], mapping[0, r + 1, 1] = 1, r
+        fixed = [qcol]
+        if tcol is not None:
+            fixed.append(small_to_mont(np.arange(n, dtype=np.uint64) & np.uint64(0xFFF)))
         return ProvingKey(self.ctx, self.params, self.k, 0, [], self.cfg, self.params.g_dev + 64, fr_to_mont(0xC0FFEE + self.k),
-                          cs=cs, fixed=[qcol], permutation=mapping)
+                          cs=cs, fixed=fixed, permutation=mapping)
 
     def _extra_witness(self, words):
         n, pairs, u = self.n, self.pairs, self.pk.usable_rows

@@ -198,6 +198,38 @@ def test_legacy_lookup_failure_is_an_error(ctx):
         CP.create_proof(fx["params"], fx["pk"], adv, B.Xoshiro256ss(1), instances=fx["instances"])
 
 
+@pytest.mark.parametrize("k,usable,distinct", [(3, 2, 2), (5, 26, 7), (10, 1018, 50), (11, 2042, 2042), (12, 4090, 300),
+                                               (14, 16378, 5000), (16, 65530, 65530), (16, 40000, 1), (17, 131066, 9)])
+def test_permute_expression_pair_matches_oracle(ctx, k, usable, distinct):
+    """`permute_expression_pair` (lookup/prover.rs:400-502) on the device -- a bitonic sort of the canonical values, LDS and
+    streaming steps, first-occurrence claims, leftovers into the repeated rows -- against the oracle's restatement
+    (oracle/plonk.py), value for value: small domains (one block), one LDS tile, several merge phases; inputs with few
+    and with all-distinct values; a table with duplicates; a usable range that is not the whole domain."""
+    from oracle import plonk as OP
+    from sha2_on_cq_halo2_amd import CqError
+
+    rs = np.random.RandomState(k * 1000 + distinct)
+    rng = B.Xoshiro256ss(k + distinct)
+    values = [B.fr_random(rng) for _ in range(min(distinct, 64))] + [int(v) for v in rs.randint(0, 1 << 62, size=max(0, distinct - 64))]
+    values = list(dict.fromkeys(values))
+    # table: every value at least once, padded with repeats of the first ones; input: values drawn from the table
+    table = [values[i % len(values)] for i in range(usable)]
+    table = [table[i] for i in rs.permutation(usable)]
+    inp = [values[int(i)] for i in rs.randint(0, min(len(values), usable), size=usable)]
+    n, bf = 1 << k, (1 << k) - usable - 1
+    exp_in, exp_tab = OP.permute_expression_pair(n, bf, inp, table, B.Xoshiro256ss(1))
+    got_in, got_tab = ctx.permute_expression_pair(k, B.to_mont_limbs(inp), B.to_mont_limbs(table))
+    assert np.array_equal(got_in, B.to_mont_limbs(exp_in[:usable]))
+    assert np.array_equal(got_tab, B.to_mont_limbs(exp_tab[:usable]))
+    if usable > 1 and len(values) > 1:  # an input value the table does not hold
+        bad = list(inp)
+        bad[usable // 2] = (max(values) + 1) % P
+        if bad[usable // 2] not in values:
+            with pytest.raises(CqError) as e:
+                ctx.permute_expression_pair(k, B.to_mont_limbs(bad), B.to_mont_limbs(table))
+            assert e.value.code == -4
+
+
 @pytest.mark.parametrize("seed", range(int(os.environ.get("CQ_FUZZ_SEEDS", "12"))))  # CQ_FUZZ_SEEDS=100 for a long run
 def test_random_circuits_proof_bytes_match_oracle(ctx, seed):
     """Fuzz: random gates (random expression trees, rotations in [-2, 2]), random column mix, random copy
