@@ -321,11 +321,126 @@ struct Fp {
     return acc;
   }
   // Fermat inversion a^(p-2) (fr.rs:200-209); inverse of zero is zero.
-  CQ_HD Fp inv() const {
+  CQ_HD Fp inv_fermat() const {
     uint32_t e[8];
     CQ_UNROLL for (int i = 0; i < 8; i++) e[i] = P::MOD[i];
     e[0] -= 2;  // low limb of both moduli is >= 2
     return pow(e);
+  }
+  // the inverse every caller uses: the same field element (inverse of zero is zero), a tenth of the work
+  CQ_HD Fp inv() const { return inv_safegcd(); }
+  // The same inverse by Bernstein-Yang "safegcd" division steps (the 30-bit-limb form used by libsecp256k1's modinv32,
+  // restated): 20 batches of 30 branch-free steps on the low words of (f, g) = (p, x) build a 2 x 2 transition matrix
+  // with entries below 2^30, which is then applied to the 9-limb f, g (exactly divisible by 2^30) and to d, e modulo p.
+  // 600 >= the 590 steps a 256-bit modulus needs.  ~12 000 dependent instructions instead of the ~40 000 of the binary
+  // Euclid below: where ONE lane inverts (the total of a batch inversion) that chain is what the workgroup waits for.
+  CQ_HD Fp inv_safegcd() const {
+    if (is_zero()) return zero();
+    constexpr int32_t M30 = 0x3fffffff;
+    constexpr uint32_t PINV30 = (0u - P::INV) & 0x3fffffffu;  // p^-1 mod 2^30
+    int32_t d[9], e[9], f[9], g[9], pm[9];
+    CQ_UNROLL for (int i = 0; i < 9; i++) {
+      const int bit = 30 * i, word = bit >> 5, sh = bit & 31;
+      uint64_t tp = P::MOD[word], tx = v.l[word];
+      if (word + 1 < 8) {
+        tp |= (uint64_t)P::MOD[word + 1] << 32;
+        tx |= (uint64_t)v.l[word + 1] << 32;
+      }
+      pm[i] = (int32_t)((tp >> sh) & M30);
+      f[i] = pm[i];
+      g[i] = (int32_t)((tx >> sh) & M30);
+      d[i] = 0;
+      e[i] = i == 0 ? 1 : 0;
+    }
+    int32_t zeta = -1;  // -(delta + 1/2)
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 1
+#endif
+    for (int batch = 0; batch < 20; batch++) {
+      // 30 division steps on the low words; (u, v; q, r) = the transition matrix times 2^30
+      uint32_t u = 1, vv = 0, q = 0, r = 1, fl = (uint32_t)f[0] | ((uint32_t)f[1] << 30), gl = (uint32_t)g[0] | ((uint32_t)g[1] << 30);
+      CQ_UNROLL for (int i = 0; i < 30; i++) {
+        uint32_t m1 = (uint32_t)(zeta >> 31);
+        const uint32_t m2 = 0u - (gl & 1u);
+        const uint32_t x = (fl ^ m1) - m1, y = (u ^ m1) - m1, z = (vv ^ m1) - m1;
+        gl += x & m2;
+        q += y & m2;
+        r += z & m2;
+        m1 &= m2;
+        zeta = (int32_t)((uint32_t)zeta ^ m1) - 1;
+        fl += gl & m1;
+        u += q & m1;
+        vv += r & m1;
+        gl >>= 1;
+        u <<= 1;
+        vv <<= 1;
+      }
+      const int64_t tu = (int32_t)u, tv = (int32_t)vv, tq = (int32_t)q, tr = (int32_t)r;
+      {  // (d, e) <- (t / 2^30) (d, e) mod p, both kept in (-2p, p)
+        const int32_t sd = d[8] >> 31, se = e[8] >> 31;
+        int32_t md = ((int32_t)tu & sd) + ((int32_t)tv & se), me = ((int32_t)tq & sd) + ((int32_t)tr & se);
+        int64_t cd = tu * d[0] + tv * e[0], ce = tq * d[0] + tr * e[0];
+        md -= (int32_t)((PINV30 * (uint32_t)cd + (uint32_t)md) & (uint32_t)M30);
+        me -= (int32_t)((PINV30 * (uint32_t)ce + (uint32_t)me) & (uint32_t)M30);
+        cd += (int64_t)pm[0] * md;
+        ce += (int64_t)pm[0] * me;
+        cd >>= 30;
+        ce >>= 30;
+        CQ_UNROLL for (int i = 1; i < 9; i++) {
+          cd += tu * d[i] + tv * e[i] + (int64_t)pm[i] * md;
+          ce += tq * d[i] + tr * e[i] + (int64_t)pm[i] * me;
+          d[i - 1] = (int32_t)cd & M30;
+          e[i - 1] = (int32_t)ce & M30;
+          cd >>= 30;
+          ce >>= 30;
+        }
+        d[8] = (int32_t)cd;
+        e[8] = (int32_t)ce;
+      }
+      {  // (f, g) <- (t / 2^30) (f, g), exact
+        int64_t cf = tu * f[0] + tv * g[0], cg = tq * f[0] + tr * g[0];
+        cf >>= 30;
+        cg >>= 30;
+        CQ_UNROLL for (int i = 1; i < 9; i++) {
+          cf += tu * f[i] + tv * g[i];
+          cg += tq * f[i] + tr * g[i];
+          f[i - 1] = (int32_t)cf & M30;
+          g[i - 1] = (int32_t)cg & M30;
+          cf >>= 30;
+          cg >>= 30;
+        }
+        f[8] = (int32_t)cf;
+        g[8] = (int32_t)cg;
+      }
+    }
+    // now g = 0, f = +-1, d = +-x^-1 in (-2p, p): into [0, p)
+    {
+      int32_t add = d[8] >> 31;
+      const int32_t neg = f[8] >> 31;
+      CQ_UNROLL for (int i = 0; i < 9; i++) {
+        d[i] += pm[i] & add;
+        d[i] = (d[i] ^ neg) - neg;
+      }
+      CQ_UNROLL for (int i = 0; i < 8; i++) {
+        d[i + 1] += d[i] >> 30;
+        d[i] &= M30;
+      }
+      add = d[8] >> 31;
+      CQ_UNROLL for (int i = 0; i < 9; i++) d[i] += pm[i] & add;
+      CQ_UNROLL for (int i = 0; i < 8; i++) {
+        d[i + 1] += d[i] >> 30;
+        d[i] &= M30;
+      }
+    }
+    Fp y;
+    CQ_UNROLL for (int w = 0; w < 8; w++) {
+      const int bit = 32 * w, li = bit / 30, sh = bit - 30 * li;  // word w = bits of limbs li, li + 1 (and li + 2 when sh > 28)
+      uint64_t t = (uint64_t)(uint32_t)d[li] >> sh;
+      t |= (uint64_t)(uint32_t)d[li + 1] << (30 - sh);
+      if (li + 2 < 9) t |= (uint64_t)(uint32_t)d[li + 2] << (60 - sh);
+      y.v.l[w] = (uint32_t)t;
+    }
+    return y * r3();
   }
   // The same inverse by the binary extended Euclid on the 8 x 32-bit integers: ~750 data-dependent steps of shifts
   // and additions instead of ~380 dependent modular products -- about 3x shorter as a chain.  It diverges across

@@ -31,8 +31,11 @@ static_assert(MSM_S1_BIG >= MSM_S1, "the workspace is sized for MSM_S1");
 // the accumulate kernel -- a chain of dependent additions per lane, ~7 us each -- has a lane per few entries instead of
 // 17-24 of them on a fraction of the SIMDs (k = 14: one 16 384-term MSM was 140 us of pure latency).  A function of the
 // launch's entry BOUND (batch x windows x n), so that the workspace layout and the launch agree.
+#ifndef CQ_MSM_SMALL_LANES
+#define CQ_MSM_SMALL_LANES 65536
+#endif
 constexpr uint32_t MSM_S1_MIN = 4;
-constexpr uint64_t MSM_SMALL_LANES = 65536;
+constexpr uint64_t MSM_SMALL_LANES = CQ_MSM_SMALL_LANES;
 inline uint32_t msm_small_launch_s1(uint64_t entry_bound) {
   if (entry_bound >= (uint64_t)MSM_S1 * MSM_SMALL_LANES) return MSM_S1;
   const uint64_t s = entry_bound / MSM_SMALL_LANES;

@@ -2,6 +2,7 @@
 // between transforms and commitments.  Each replaces a rayon `parallelize` loop or a serial
 // recurrence of the reference (cited per function).  All are HBM-bandwidth bound: one 16-byte-per-lane
 // coalesced read and write per element, arithmetic fused so every vector is touched once.
+#include <cstdlib>
 #include "poly.hpp"
 #include <algorithm>
 #include <cstring>
@@ -97,7 +98,8 @@ __global__ __launch_bounds__(256) void kate_fill_kernel(const Fr* __restrict__ a
 // strided (coalesced) elements.  Each lane keeps its elements in registers, parks the running prefix products in
 // the output array, the lane totals are scanned in LDS (prefix and suffix), lane 0 inverts the block total, and
 // every lane unwinds its own elements: ~5 products per element + one inversion per 4096 elements.
-constexpr int BI_PER_LANE = 16;  // (4 -- four workgroups per CU -- was tried: 290 -> 334 us at 2^20 elements; the lone-lane inversions, now four per CU, are what the kernel waits for)
+// BI_PER_LANE: 16 for large arrays (one inversion per 4096 elements), 4 while the array leaves CUs idle anyway (the chain
+// of a lane -- its elements, two 8-level scans, the inversion -- is then what the launch waits for): poly_batch_invert.
 static __device__ __forceinline__ void bi_put(uint4* lo, uint4* hi, uint32_t t, const Fr& v) {
   lo[t] = make_uint4(v.v.l[0], v.v.l[1], v.v.l[2], v.v.l[3]);
   hi[t] = make_uint4(v.v.l[4], v.v.l[5], v.v.l[6], v.v.l[7]);
@@ -109,6 +111,7 @@ static __device__ __forceinline__ Fr bi_get(const uint4* lo, const uint4* hi, ui
   r.v.l[4] = b.x; r.v.l[5] = b.y; r.v.l[6] = b.z; r.v.l[7] = b.w;
   return r;
 }
+template <int BI_PER_LANE>
 __global__ __launch_bounds__(256) void batch_invert_kernel(Fr* __restrict__ a, uint32_t n) {
   __shared__ uint4 lo[256], hi[256];
   const uint32_t t = threadIdx.x;
@@ -151,7 +154,7 @@ __global__ __launch_bounds__(256) void batch_invert_kernel(Fr* __restrict__ a, u
   __syncthreads();
   const Fr after = t < 255 ? bi_get(lo, hi, t + 1) : Fr::one();
   __syncthreads();
-  if (t == 0) bi_put(lo, hi, 0, total.inv_euclid());
+  if (t == 0) bi_put(lo, hi, 0, total.inv_safegcd());
   __syncthreads();
   const Fr total_inv = bi_get(lo, hi, 0);
   // inverse of (everything up to and including this lane) = total^-1 * (product of the later lanes)
@@ -337,7 +340,11 @@ int poly_kate_division(cq_ctx* c, const Fr* a, uint32_t n, const Fr& z, Fr* q) {
 
 int poly_batch_invert(cq_ctx* c, Fr* a, uint32_t n) {
   if (!n) return CQ_OK;
-  batch_invert_kernel<<<(n + 256 * BI_PER_LANE - 1) / (256 * BI_PER_LANE), 256, 0, c->stream>>>(a, n);
+  static const int forced = getenv("CQ_BI_PER_LANE") ? atoi(getenv("CQ_BI_PER_LANE")) : 0;
+  const int per = forced ? forced : (n <= (1u << 19) ? 4 : 16);
+  if (per == 4) batch_invert_kernel<4><<<(n + 256 * 4 - 1) / (256 * 4), 256, 0, c->stream>>>(a, n);
+  else if (per == 8) batch_invert_kernel<8><<<(n + 256 * 8 - 1) / (256 * 8), 256, 0, c->stream>>>(a, n);
+  else batch_invert_kernel<16><<<(n + 256 * 16 - 1) / (256 * 16), 256, 0, c->stream>>>(a, n);
   return hipGetLastError() == hipSuccess ? CQ_OK : c->fail(CQ_ERR_HIP, "batch_invert launch failed");
 }
 
