@@ -51,7 +51,10 @@ def main():
     ap.add_argument("--no-in-flight", action="store_true")
     ap.add_argument("--no-generic-rng", action="store_true")
     ap.add_argument("--no-k20", action="store_true", help="skip the BASELINE configs[3] leg (k=20, one proof over all ranks)")
+    ap.add_argument("--k20-child", action="store_true", help=argparse.SUPPRESS)  # internal: the configs[3] leg in a process of its own
     args = ap.parse_args()
+    if args.k20_child:
+        return k20_child_main()
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -164,27 +167,13 @@ def main():
     #      takes part; rank 0 keeps the figures.  A watchdog prints the line without it should a collective hang. ----
     k20 = None
     if not args.no_k20 and k == 18:
-        done = {"v": False}
-
-        def bail():
-            if done["v"]:
-                return
-            if rank == 0:
-                out["config3_k20"] = {"error": "timed out (a collective did not complete); headline unaffected"}
-                _finish_line(out, ctx, wl, args, k, acc_ms, acc_calls, ntt_ms, ntt_calls, msm_entries, world, light=True)
-            os._exit(0)
-
-        import threading
-
-        wd = threading.Timer(float(os.environ.get("CQ_BENCH_K20_TIMEOUT", "420")), bail)
-        wd.daemon = True
-        wd.start()
-        try:
-            k20 = config3_k20(ctx, rank, world, local_rank)
-        except Exception as e:  # noqa: BLE001
-            k20 = {"error": f"{type(e).__name__}: {e}"}
-        done["v"] = True
-        wd.cancel()
+        if world == 1 and os.environ.get("CQ_BENCH_K20_CHILD", "0") != "1":  # (the env switch: the child path on one GPU, for testing)
+            try:
+                k20 = config3_k20(ctx, rank, world, local_rank)
+            except Exception as e:  # noqa: BLE001
+                k20 = {"error": f"{type(e).__name__}: {e}"}
+        else:
+            k20 = k20_in_children(rank)
     if rank == 0:
         if k20 is not None:
             out["config3_k20"] = k20
@@ -460,6 +449,63 @@ def pmc_valu_issue():
         return max(rows, key=lambda r: r["valu_wave_instructions"])["valu_issue_utilisation"]
     except Exception:
         return None
+
+
+def k20_in_children(rank):
+    """N > 1: the collective configs[3] leg runs in a CHILD process per rank (same RANK / WORLD_SIZE, rendezvous on another
+    port, a communicator and a library context of its own), so that nothing it does -- a hung collective, a fault inside
+    RCCL on hardware this code has never met -- can take the headline measurement of the parent with it.  Rank 0's child
+    prints the block as JSON; a child that does not finish in time is killed (by pid) and reported as an error."""
+    import subprocess
+
+    env = dict(os.environ)
+    env["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 1000 + int(os.environ.get("WORLD_SIZE", "1")))
+    timeout = float(os.environ.get("CQ_BENCH_K20_TIMEOUT", "240"))
+    try:
+        p = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--k20-child"], env=env, stdout=subprocess.PIPE,
+                             stderr=subprocess.DEVNULL, cwd=os.path.dirname(os.path.abspath(__file__)) or ".")
+    except OSError as e:
+        return {"error": f"could not start the child process: {e}"}
+    try:
+        stdout, _ = p.communicate(timeout=timeout)
+    except subprocess.TimeoutExpired:
+        p.kill()
+        p.communicate()
+        return {"error": f"timed out after {timeout:.0f} s (a collective did not complete); headline unaffected"}
+    if rank != 0:
+        return None
+    for line in reversed(stdout.decode(errors="replace").strip().splitlines()):
+        if line.startswith("{"):
+            try:
+                return json.loads(line)
+            except ValueError:
+                break
+    return {"error": f"child exited with code {p.returncode} and no result; headline unaffected"}
+
+
+def k20_child_main():
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    import torch.distributed as dist
+
+    torch.cuda.set_device(local_rank)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    from sha2_on_cq_halo2_amd import Context
+
+    stream = torch.cuda.Stream(device=local_rank)
+    ctx = Context(local_rank, stream.cuda_stream)
+    try:
+        res = config3_k20(ctx, rank, world, local_rank)
+    except Exception as e:  # noqa: BLE001
+        res = {"error": f"{type(e).__name__}: {e}"}
+    if rank == 0:
+        print(json.dumps(res), flush=True)
+    sys.stdout.flush()
+    os._exit(0)  # no teardown of communicators whose peers may be gone
 
 
 def config3_k20(ctx, rank, world, local_rank, steps=4, warmup=2):
