@@ -202,6 +202,15 @@ def test_msm_table_window_widths(ctx, c):
     assert np.array_equal(OC.g1_to_affine(ctx.best_multiexp_dev(dev[0], dpts, m)), OC.g1_to_affine(OC.best_multiexp(uni[:m], pts[:m])))
 
 
+def test_msm_table_window_argument_range(ctx):
+    from sha2_on_cq_halo2_amd import CqError
+
+    for bad in (1, 7, 21, 64):
+        with pytest.raises(CqError):
+            ctx.set_msm_table_window(bad)
+    ctx.set_msm_table_window(0)
+
+
 def test_msm_k18_round2_shaped_launch_matches_c_oracle(ctx):
     """One table-mode launch of the size a k = 18 proof really issues: 11 multiexps of 2^18 terms over a registered
     SRS array in ONE cq_msm_batch_dev call (~49 M sorted entries, equal sub-lists, shared lists for the repeated

@@ -230,6 +230,28 @@ def test_permute_expression_pair_matches_oracle(ctx, k, usable, distinct):
             assert e.value.code == -4
 
 
+def test_permute_expression_pair_edge_cases(ctx):
+    """Empty and one-row inputs, a usable range equal to the whole domain, and argument errors."""
+    from oracle import plonk as OP
+    from sha2_on_cq_halo2_amd import CqError
+
+    a, t = ctx.permute_expression_pair(4, np.zeros((0, 4), dtype=np.uint64), np.zeros((0, 4), dtype=np.uint64))
+    assert a.shape == (0, 4) and t.shape == (0, 4)
+    one = B.to_mont_limbs([7])
+    a, t = ctx.permute_expression_pair(0, one, one)  # domain of one row
+    assert np.array_equal(a, one) and np.array_equal(t, one)
+    vals = [5, 3, 5, 1, 3, 3, 1, 5]  # usable == 2^k: no padding slots at all
+    tab = [1, 3, 5, 9, 9, 9, 2, 2]
+    exp_in, exp_tab = OP.permute_expression_pair(8, -1, vals, tab, B.Xoshiro256ss(1))
+    a, t = ctx.permute_expression_pair(3, B.to_mont_limbs(vals), B.to_mont_limbs(tab))
+    assert np.array_equal(a, B.to_mont_limbs(exp_in[:8])) and np.array_equal(t, B.to_mont_limbs(exp_tab[:8]))
+    with pytest.raises(CqError):  # more rows than the domain holds
+        ctx.permute_expression_pair(2, B.to_mont_limbs(vals), B.to_mont_limbs(tab))
+    with pytest.raises(CqError) as e:  # 4 is not in the table
+        ctx.permute_expression_pair(3, B.to_mont_limbs([4] + vals[1:]), B.to_mont_limbs(tab))
+    assert e.value.code == -4
+
+
 @pytest.mark.parametrize("seed", range(int(os.environ.get("CQ_FUZZ_SEEDS", "12"))))  # CQ_FUZZ_SEEDS=100 for a long run
 def test_random_circuits_proof_bytes_match_oracle(ctx, seed):
     """Fuzz: random gates (random expression trees, rotations in [-2, 2]), random column mix, random copy
