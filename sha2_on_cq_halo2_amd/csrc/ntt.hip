@@ -163,8 +163,55 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(NttPassArgs a) {
   __syncthreads();
 
   // ---- 2^deg-point DIF in LDS, all T columns at once ----
+  // Templated shapes: two levels at a time in registers (a radix-4 step is the same four products as two radix-2 levels,
+  // but the four elements make ONE round trip through LDS instead of two, the intermediate sums are not normalised, and
+  // there is one barrier per pair of levels); an odd DEG ends with a plain level.  Generic shape: level by level.
+#ifdef CQ_NTT_RADIX2  // A/B knob: level by level as in the generic shape
+  constexpr uint32_t R4 = 0;
+#else
+  constexpr uint32_t R4 = DEG / 2;  // (no radix-4 steps for the generic shape, DEG = 0)
+#endif
 #pragma unroll
-  for (uint32_t rnd = 0; rnd < (DYN ? 6u : DEG); rnd++) {
+  for (uint32_t st = 0; st < R4; st++) {
+    const uint32_t rnd = 2 * st;
+    const uint32_t bit = half >> rnd;
+    // group (blk, dj), dj < bit / 2: rows r0 = 2 blk bit + dj, r1 = r0 + bit / 2, r2 = r0 + bit, r3 = r2 + bit / 2.
+    // Level rnd pairs (r0, r2) with root index dj and (r1, r3) with dj + bit / 2; level rnd + 1 pairs (r0, r1) and
+    // (r2, r3), both with root index dj.  dj sits in the high bits of the work index, so the waves with dj = 0 skip
+    // the products by 1 as before.
+    const uint32_t hb = bit >> 1;
+    for (uint32_t w = threadIdx.x; w < (half >> 1) * T; w += NTT_THREADS) {
+      const uint32_t c = w & (T - 1);
+      const uint32_t wg = w >> log_t;
+      const uint32_t dj = wg >> rnd;
+      const uint32_t r0 = (((wg & ((1u << rnd) - 1u)) * bit) << 1) + dj;
+      const uint32_t o0 = r0 * T + c, o1 = o0 + hb * T, o2 = o0 + bit * T, o3 = o2 + hb * T;
+      const Fr29 x0 = lds_load29(smem29, E, o0), x1 = lds_load29(smem29, E, o1);
+      const Fr29 x2 = lds_load29(smem29, E, o2), x3 = lds_load29(smem29, E, o3);
+      const Fr29 s02 = x0 + x2, s13 = x1 + x3;  // < 2 B_r p, limbs < 2^30: not normalised (operands of + and sub only)
+      Fr29 d02 = sub_level(x0, x2, rnd);        // < 2 B_r p
+      if (dj) d02 = Fr29::mul(d02, lds_load29(tw29, half, dj << rnd));
+      const Fr29 d13 = Fr29::mul(sub_level(x1, x3, rnd), lds_load29(tw29, half, (dj + hb) << rnd));  // < 2 p
+      Fr29 y0 = s02 + s13;                      // < 4 B_r p = B_(r+2) p, limbs < 2^31
+      y0.normalise();
+      Fr29 y1 = sub_level(s02, s13, rnd + 1);   // < 4 B_r p
+      Fr29 y2 = d02 + d13;                      // < (2 B_r + 2) p
+      y2.normalise();
+      Fr29 y3 = sub_level(d02, d13, rnd + 1);   // d13 < 2 p <= 2 B_r p: < 4 B_r p
+      if (dj) {
+        const Fr29 w2 = lds_load29(tw29, half, dj << (rnd + 1));
+        y1 = Fr29::mul(y1, w2);                 // 4 B_r * 1 <= 128
+        y3 = Fr29::mul(y3, w2);
+      }
+      lds_store29(smem29, E, o0, y0);
+      lds_store29(smem29, E, o1, y1);
+      lds_store29(smem29, E, o2, y2);
+      lds_store29(smem29, E, o3, y3);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (uint32_t rnd = 2 * R4; rnd < (DYN ? 6u : DEG); rnd++) {  // generic shape: every level; odd DEG: the last one
     if (DYN && rnd >= deg) break;
     const uint32_t bit = half >> rnd;
     // Work item w -> (butterfly b, column c) with the butterfly's root index di = b mod bit in the HIGH bits of w: the
@@ -276,6 +323,24 @@ int ntt_run(const NttTables& tb, const Fr* in, Fr* out, Fr* scratch, const NttIo
       uint32_t d = (rem + (npass - i) - 1) / (npass - i);
       degs[i] = d;
       rem -= d;
+    }
+    // Prefer even pass widths (6 and 4 bits: whole radix-4 steps, one LDS round trip per two levels) with as few 5-bit
+    // passes as the sum allows: 2^20 = 6 + 6 + 4 + 4 instead of 5 + 5 + 5 + 5 (ten round trips instead of twelve).
+    if (NTT_MAX_DEG == 6 && log_n >= 12) {
+      for (uint32_t c5 = 0; c5 <= npass; c5++) {
+        bool found = false;
+        for (uint32_t a6 = 0; a6 + c5 <= npass; a6++) {
+          const uint32_t b4 = npass - c5 - a6;
+          if (6 * a6 + 5 * c5 + 4 * b4 != log_n) continue;
+          uint32_t i = 0;
+          for (uint32_t q = 0; q < a6; q++) degs[i++] = 6;
+          for (uint32_t q = 0; q < c5; q++) degs[i++] = 5;
+          for (uint32_t q = 0; q < b4; q++) degs[i++] = 4;
+          found = true;
+          break;
+        }
+        if (found) break;
+      }
     }
   }
   // intermediate passes ping-pong between the two halves of `scratch`; only the last pass writes
