@@ -166,10 +166,12 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(NttPassArgs a) {
   // Templated shapes: two levels at a time in registers (a radix-4 step is the same four products as two radix-2 levels,
   // but the four elements make ONE round trip through LDS instead of two, the intermediate sums are not normalised, and
   // there is one barrier per pair of levels); an odd DEG ends with a plain level.  Generic shape: level by level.
-#ifdef CQ_NTT_RADIX2  // A/B knob: level by level as in the generic shape
-  constexpr uint32_t R4 = 0;
+#if defined(CQ_NTT_EXP_NOSTAGES)  // timing experiment (wrong results; tools/ntt_phase_exp.sh): no butterflies in the templated shapes
+  constexpr uint32_t R4 = 0, LEVELS = 0;
+#elif defined(CQ_NTT_RADIX2)  // A/B knob: level by level as in the generic shape
+  constexpr uint32_t R4 = 0, LEVELS = DEG;
 #else
-  constexpr uint32_t R4 = DEG / 2;  // (no radix-4 steps for the generic shape, DEG = 0)
+  constexpr uint32_t R4 = DEG / 2, LEVELS = DEG;  // (no radix-4 steps for the generic shape, DEG = 0)
 #endif
 #pragma unroll
   for (uint32_t st = 0; st < R4; st++) {
@@ -211,7 +213,7 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(NttPassArgs a) {
     __syncthreads();
   }
 #pragma unroll
-  for (uint32_t rnd = 2 * R4; rnd < (DYN ? 6u : DEG); rnd++) {  // generic shape: every level; odd DEG: the last one
+  for (uint32_t rnd = 2 * R4; rnd < (DYN ? 6u : LEVELS); rnd++) {  // generic shape: every level; odd DEG: the last one
     if (DYN && rnd >= deg) break;
     const uint32_t bit = half >> rnd;
     // Work item w -> (butterfly b, column c) with the butterfly's root index di = b mod bit in the HIGH bits of w: the
@@ -249,6 +251,10 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(NttPassArgs a) {
     const uint32_t g = ((index - k) << deg) + k + i * p;
     if (g >= a.out_len) continue;
     const Fr29 x = lds_load29(smem29, E, bitrev(i, deg) * T + c);  // < 128 p
+#ifdef CQ_NTT_EXP_NOTW  // timing experiment (wrong results): no twiddle load, no product at the store
+    g_store29(out + g, x, false);
+    continue;
+#endif
     if (last) {
       const uint32_t m = (a.flags & NTT_OUT_COSET) ? g % 3 : 0;
       g_store29(out + g, Fr29::mul(x, lds_load29(cs29 + m * 9, 1, 0)), true);
