@@ -405,9 +405,12 @@ int ntt_run(const NttTables& tb, const Fr* in, Fr* out, Fr* scratch, const NttIo
     dim3 grid(t / T, io.batch);
     const size_t lds = ((size_t)(T << degs[ps]) + ((size_t)1 << degs[ps]) / 2 + 1) * 36 + 54 * 4;  // nine 32-bit limb planes: tile + roots; constants
     hipEvent_t pe = io.prof ? io.prof->prof_begin(CQ_PROF_NTT_PASS) : nullptr;
-    if (degs[ps] == 6 && log_t == 4) ntt_pass_kernel<6, 4><<<grid, NTT_THREADS, lds, stream>>>(a);
-    else if (degs[ps] == 5 && log_t == 5) ntt_pass_kernel<5, 5><<<grid, NTT_THREADS, lds, stream>>>(a);
-    else if (degs[ps] == 4 && log_t == 6) ntt_pass_kernel<4, 6><<<grid, NTT_THREADS, lds, stream>>>(a);
+    // templated shapes: full tiles (2^LT elements) of 6-, 5- and 4-bit passes
+    constexpr uint32_t LT = NTT_TILE_ELEMS == 512 ? 9 : NTT_TILE_ELEMS == 2048 ? 11 : 10;
+    static_assert(NTT_TILE_ELEMS == (1u << LT), "NTT_TILE_ELEMS: 512, 1024 or 2048");
+    if (degs[ps] == 6 && log_t == LT - 6) ntt_pass_kernel<6, LT - 6><<<grid, NTT_THREADS, lds, stream>>>(a);
+    else if (degs[ps] == 5 && log_t == LT - 5) ntt_pass_kernel<5, LT - 5><<<grid, NTT_THREADS, lds, stream>>>(a);
+    else if (degs[ps] == 4 && log_t == LT - 4) ntt_pass_kernel<4, LT - 4><<<grid, NTT_THREADS, lds, stream>>>(a);
     else ntt_pass_kernel<0, 0><<<grid, NTT_THREADS, lds, stream>>>(a);
     if (io.prof) io.prof->prof_end(pe);
     src = dst;
