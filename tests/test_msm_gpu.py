@@ -1,4 +1,6 @@
 """GPU parity: HIP Pippenger MSM (C ABI) vs the oracle's restatement of `best_multiexp`."""
+import os
+
 import numpy as np
 import pytest
 
@@ -200,6 +202,59 @@ def test_msm_table_window_widths(ctx, c):
         assert np.array_equal(OC.g1_to_affine(res[j]), exp[i]), "MSM %d differs from the oracle at c = %d" % (j, c)
     m = n - 4099  # a prefix of the registered array
     assert np.array_equal(OC.g1_to_affine(ctx.best_multiexp_dev(dev[0], dpts, m)), OC.g1_to_affine(OC.best_multiexp(uni[:m], pts[:m])))
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("CQ_FUZZ_SEEDS", "8"))))  # CQ_FUZZ_SEEDS=100 for a long run
+def test_msm_fuzz_table_mode(ctx, seed):
+    """Fuzz of the table-mode launch: random length, table window width (8..20: every sort shape), number of MSMs, scalar
+    mixes (uniform, small, 0/1, constant, sparse, zero) with repeated vectors and prefix lengths, against the C oracle."""
+    from oracle import cbind as OC
+
+    rs = np.random.RandomState(1000 + seed)
+    n = int(rs.choice([rs.randint(1, 300), rs.randint(300, 5000), rs.randint(5000, 120000)]))
+    c = int(rs.randint(8, 21))
+    pts = B.points_to_mont_limbs(random_points(min(n, 512), 500 + seed))
+    pts = np.tile(pts, ((n + 511) // 512, 1))[:n]
+    if n > 3:
+        pts[rs.randint(0, n)] = 0  # an identity base
+
+    def vec(kind):
+        a = np.zeros((n, 4), dtype=np.uint64)
+        if kind == 0:
+            a = rs.randint(0, 2**63, size=(n, 4), dtype=np.int64).astype(np.uint64)
+            a[:, 3] &= np.uint64((1 << 60) - 1)
+        elif kind == 1:
+            a[:, 0] = rs.randint(0, 1 << int(rs.randint(1, 40)), size=n).astype(np.uint64)
+        elif kind == 2:
+            a = np.tile(B.to_mont_limbs([int(v) for v in rs.randint(0, 2, size=min(n, 64))]), ((n + 63) // 64, 1))[:n]
+        elif kind == 3:
+            a = np.tile(B.to_mont_limbs([B.fr_random(B.Xoshiro256ss(seed))]), (n, 1))
+        elif kind == 4:
+            u = rs.randint(0, 2**63, size=(n, 4), dtype=np.int64).astype(np.uint64)
+            u[:, 3] &= np.uint64((1 << 60) - 1)
+            step = int(rs.randint(2, 50))
+            a[::step] = u[::step]
+        return np.ascontiguousarray(a)
+
+    count = int(rs.randint(1, 6))
+    kinds = [int(k) for k in rs.randint(0, 6, size=count)]
+    vecs = [vec(k) for k in kinds]
+    order = list(range(count))
+    if count > 1 and rs.randint(0, 2):
+        order.append(int(rs.randint(0, count)))  # one vector twice: shared entry lists
+    dpts = ctx.to_device(pts)
+    ctx.set_msm_table_window(c)
+    try:
+        ctx.msm_precompute(dpts.ptr, n)
+    finally:
+        ctx.set_msm_table_window(0)
+    dev = [ctx.to_device(v) for v in vecs]
+    res = ctx.msm_batch_dev([dev[i].ptr for i in order], dpts.ptr, n)
+    exp = [OC.g1_to_affine(OC.best_multiexp(v, pts)) for v in vecs]
+    for j, i in enumerate(order):
+        assert np.array_equal(OC.g1_to_affine(res[j]), exp[i]), "seed %d: MSM %d (kind %d) at c = %d, n = %d" % (seed, j, kinds[i], c, n)
+    m = int(rs.randint(1, n + 1))
+    assert np.array_equal(OC.g1_to_affine(ctx.best_multiexp_dev(dev[0], dpts, m)), OC.g1_to_affine(OC.best_multiexp(vecs[0][:m], pts[:m])))
 
 
 def test_msm_table_window_argument_range(ctx):
