@@ -133,10 +133,15 @@ int cq_msm_set_precompute(cq_ctx* ctx, int on);
 /* Pippenger window width in bits (2..15), 0 = automatic.  Tuning knob; results do not depend on it. */
 int cq_msm_set_window(cq_ctx* ctx, uint32_t bits);
 /* Window width (8..20) of the per-window tables built from now on by cq_msm_precompute_dev, the params and key
- * constructors; 0 = automatic (the first table built on the context decides: 15 bits up to 2^19 points, wider beyond).
- * One width per context, because MSMs over different base arrays share launches only when their tables agree.
- * Tuning knob; results do not depend on it. */
+ * constructors; 0 = automatic: every array's own length decides (15 bits up to 2^19 points, 17 from 2^20 on), and a
+ * proving key brings the small arrays it multiplies over (table SRS, cached quotients) to the width of its SRS tables --
+ * MSMs over different base arrays share a launch only when their tables agree -- whatever was built first on the
+ * context.  Tuning knob; results do not depend on it. */
 int cq_msm_set_table_window(cq_ctx* ctx, uint32_t bits);
+/* Which tables would a multiexp over [bases_dev, bases_dev + n) use?  *bits = their window width, 0 = none (plain
+ * Pippenger over the array itself); `preferred_bits` != 0 asks for that width first, as a launch does for the width of
+ * its longest MSM.  Introspection for callers and tests: results never depend on it. */
+int cq_msm_table_width_dev(cq_ctx* ctx, const uint64_t* bases_dev, size_t n, uint32_t preferred_bits, uint32_t* bits);
 
 /* eval_polynomial(poly, point)  arithmetic.rs:304-329 */
 int cq_eval_polynomial(cq_ctx* ctx, const uint64_t* poly, size_t n, const uint64_t point[4], uint64_t out[4]);
@@ -287,8 +292,8 @@ typedef struct {
   const uint32_t* lookup_input_programs;
   /* Legacy (plookup-style) lookups, `cs.lookups` (plonk/lookup.rs:9-36): lookup l has legacy_lookup_widths[l] input
    * expressions and as many table expressions; programs are flattened lookup by lookup, inputs first, then tables,
-   * and share `constants`.  The grand product, its quotient terms and all commitments run on the GPU; the sort of
-   * `permute_expression_pair` (lookup/prover.rs:400-502) runs on the host. */
+   * and share `constants`.  The grand product, its quotient terms, all commitments and the sort of
+   * `permute_expression_pair` (lookup/prover.rs:400-502; cq_permute_expression_pair_dev) run on the GPU. */
   uint32_t num_legacy_lookups;
   const uint32_t* legacy_lookup_widths;
   const uint32_t* legacy_program_lens;
@@ -329,7 +334,9 @@ int cq_permutation_assembly_copy(uint32_t columns, uint32_t n, uint32_t* mapping
 /* keygen_pk (plonk/keygen.rs:278-397): the domain, l0 / l_last / l_active_row on the extended coset
  * (:338-373), fixed polys and cosets (:328-336), the permutation proving key (permutation/keygen.rs:151-208),
  * the table config and `b0_g1_bound` (n-1 affine points; device pointer if b0_on_device != 0, else
- * host; may be NULL when the circuit has no static lookup, as may `cfg`). */
+ * host; may be NULL when the circuit has no static lookup, as may `cfg`).
+ * Lifetimes: `params`, `cfg` and the static tables must outlive the key (as `ProvingKey<'params>` borrows them in the
+ * reference); destroy keys first. */
 int cq_pk_create(cq_ctx* ctx, cq_params* params, const cq_circuit* circuit, cq_table_config* cfg,
                  const uint64_t* b0_g1_bound, int b0_on_device, cq_pk** out);
 /* ProvingKey::write / ProvingKey::read, SerdeFormat::RawBytes / RawBytesUnchecked (plonk.rs:349-403).  Layout:
@@ -480,8 +487,9 @@ uint64_t cq_xoshiro256ss_next_u64(void* state /* uint64_t[4] */);
  * (8 * 2^k words: the RNG, not the GPU, bounds the first rounds of a large proof otherwise). */
 void cq_xoshiro256ss_fill(uint64_t state[4], uint64_t* dst, size_t count, uint32_t threads);
 /* replays a pre-drawn stream: state = {const uint64_t* words; size_t pos; size_t len; size_t overrun}.  Words asked
- * for beyond `len` read as zero and are counted in `overrun`; cq_create_proof* fails with CQ_ERR_ARG when the stream
- * it was given ran out (a proof blinded with zeros is not zero-knowledge).  Like the xoshiro generator below this is
+ * for beyond `len` read as zero and are counted in `overrun` (reset by cq_create_proof* when a proof starts: the
+ * caller need not initialise it); cq_create_proof* fails with CQ_ERR_ARG when the stream it was given ran out (a proof
+ * blinded with zeros is not zero-knowledge); an unrelated failure (e.g. CQ_ERR_LOOKUP) keeps its own code.  Like the xoshiro generator below this is
  * for tests and benches; production blinding comes from the caller's CSPRNG through cq_rng_next_u64. */
 typedef struct { const uint64_t* words; size_t pos; size_t len; size_t overrun; } cq_buffer_rng;
 uint64_t cq_buffer_rng_next_u64(void* state /* cq_buffer_rng* */);

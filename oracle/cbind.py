@@ -22,12 +22,48 @@ def build(force: bool = False) -> str:
     return LIB
 
 
-def lib() -> C.CDLL:
+def build_native() -> str:
+    """The same source built `-O3 -march=native` ON THE MACHINE THAT RUNS IT (the CPU baseline's
+    flags): the portable library above is built in the authoring container and travels, so it may not assume the GPU box's
+    instruction set; this one is keyed by the host's CPU flags and never reused elsewhere.  Falls back to the portable
+    build when no compiler is at hand."""
+    import hashlib
+
+    try:
+        flags = next(line for line in open("/proc/cpuinfo") if line.startswith("flags"))
+    except (OSError, StopIteration):
+        flags = "unknown"
+    src = os.path.join(HERE, "cq_oracle.c")
+    tag = hashlib.sha256((flags + open(src).read()).encode()).hexdigest()[:10]
+    out = os.path.join(HERE, "libcq_oracle_native_%s.so" % tag)
+    if not os.path.exists(out):
+        r = subprocess.run(["make", "-C", HERE, "-B", "native", "NATIVE_OUT=" + out], capture_output=True)
+        if r.returncode != 0 or not os.path.exists(out):
+            return build()
+    return out
+
+
+def lib(native: bool = False) -> C.CDLL:
+    """native=True (bench.py's cpu_baseline leg): the -march=native build of this host replaces the loaded library.
+    CQ_ORACLE_LIB in the environment names another build of the same source (the sanitizer pass: `make asan`)."""
     global _lib
+    if native and not getattr(_lib, "_cq_native", False):
+        return _load(build_native(), True)
     if _lib is None:
+        override = os.environ.get("CQ_ORACLE_LIB")
+        if override:
+            return _load(override, False)
         if not os.path.exists(LIB):
             build()
-        _lib = C.CDLL(LIB)
+        return _load(LIB, False)
+    return _lib
+
+
+def _load(path: str, native: bool) -> C.CDLL:
+    global _lib
+    if True:
+        _lib = C.CDLL(path)
+        _lib._cq_native = native
         vp = C.c_void_p
         _lib.cqo_best_multiexp.argtypes = [vp, vp, C.c_size_t, vp]
         _lib.cqo_best_fft.argtypes = [vp, vp, C.c_uint32]

@@ -98,3 +98,44 @@ def create_decomposition_table(limbs: str, k: int):
             z &= ~(1 << (i + second))
         out.append((a, x, y, z))
     return out
+
+
+# ---- toy bit-vector SHA round (sha-reference/src/lib.rs, word.rs) -- restated only for its one KAT --------------------
+# Words are lists of L bits.  Quirks preserved: `+` is bitwise XOR (word.rs:12-21, 98-108), the round has no K_t / W_t,
+# and right_rotation(n) reads result[i] = self[(i + n L - n) mod L] (word.rs:36-42).
+def toy_right_rotation(w, n: int):
+    L = len(w)
+    return [w[(i + n * L - n) % L] for i in range(L)]
+
+
+def _toy_xor(*ws):
+    return [sum(bits) & 1 for bits in zip(*ws)]
+
+
+def toy_rot_0(w):
+    """word.rs:44-46."""
+    return _toy_xor(toy_right_rotation(w, 2), toy_right_rotation(w, 13), toy_right_rotation(w, 22))
+
+
+def toy_rot_1(w):
+    """word.rs:48-50."""
+    return _toy_xor(toy_right_rotation(w, 6), toy_right_rotation(w, 11), toy_right_rotation(w, 25))
+
+
+def toy_majority(a, b, c):
+    """word.rs:59-71."""
+    return [1 if x + y + z >= 2 else 0 for x, y, z in zip(a, b, c)]
+
+
+def toy_choose(a, b, c):
+    """word.rs:73-80."""
+    return [y if x == 1 else z for x, y, z in zip(a, b, c)]
+
+
+def toy_sha_round(octet):
+    """sha-reference/src/lib.rs:18-33: octet = (a, b, c, d, e, f, g, h), each a list of L bits."""
+    a, b, c, d, e, f, g, h = octet
+    temp = _toy_xor(h, toy_rot_1(e), toy_choose(e, f, g))
+    new_e = _toy_xor(d, temp)
+    new_a = _toy_xor(temp, toy_rot_0(a), toy_majority(a, b, c))
+    return (new_a, a, b, c, new_e, e, f, g)

@@ -32,153 +32,89 @@ def load() -> C.CDLL:
     return _lib
 
 
+def _header_text() -> str:
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)      # comments
+    src = re.sub(r"^\s*#.*$", "", src, flags=re.M)        # preprocessor lines
+    return src
+
+
 def header_symbols():
     """Every function name declared in include/cq_halo2.h."""
-    src = open(HEADER).read()
-    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(cq_[a-z0-9_]+)\s*\(", src)))
+    return sorted(p.name for p in header_prototypes())
 
 
-u64p = C.POINTER(C.c_uint64)
-vp = C.c_void_p
+class Prototype:
+    """One `extern "C"` prototype of include/cq_halo2.h: C return type and parameter types as written there."""
+
+    def __init__(self, name, ret, params):
+        self.name, self.ret, self.params = name, ret, params
+
+    def __repr__(self):
+        return f"{self.ret} {self.name}({', '.join(self.params)})"
+
+
+def header_prototypes():
+    """Parses the header (the ABI's single source of truth): the ctypes signatures below are DERIVED from it, so the
+    Python binding cannot drift from the C declarations -- and the compiler holds the definitions in csrc/capi*.hip to
+    the same declarations (they include the header under `extern "C"`)."""
+    src = _header_text()
+    src = re.sub(r"typedef\s+struct\s*\{.*?\}\s*\w+\s*;", "", src, flags=re.S)  # struct bodies
+    src = re.sub(r"typedef[^;{]*;", "", src)                                       # opaque / function-pointer typedefs
+    src = src.replace('extern "C" {', "")
+    out = []
+    for m in re.finditer(r"([A-Za-z_][\w\s\*]*?)\b(cq_[a-z0-9_]+)\s*\(([^()]*)\)\s*;", src):
+        ret, name, params = m.group(1).strip(), m.group(2), m.group(3).strip()
+        plist = [] if params in ("", "void") else [re.sub(r"\s+", " ", p.strip()) for p in params.split(",")]
+        out.append(Prototype(name, re.sub(r"\s+", " ", ret), plist))
+    return out
+
+
+def header_fnptr_typedefs():
+    """Names of the function-pointer typedefs (callbacks crossing the ABI)."""
+    return set(re.findall(r"typedef\s+[\w\s\*]+?\(\s*\*\s*(cq_\w+)\s*\)", _header_text()))
+
+
+_SCALARS = {"int": C.c_int, "uint32_t": C.c_uint32, "int32_t": C.c_int32, "uint64_t": C.c_uint64, "int64_t": C.c_int64,
+            "size_t": C.c_size_t, "double": C.c_double, "uint8_t": C.c_uint8}
+
+
+def ctype_of_param(decl: str, fnptrs) -> object:
+    """ctypes class of one C parameter declaration: every pointer, array parameter and callback is a machine address
+    (c_void_p accepts ints, None, byref(), arrays and CFUNCTYPE instances); scalars keep their width."""
+    if "*" in decl or "[" in decl:
+        return C.c_void_p
+    words = [w for w in decl.replace("const", " ").split() if w]
+    ty = words[0] if len(words) == 1 else " ".join(words[:-1])  # drop the parameter name
+    if ty in fnptrs:
+        return C.c_void_p
+    if ty not in _SCALARS:
+        raise TypeError(f"cq_halo2.h: parameter type not understood: {decl!r}")
+    return _SCALARS[ty]
+
+
+def ctype_of_return(ret: str):
+    ret = ret.replace("const", " ").strip()
+    ret = re.sub(r"\s+", " ", ret).replace(" *", "*")
+    if ret == "void":
+        return None
+    if ret == "char*":
+        return C.c_char_p
+    if ret.endswith("*"):
+        return C.c_void_p
+    if ret not in _SCALARS:
+        raise TypeError(f"cq_halo2.h: return type not understood: {ret!r}")
+    return _SCALARS[ret]
+
+
+def signatures():
+    """{name: (restype, [argtypes])} for every prototype of the header."""
+    fnptrs = header_fnptr_typedefs()
+    return {p.name: (ctype_of_return(p.ret), [ctype_of_param(d, fnptrs) for d in p.params]) for p in header_prototypes()}
 
 
 def _declare(lib):
-    lib.cq_version.restype = C.c_char_p
-    lib.cq_last_error.restype = C.c_char_p
-    lib.cq_last_error.argtypes = [vp]
-    lib.cq_ctx_stream.restype = vp
-    lib.cq_ctx_stream.argtypes = [vp]
-    lib.cq_ctx_destroy.restype = None
-    lib.cq_ctx_destroy.argtypes = [vp]
-    lib.cq_ctx_create.argtypes = [C.c_int, vp, C.POINTER(vp)]
-    lib.cq_ctx_sync.argtypes = [vp]
-    lib.cq_ctx_set_hip_graphs.argtypes = [vp, C.c_int]
-    lib.cq_dev_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
-    lib.cq_dev_free.argtypes = [vp, vp]
-    lib.cq_dev_upload.argtypes = [vp, vp, vp, C.c_size_t]
-    lib.cq_dev_download.argtypes = [vp, vp, vp, C.c_size_t]
-    lib.cq_dev_memset.argtypes = [vp, vp, C.c_int, C.c_size_t]
-    lib.cq_best_fft.argtypes = [vp, vp, C.c_uint32, vp]
-    lib.cq_best_fft_dev.argtypes = [vp, vp, vp, C.c_uint32, vp]
-    lib.cq_bench_modmul_dev.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_int]
-
-
-def _declare_msm(lib):
-    lib.cq_best_multiexp.argtypes = [vp, vp, vp, C.c_size_t, vp]
-    lib.cq_best_multiexp_dev.argtypes = [vp, vp, vp, C.c_size_t, vp]
-    lib.cq_msm_batch_dev.argtypes = [vp, vp, vp, C.c_size_t, C.c_size_t, vp]
-    lib.cq_msm_set_window.argtypes = [vp, C.c_uint32]
-    lib.cq_msm_set_table_window.argtypes = [vp, C.c_uint32]
-    lib.cq_permute_expression_pair_dev.argtypes = [vp, C.c_uint32, C.c_uint32, vp, vp, vp, vp]
-    lib.cq_params_create.argtypes = [vp, C.c_uint32, vp, vp, C.POINTER(vp)]
-    lib.cq_params_destroy.restype = None
-    lib.cq_params_destroy.argtypes = [vp]
-    lib.cq_params_g_dev.restype = vp
-    lib.cq_params_g_dev.argtypes = [vp]
-    lib.cq_params_g_lagrange_dev.restype = vp
-    lib.cq_params_g_lagrange_dev.argtypes = [vp]
-    for name in ("cq_commit", "cq_commit_lagrange", "cq_commit_dev", "cq_commit_lagrange_dev"):
-        getattr(lib, name).argtypes = [vp, vp, C.c_size_t, vp]
-
-
-_declare_base = _declare
-
-
-def _declare(lib):  # noqa: F811
-    _declare_base(lib)
-    _declare_msm(lib)
-    lib.cq_params_setup_from_toxic_waste.argtypes = [vp, C.c_uint32, vp, C.POINTER(vp)]
-    lib.cq_fixed_base_mul_dev.argtypes = [vp, vp, C.c_size_t, vp]
-    lib.cq_eval_polynomial.argtypes = [vp, vp, C.c_size_t, vp, vp]
-    lib.cq_eval_polynomial_dev.argtypes = [vp, vp, C.c_size_t, vp, vp]
-    lib.cq_kate_division.argtypes = [vp, vp, C.c_size_t, vp, vp]
-    lib.cq_kate_division_dev.argtypes = [vp, vp, C.c_size_t, vp, vp]
-    lib.cq_batch_invert.argtypes = [vp, vp, C.c_size_t]
-    lib.cq_batch_invert_dev.argtypes = [vp, vp, C.c_size_t]
-    lib.cq_domain_create.argtypes = [vp, C.c_uint32, C.c_uint32, C.POINTER(vp)]
-    lib.cq_domain_destroy.restype = None
-    lib.cq_domain_destroy.argtypes = [vp]
-    lib.cq_domain_k.restype = C.c_uint32
-    lib.cq_domain_k.argtypes = [vp]
-    lib.cq_domain_extended_k.restype = C.c_uint32
-    lib.cq_domain_extended_k.argtypes = [vp]
-    lib.cq_domain_constants.argtypes = [vp, vp, vp, vp, vp]
-    lib.cq_lagrange_to_coeff.argtypes = [vp, vp]
-    lib.cq_coeff_to_extended.argtypes = [vp, vp, vp]
-    lib.cq_extended_to_coeff.argtypes = [vp, vp, vp]
-    lib.cq_lagrange_to_coeff_dev.argtypes = [vp, vp, vp, C.c_uint32]
-    lib.cq_coeff_to_extended_dev.argtypes = [vp, vp, vp, C.c_uint32]
-    lib.cq_extended_to_coeff_dev.argtypes = [vp, vp, vp]
-    lib.cq_table_config_create.argtypes = [vp, C.c_size_t, vp, vp, C.POINTER(vp)]
-    lib.cq_table_config_setup_from_toxic_waste.argtypes = [vp, C.c_size_t, vp, C.POINTER(vp)]
-    lib.cq_table_config_destroy.restype = None
-    lib.cq_table_config_destroy.argtypes = [vp]
-    lib.cq_table_config_download.argtypes = [vp, vp, vp]
-    lib.cq_static_table_create.argtypes = [vp, C.c_size_t, vp, vp, C.POINTER(vp)]
-    lib.cq_static_table_setup_from_toxic_waste.argtypes = [vp, C.c_size_t, vp, vp, C.POINTER(vp)]
-    lib.cq_static_table_destroy.restype = None
-    lib.cq_static_table_destroy.argtypes = [vp]
-    lib.cq_static_table_download_qs.argtypes = [vp, vp]
-    lib.cq_pk_create.argtypes = [vp, vp, vp, vp, vp, C.c_int, C.POINTER(vp)]
-    lib.cq_pk_set_sharding.argtypes = [vp, C.c_uint32, C.c_uint32, vp, vp]
-    lib.cq_pk_set_column_sharding.argtypes = [vp, C.c_int, vp, vp]
-    lib.cq_rccl_unique_id.argtypes = [vp]
-    lib.cq_ctx_comm_init_rccl.argtypes = [vp, C.c_uint32, C.c_uint32, vp]
-    lib.cq_ctx_comm_destroy.argtypes = [vp]
-    lib.cq_ctx_comm_selftest.argtypes = [vp]
-    lib.cq_pk_destroy.restype = None
-    lib.cq_pk_destroy.argtypes = [vp]
-    lib.cq_pk_usable_rows.restype = C.c_uint32
-    lib.cq_pk_usable_rows.argtypes = [vp]
-    lib.cq_pk_proof_size.restype = C.c_size_t
-    lib.cq_pk_proof_size.argtypes = [vp]
-    lib.cq_create_proof.argtypes = [vp, vp, vp, vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
-    lib.cq_create_proof_batch.argtypes = [vp, C.c_size_t, vp, vp, vp, vp, C.c_size_t, vp, C.c_uint32]
-    lib.cq_create_proof_host.argtypes = [vp, vp, vp, vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
-    lib.cq_create_proof_instances.argtypes = [vp, vp, C.c_int, vp, vp, vp, vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
-    lib.cq_pk_vk_commitments.argtypes = [vp, vp, vp]
-    lib.cq_cq_round1_dev.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
-    lib.cq_cq_round2_dev.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp]
-    lib.cq_quotient_dev.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int, vp]
-    lib.cq_g_to_lagrange_dev.argtypes = [vp, vp, C.c_uint32, vp]
-    lib.cq_params_downsize.argtypes = [vp, C.c_uint32, C.POINTER(vp)]
-    lib.cq_static_table_new_fk.argtypes = [vp, C.c_size_t, vp, vp, C.POINTER(vp)]
-    lib.cq_create_proof_phases.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
-    lib.cq_pk_set_opener.argtypes = [vp, C.c_int]
-    lib.cq_pk_read_raw.argtypes = [vp, vp, vp, vp, vp, C.c_int, vp, C.c_size_t, C.c_uint32, C.c_int, C.POINTER(vp)]
-    lib.cq_pk_raw_size.restype = C.c_size_t
-    lib.cq_pk_raw_size.argtypes = [vp, C.c_uint32]
-    lib.cq_pk_write_raw.argtypes = [vp, vp, C.c_uint32, vp, C.c_size_t, C.POINTER(C.c_size_t)]
-    u32p = C.POINTER(C.c_uint32)
-    lib.cq_permutation_assembly_init.restype = None
-    lib.cq_permutation_assembly_init.argtypes = [C.c_uint32, C.c_uint32, u32p, u32p, u32p]
-    lib.cq_permutation_assembly_copy.argtypes = [C.c_uint32, C.c_uint32, u32p, u32p, u32p, C.c_uint32, C.c_uint32,
-                                                 C.c_uint32, C.c_uint32]
-    lib.cq_sha_witness_fill_dev.argtypes = [vp, vp, C.c_size_t, C.c_uint32, C.c_size_t, vp]
-    lib.cq_sha_spread_table_dev.argtypes = [vp, C.c_size_t, vp, vp]
-    lib.cq_xoshiro256ss_seed.restype = None
-    lib.cq_xoshiro256ss_seed.argtypes = [C.c_uint64, vp]
-    lib.cq_xoshiro256ss_next_u64.restype = C.c_uint64
-    lib.cq_xoshiro256ss_next_u64.argtypes = [vp]
-    lib.cq_xoshiro256ss_fill.restype = None
-    lib.cq_xoshiro256ss_fill.argtypes = [vp, vp, C.c_size_t, C.c_uint32]
-    lib.cq_buffer_rng_next_u64.restype = C.c_uint64
-    lib.cq_buffer_rng_next_u64.argtypes = [vp]
-    lib.cq_opaque_rng_next_u64.restype = C.c_uint64
-    lib.cq_opaque_rng_next_u64.argtypes = [vp]
-    lib.cq_opaque_rng_fill.restype = None
-    lib.cq_opaque_rng_fill.argtypes = [vp, vp, C.c_size_t]
-    lib.cq_pk_set_rng_fill.argtypes = [vp, vp]
-    lib.cq_msm_precompute_dev.argtypes = [vp, vp, C.c_size_t]
-    lib.cq_msm_set_precompute.argtypes = [vp, C.c_int]
-    lib.cq_msm_forget_dev.argtypes = [vp, vp]
-    lib.cq_sha_synthesis_table_dev.argtypes = [vp, C.c_int, C.c_uint32, C.c_uint32, vp]
-    lib.cq_sha_decomposition_table_dev.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, vp]
-    lib.cq_static_table_new.argtypes = [vp, C.c_size_t, vp, vp, C.POINTER(vp)]
-    lib.cq_params_read_raw.argtypes = [vp, vp, C.c_size_t, C.c_int, C.POINTER(vp)]
-    lib.cq_params_write_raw.argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
-    lib.cq_g1_sum.argtypes = [vp, C.c_size_t, vp]
-    lib.cq_g1_to_affine.argtypes = [vp, vp]
-    lib.cq_profile_enable.argtypes = [vp, C.c_int]
-    lib.cq_profile_read.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
+    for name, (restype, argtypes) in signatures().items():
+        fn = getattr(lib, name)  # AttributeError: the header declares a symbol the library does not export
+        fn.restype = restype
+        fn.argtypes = argtypes

@@ -69,7 +69,8 @@ class Context:
 
     def close(self):
         if self.h:
-            for ch in list(self._children):
+            # proving keys first: a key refers to the params / table config it was built on until it is destroyed
+            for ch in sorted(list(self._children), key=lambda o: 0 if type(o).__name__ == "ProvingKey" else 1):
                 ch.close()
             self.lib.cq_ctx_destroy(self.h)
             self.h = None
@@ -966,6 +967,14 @@ def _ctx_comm_destroy(self):
     self._chk(self.lib.cq_ctx_comm_destroy(self.h))
 
 
+def _ctx_msm_table_width(self, bases_ptr: int, n: int, preferred: int = 0) -> int:
+    """Window width of the precomputed tables a multiexp over [bases_ptr, bases_ptr + n) would use (0: none)."""
+    bits = C.c_uint32()
+    self._chk(self.lib.cq_msm_table_width_dev(self.h, bases_ptr, n, preferred, C.byref(bits)))
+    return bits.value
+
+
+Context.msm_table_width = _ctx_msm_table_width
 Context.set_hip_graphs = lambda self, on: self._chk(self.lib.cq_ctx_set_hip_graphs(self.h, 1 if on else 0))
 Context.comm_init_rccl = _ctx_comm_init_rccl
 Context.comm_init_from_torch = _ctx_comm_init_from_torch

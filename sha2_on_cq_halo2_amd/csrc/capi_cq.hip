@@ -241,6 +241,36 @@ int unit_coset(cq_pk* pk, size_t row, Fr* tmp, Fr* dst) {
 }
 }  // namespace
 
+// Window tables of the arrays a key multiplies over besides its SRS, at the width of the SRS tables (so that all MSMs of
+// a round share one launch): the cached quotients and an own b0 bound are the key's; the table SRS may be shared with
+// keys of other sizes and then carries a table per width (2^12 points: 4 MiB each).  The width follows the length of
+// the point range a rank multiplies: 2^k / world.
+static int pk_small_tables(cq_pk* pk) {
+  cq_ctx* c = pk->ctx;
+  const size_t n = (size_t)1 << pk->k;
+  const uint32_t width = c->msm_table_c ? c->msm_table_c : msm_table_window_bits(n / std::max<uint32_t>(pk->shard_world, 1));
+  if (width == pk->table_c && !pk->held_tables.empty()) return CQ_OK;
+  pk->table_c = width;
+  if (!c->msm_precompute) return CQ_OK;
+  std::vector<cq_pk::TableRef> old;
+  old.swap(pk->held_tables);
+  int rc = CQ_OK;
+  auto want = [&](const G1Affine* b, size_t len) {
+    bool held = false;
+    if (rc == CQ_OK) rc = msm_register_tables(c, b, len, pk->table_c, &held);
+    if (held) pk->held_tables.push_back({b, len, pk->table_c});
+  };
+  const cq_table_config* cfg = pk->table_cfg;
+  for (size_t l = 0; l < pk->qs_concat.size(); l++) want(pk->qs_concat[l], pk->lookups[l].tables.size() * cfg->N);
+  if (cfg && !pk->lookups.empty()) {
+    want(cfg->g1_lagrange, cfg->N);
+    want(cfg->g_lagrange_opening_at_0, cfg->N);
+  }
+  if (pk->b0_g1_bound) want(pk->b0_g1_bound, n - 1);
+  for (auto& t : old) msm_release_table(c, t.bases, t.n, t.c);  // after the new ones: a shared entry is never rebuilt in between
+  return rc;
+}
+
 static int pk_create_impl(cq_ctx* c, cq_params* params, const cq_circuit* cs, cq_table_config* cfg, const uint64_t* b0_g1_bound,
                           int b0_on_device, const uint8_t* raw, size_t raw_len, uint32_t num_selectors, int checked, cq_pk** out) {
   if (!c || !params || !cs || !out) return CQ_ERR_ARG;
@@ -258,6 +288,9 @@ static int pk_create_impl(cq_ctx* c, cq_params* params, const cq_circuit* cs, cq
   pk->num_advice = cs->num_advice;
   pk->table_cfg = cfg;
   pk->vk_repr = Fr::from_limbs64(cs->vk_repr);
+  params->key_users++;
+  if (cfg) cfg->key_users++;
+  pk->counted_users = true;
   const size_t n = (size_t)1 << pk->k;
   size_t off = 0;
   for (uint32_t l = 0; l < cs->num_lookups; l++) {
@@ -565,9 +598,8 @@ static int pk_create_impl(cq_ctx* c, cq_params* params, const cq_circuit* cs, cq
     pk->qs_concat.push_back(cat);
     for (size_t j = 0; j < lk.tables.size(); j++)
       CQ_HIP(c, hipMemcpyAsync(cat + j * N, lk.tables[j]->qs, N * sizeof(G1Affine), hipMemcpyDeviceToDevice, c->stream));
-    if (c->msm_precompute && (rc = msm_register_tables(c, cat, lk.tables.size() * N)) != CQ_OK) return pk_abort(pk, rc);
   }
-  if (pk->b0_g1_bound && c->msm_precompute && (rc = msm_register_tables(c, pk->b0_g1_bound, n - 1)) != CQ_OK) return pk_abort(pk, rc);
+  if ((rc = pk_small_tables(pk)) != CQ_OK) return pk_abort(pk, rc);
   CQ_HIP(c, hipStreamSynchronize(c->stream));
   *out = guard.release();
   return CQ_OK;
@@ -662,28 +694,49 @@ int cq_pk_set_rng_fill(cq_pk* pk, cq_rng_fill_fn fill) {
 
 // MSM window tables of a sharded key: a rank only ever multiplies its slice of every (scalars, bases) range, so the
 // 17 x SRS tables are built for those slices alone (the union of the slices over the MSMs that share an array: lengths
-// n, n - 1, N, w N).  The full-array tables of the key's SRS objects are dropped; world = 1 brings them back.
+// n, n - 1, N, w N).  The whole-array tables of the SRS objects the key is built on are given up for that only while this
+// key is their one user -- another key on the same params / table config keeps finding them, and the slices then resolve
+// into them -- and are rebuilt when the key returns to world = 1 or is destroyed.
 static int pk_shard_tables(cq_pk* pk) {
   cq_ctx* c = pk->ctx;
-  for (const void* p : pk->shard_tables) msm_unregister_tables(c, p);
+  for (auto& t : pk->shard_tables) msm_release_table(c, t.bases, t.n, t.c);
   pk->shard_tables.clear();
   if (!c->msm_precompute) return CQ_OK;
   const size_t n = (size_t)1 << pk->k, N = pk->table_cfg ? pk->table_cfg->N : 0;
+  const bool has_cfg = pk->table_cfg && !pk->lookups.empty();
+  int rc;
+  if ((rc = pk_small_tables(pk)) != CQ_OK) return rc;  // the window width follows the length of a rank's point range
+  if (pk->shard_world <= 1) {  // back to whole arrays
+    if (pk->dropped_params_tables) {
+      pk->dropped_params_tables = false;
+      if ((rc = msm_register_tables(c, pk->params->g, n)) != CQ_OK || (rc = msm_register_tables(c, pk->params->g_lagrange, n)) != CQ_OK) return rc;
+    }
+    if (pk->dropped_cfg_tables) {
+      pk->dropped_cfg_tables = false;
+      if ((rc = msm_register_tables(c, pk->table_cfg->g1_lagrange, N)) != CQ_OK ||
+          (rc = msm_register_tables(c, pk->table_cfg->g_lagrange_opening_at_0, N)) != CQ_OK)
+        return rc;
+    }
+    return CQ_OK;
+  }
+  if (pk->params->key_users <= 1 && !pk->dropped_params_tables) {
+    msm_unregister_tables(c, pk->params->g);
+    msm_unregister_tables(c, pk->params->g_lagrange);
+    pk->dropped_params_tables = true;
+  }
+  if (has_cfg && pk->table_cfg->key_users <= 1 && !pk->dropped_cfg_tables) {
+    msm_unregister_tables(c, pk->table_cfg->g1_lagrange);
+    msm_unregister_tables(c, pk->table_cfg->g_lagrange_opening_at_0);
+    pk->dropped_cfg_tables = true;
+  }
   struct Use { const G1Affine* b; size_t len; };
   std::vector<Use> uses{{pk->params->g_lagrange, n}, {pk->params->g, n}, {pk->params->g, n - 1}};
-  if (pk->table_cfg) {
+  if (has_cfg) {
     uses.push_back({pk->table_cfg->g1_lagrange, N});
     uses.push_back({pk->table_cfg->g_lagrange_opening_at_0, N});
   }
-  for (size_t l = 0; l < pk->lookups.size(); l++) uses.push_back({pk->qs_concat[l], pk->lookups[l].tables.size() * N});
   if (pk->b0_g1_bound) uses.push_back({pk->b0_g1_bound, n - 1});
-  int rc;
-  if (pk->shard_world <= 1) {  // back to whole arrays
-    for (auto& u : uses)
-      if ((rc = msm_register_tables(c, u.b, u.len)) != CQ_OK) return rc;
-    return CQ_OK;
-  }
-  for (auto& u : uses) msm_unregister_tables(c, u.b);
+  // (the cached quotients [qs_0 | qs_1 | ...] are the key's own small arrays: their whole-array tables stay)
   std::vector<std::pair<const G1Affine*, const G1Affine*>> iv;
   for (auto& u : uses) {
     size_t lo, hi;
@@ -697,8 +750,10 @@ static int pk_shard_tables(cq_pk* pk) {
     else merged.push_back(x);
   }
   for (auto& m : merged) {
-    if ((rc = msm_register_tables(c, m.first, (size_t)(m.second - m.first))) != CQ_OK) return rc;
-    pk->shard_tables.push_back(m.first);
+    bool held = false;
+    const size_t len = (size_t)(m.second - m.first);
+    if ((rc = msm_register_tables(c, m.first, len, pk->table_c, &held)) != CQ_OK) return rc;
+    if (held) pk->shard_tables.push_back({m.first, len, pk->table_c});  // not held: served by a whole-array table that stayed
   }
   return CQ_OK;
 }
@@ -739,12 +794,24 @@ void cq_pk_destroy(cq_pk* pk) {
                   (void*)pk->gate_prog, (void*)pk->constants, (void*)pk->lookup_prog, (void*)pk->legacy_prog, (void*)pk->perm_values, (void*)pk->perm_polys, (void*)pk->perm_cosets,
                   (void*)pk->omega_powers, (void*)pk->ext_pow_lo, (void*)pk->ext_pow_hi})
     if (p) hipFree(p);
-  for (const void* p : pk->shard_tables) msm_unregister_tables(pk->ctx, p);
-  if (pk->b0_g1_bound) msm_unregister_tables(pk->ctx, pk->b0_g1_bound);
-  if (pk->own_b0 && pk->b0_g1_bound) hipFree(pk->b0_g1_bound);
+  // window tables: the slices of a sharded key go, the whole-array tables it had given up come back (their owners --
+  // params, table config -- are still alive: a key never outlives them), its references are returned
+  if (pk->shard_world > 1 || pk->dropped_params_tables || pk->dropped_cfg_tables) {
+    pk->shard_world = 1;
+    (void)pk_shard_tables(pk);
+  }
+  for (auto& t : pk->held_tables) msm_release_table(pk->ctx, t.bases, t.n, t.c);
+  if (pk->own_b0 && pk->b0_g1_bound) {
+    msm_unregister_tables(pk->ctx, pk->b0_g1_bound);
+    hipFree(pk->b0_g1_bound);
+  }
   for (auto p : pk->qs_concat) {
     msm_unregister_tables(pk->ctx, p);
     hipFree(p);
+  }
+  if (pk->counted_users) {
+    pk->params->key_users--;
+    if (pk->table_cfg) pk->table_cfg->key_users--;
   }
   delete pk;
 }
@@ -781,9 +848,12 @@ static int create_proof_any(cq_pk* pk, const uint64_t* const* advice_dev, const 
   CQ_HIP(c, hipSetDevice(c->device));
   std::vector<uint8_t> out;
   if (pk->num_phases > 1 && !phase_fn) return c->fail(CQ_ERR_ARG, "create_proof: a multi-phase circuit needs cq_create_proof_phases");
+  // `overrun` counts the words THIS proof asked for beyond the stream (a caller's struct may hold anything there)
+  if (rng == cq_buffer_rng_next_u64) ((cq_buffer_rng*)rng_state)->overrun = 0;
   int rc = create_proof_dev(pk, advice_dev, instances, instance_lens, phase_fn, phase_user, rng, rng_state, out);
-  // checked before rc: an all-zero random polynomial also trips the identity-commitment check of the transcript
-  if (rng == cq_buffer_rng_next_u64 && ((cq_buffer_rng*)rng_state)->overrun)
+  // An exhausted stream reads as zeros: the proof would not be zero-knowledge, and an all-zero random polynomial also
+  // trips the transcript's identity-commitment check -- both are reported as what they are.  Any other error keeps its code.
+  if (rng == cq_buffer_rng_next_u64 && ((cq_buffer_rng*)rng_state)->overrun && (rc == CQ_OK || rc == CQ_ERR_TRANSCRIPT))
     return c->fail(CQ_ERR_ARG, "create_proof: the pre-drawn RNG stream ran out (blinding would be zero)");
   if (rc != CQ_OK) return rc;
   if (out.size() > proof_cap) return c->fail(CQ_ERR_ARG, "proof buffer too small");
@@ -879,8 +949,9 @@ int cq_create_proof_batch(cq_pk* pk, size_t count, const uint64_t* const* const*
       const size_t i = next.fetch_add(1);
       if (i >= count || first_rc.load() != CQ_OK) break;
       std::vector<uint8_t> out;
+      if (rng == cq_buffer_rng_next_u64) ((cq_buffer_rng*)rng_states[i])->overrun = 0;
       int rc = create_proof_dev(&lane_pk, advice_dev[i], nullptr, nullptr, nullptr, nullptr, rng, rng_states[i], out);
-      if (rc == CQ_OK && rng == cq_buffer_rng_next_u64 && ((cq_buffer_rng*)rng_states[i])->overrun) {
+      if ((rc == CQ_OK || rc == CQ_ERR_TRANSCRIPT) && rng == cq_buffer_rng_next_u64 && ((cq_buffer_rng*)rng_states[i])->overrun) {
         rc = CQ_ERR_ARG;
         lc->err = "create_proof: the pre-drawn RNG stream ran out (blinding would be zero)";
       }

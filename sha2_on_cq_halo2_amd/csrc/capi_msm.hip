@@ -38,6 +38,15 @@ int msm_multi_begin(cq_ctx* c, const Fr* const* scalars, const G1Affine* const* 
   pend.count = count;
   for (size_t j = 0; j < count; j++)
     if (lens[j] > 0x7fffffffull) return c->fail(CQ_ERR_ARG, "msm: len too large");
+  // Tables of one width share a launch: where an array has several (a small table SRS next to SRS arrays of different
+  // sizes), take the width of the longest MSM's table.
+  uint32_t want_c = 0;
+  {
+    size_t longest = 0;
+    for (size_t j = 0; j < count; j++)
+      if (lens[j] > longest)
+        if (const cq_ctx::MsmTable* t = c->find_msm_table(bases[j], lens[j])) { longest = lens[j]; want_c = t->c; }
+  }
   // first pass: plan the launches and the result slots
   size_t done = 0, slots = 0;
   while (done < count) {
@@ -50,14 +59,14 @@ int msm_multi_begin(cq_ctx* c, const Fr* const* scalars, const G1Affine* const* 
       done++;
       continue;
     }
-    const cq_ctx::MsmTable* t0 = c->find_msm_table(bases[done], lens[done]);
+    const cq_ctx::MsmTable* t0 = c->find_msm_table(bases[done], lens[done], nullptr, want_c);
     const bool pre = t0 != nullptr;
     uint32_t nmax = (uint32_t)lens[done];
     uint32_t batch = 1;
     while (done + batch < count && batch < MSM_MAX_BATCH) {
       const size_t l = lens[done + batch];
       if (l == 0) break;
-      const cq_ctx::MsmTable* t = c->find_msm_table(bases[done + batch], l);
+      const cq_ctx::MsmTable* t = c->find_msm_table(bases[done + batch], l, nullptr, want_c);
       if ((t != nullptr) != pre) break;
       if (pre && t->c != t0->c) break;
       if (!pre && l != lens[done]) break;
@@ -96,7 +105,7 @@ int msm_multi_begin(cq_ctx* c, const Fr* const* scalars, const G1Affine* const* 
     std::vector<size_t> strides(ln.batch, 0);
     for (uint32_t j = 0; j < ln.batch; j++) {
       size_t toff = 0;
-      const cq_ctx::MsmTable* t = ln.pre ? c->find_msm_table(bases[ln.first + j], lens[ln.first + j], &toff) : nullptr;
+      const cq_ctx::MsmTable* t = ln.pre ? c->find_msm_table(bases[ln.first + j], lens[ln.first + j], &toff, ln.c) : nullptr;
       bp[j] = ln.pre ? (const G1Affine*)t->table + toff : bases[ln.first + j];
       strides[j] = ln.pre ? t->n : 0;
     }
@@ -162,27 +171,48 @@ int cq_msm_multi(cq_ctx* c, const Fr* const* scalars, const G1Affine* const* bas
 }
 
 void msm_unregister_tables(cq_ctx* c, const void* bases) {
-  for (size_t i = 0; i < c->msm_tables.size(); i++)
+  for (size_t i = 0; i < c->msm_tables.size();) {
     if (c->msm_tables[i].bases == bases) {
       hipFree(c->msm_tables[i].table);
       c->msm_tables.erase(c->msm_tables.begin() + i);
-      return;
+    } else {
+      i++;
     }
+  }
+}
+
+void msm_release_table(cq_ctx* c, const void* bases, size_t n, uint32_t c_bits) {
+  for (size_t i = 0; i < c->msm_tables.size(); i++) {
+    cq_ctx::MsmTable& t = c->msm_tables[i];
+    if (t.bases != bases || t.n != n || t.c != c_bits) continue;
+    if (--t.refs == 0) {
+      hipFree(t.table);
+      c->msm_tables.erase(c->msm_tables.begin() + i);
+    }
+    return;
+  }
 }
 
 // Builds and registers per-window tables T[w][i] = 2^(c*w) * bases[i] for a device-resident base array.
 // Memory: ceil(255/c) x n x 64 B (17 x the SRS for n >= 2^15) -- sized for 288 GB of HBM.
-int msm_register_tables(cq_ctx* c, const G1Affine* bases, size_t n) {
+int msm_register_tables(cq_ctx* c, const G1Affine* bases, size_t n, uint32_t want_c, bool* held) {
+  if (held) *held = false;
   if (!bases || n == 0 || n > (1u << 26)) return CQ_OK;  // nothing to do / unsupported: plain mode
+  // The width comes from the array's own length (15 bits up to 2^19 points, 17 from 2^20 on) unless the caller of the
+  // library (cq_msm_set_table_window) or of this function (a proving key bringing its small arrays to the width of its
+  // SRS, so that its MSMs share launches) says otherwise -- never from what happened to be registered first.
+  const uint32_t cb = want_c ? want_c : (c->msm_table_c ? c->msm_table_c : msm_table_window_bits(n));
+  for (auto& t : c->msm_tables)
+    if (t.bases == bases && t.n == n && t.c == cb) {  // the very entry: one more holder
+      t.refs++;
+      if (held) *held = true;
+      return CQ_OK;
+    }
   {
     size_t off = 0;
-    const cq_ctx::MsmTable* t = c->find_msm_table(bases, n, &off);
-    if (t && off == 0 && t->bases == bases) return CQ_OK;  // already registered (slices of it resolve to it too)
-    if (t) return CQ_OK;
+    const cq_ctx::MsmTable* t = c->find_msm_table(bases, n, &off, cb);
+    if (t && (t->c == cb || !want_c)) return CQ_OK;  // served by a registered (larger) array's table
   }
-  // one width per context (launches mix base arrays): the first registration decides unless the caller has
-  if (!c->msm_table_c) c->msm_table_c = msm_table_window_bits(n);
-  const uint32_t cb = c->msm_table_c;
   const uint32_t W = (255 + cb - 1) / cb;
   void* table = nullptr;
   if (hipMalloc(&table, (size_t)W * n * sizeof(G1Affine)) != hipSuccess) {
@@ -193,7 +223,8 @@ int msm_register_tables(cq_ctx* c, const G1Affine* bases, size_t n) {
     hipFree(table);
     return c->fail(CQ_ERR_HIP, "msm precompute failed");
   }
-  c->msm_tables.push_back({bases, n, cb, table});
+  c->msm_tables.push_back({bases, n, cb, table, 1});
+  if (held) *held = true;
   return CQ_OK;
 }
 
@@ -252,6 +283,13 @@ int cq_msm_set_precompute(cq_ctx* c, int on) {
 int cq_msm_set_table_window(cq_ctx* c, uint32_t bits) {
   if (!c || (bits != 0 && (bits < MSM_TABLE_C_MIN || bits > MSM_TABLE_C_MAX))) return CQ_ERR_ARG;
   c->msm_table_c = bits;
+  return CQ_OK;
+}
+
+int cq_msm_table_width_dev(cq_ctx* c, const uint64_t* bases_dev, size_t n, uint32_t preferred_bits, uint32_t* bits) {
+  if (!c || !bases_dev || !bits) return CQ_ERR_ARG;
+  const cq_ctx::MsmTable* t = c->find_msm_table(bases_dev, n, nullptr, preferred_bits);
+  *bits = t ? t->c : 0;
   return CQ_OK;
 }
 

@@ -69,6 +69,7 @@ struct cq_params {
   size_t n;
   cq::G1Affine* g;           // [s^i]_1
   cq::G1Affine* g_lagrange;  // [L_i(s)]_1
+  uint32_t key_users = 0;    // proving keys built on this object (a sharded key drops the whole-array tables only when alone)
 };
 
 // StaticTableConfig (plonk/static_lookup.rs:47-66): Lagrange SRS of the table-sized domain
@@ -78,6 +79,7 @@ struct cq_table_config {
   size_t N;
   cq::G1Affine* g1_lagrange = nullptr;
   cq::G1Affine* g_lagrange_opening_at_0 = nullptr;
+  uint32_t key_users = 0;
 };
 
 // StaticTableValues (plonk/static_lookup.rs:68-75)
@@ -158,6 +160,12 @@ struct cq_pk {
   bool shard_columns = true;
   cq_bcast_fn bcast = nullptr;
   void* bcast_user = nullptr;
-  // the window tables this key's MSMs use when sharded: built for the rank's slices only (capi_cq.hip)
-  std::vector<const void*> shard_tables;
+  // MSM window tables: the width this key's launches use (its SRS length decides; small arrays shared with keys of other
+  // sizes get a second table of this width), the registry entries the key holds a reference of, and -- when sharded --
+  // the tables of the rank's slices (capi_cq.hip: pk_shard_tables)
+  uint32_t table_c = 0;
+  struct TableRef { const void* bases; size_t n; uint32_t c; };
+  std::vector<TableRef> held_tables, shard_tables;
+  bool dropped_params_tables = false, dropped_cfg_tables = false;  // whole-array tables given up for slice tables
+  bool counted_users = false;
 };

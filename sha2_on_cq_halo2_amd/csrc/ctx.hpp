@@ -22,11 +22,12 @@ struct cq_ctx {
   void* pinned = nullptr;  // small pinned host staging buffer
   size_t pinned_bytes = 0;
   uint32_t msm_c = 0;  // 0 = automatic window size
-  uint32_t msm_table_c = 0;  // window width of the precomputed tables; 0 = decided by the first registration (msm.hpp)
+  uint32_t msm_table_c = 0;  // caller's override of the window width of precomputed tables (cq_msm_set_table_window); 0 = by array length
   bool msm_precompute = true;  // build per-window tables for resident SRS arrays
   void* fb_table = nullptr;  // fixed-base table d*2^(8j)*G (setup.hip)
   // precomputed MSM window tables, keyed by the base array they were derived from
-  struct MsmTable { const void* bases; size_t n; uint32_t c; void* table; };
+  // (an array may have tables of several widths: a small table SRS shared by keys of different sizes; `refs` = holders)
+  struct MsmTable { const void* bases; size_t n; uint32_t c; void* table; uint32_t refs; };
   std::vector<MsmTable> msm_tables;
   // `bases` may point anywhere inside a registered array (a rank's slice of the SRS); *offset = first point
   // Lanes: contexts of their own (stream, scratch, twiddle cache) on the same GPU, owned by `parent`, on which
@@ -34,18 +35,25 @@ struct cq_ctx {
   // and worker threads through its parent.
   cq_ctx* parent = nullptr;
   std::vector<cq_ctx*> lanes;
-  const MsmTable* find_msm_table(const void* bases, size_t len, size_t* offset = nullptr) const {
-    if (parent) return parent->find_msm_table(bases, len, offset);
+  // `want_c` != 0: a table of that window width if the range has one, any other otherwise
+  const MsmTable* find_msm_table(const void* bases, size_t len, size_t* offset = nullptr, uint32_t want_c = 0) const {
+    if (parent) return parent->find_msm_table(bases, len, offset, want_c);
+    const MsmTable* any = nullptr;
+    size_t any_off = 0;
     for (auto& t : msm_tables) {
       const char* b0 = (const char*)t.bases;
       const char* b = (const char*)bases;
       if (b < b0 || b >= b0 + t.n * 64) continue;
       const size_t off = (size_t)(b - b0) / 64;
       if ((size_t)(b - b0) % 64 || off + len > t.n) continue;
-      if (offset) *offset = off;
-      return &t;
+      if (!any) { any = &t; any_off = off; }
+      if (want_c == 0 || t.c == want_c) {
+        if (offset) *offset = off;
+        return &t;
+      }
     }
-    return nullptr;
+    if (any && offset) *offset = any_off;
+    return any;
   }
   // optional per-kernel timing with HIP events on `stream` (bench.py's roofline leg)
   struct ProfSpan { int id; hipEvent_t a, b; };

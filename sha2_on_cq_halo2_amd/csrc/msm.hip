@@ -1012,7 +1012,9 @@ int msm_run(cq_ctx* ctx, const Fr* const* scalars_host_ptrs, const G1Affine* con
     const uint32_t P = batch * L.npart;
     const uint64_t E = (uint64_t)batch * W * n;
     uint32_t* part_pay = (uint32_t*)(ws + L.off_ranks);
-    void* part_low = part_pay + E;  // u8 entries, or u16 ones followed by the refinement's output pair
+    // two passes: pay (4 E bytes) | low, a byte per entry.  With the refinement pass: pay | pay2 | low1 (u16) | low2 (u8),
+    // the 32-bit arrays first so that both stay 4-byte aligned whatever the parity of E
+    void* part_low = part_pay + (L.mid ? 2 * E : E);
     uint32_t* poff = (uint32_t*)(ws + L.off_poff);
     uint32_t* cursor = (uint32_t*)(ws + L.off_cursor);
     uint32_t* psize = (uint32_t*)(ws + L.off_psize);
@@ -1050,8 +1052,8 @@ int msm_run(cq_ctx* ctx, const Fr* const* scalars_host_ptrs, const G1Affine* con
     uint32_t F = P;
     if (L.mid) {  // 128 partitions of 2^(c-8) buckets -> partitions of 128 buckets
       const uint16_t* low1 = (const uint16_t*)part_low;
-      uint32_t* pay2 = (uint32_t*)(low1 + E);
-      uint8_t* low2 = (uint8_t*)(pay2 + E);
+      uint32_t* pay2 = part_pay + E;
+      uint8_t* low2 = (uint8_t*)(low1 + E);
       uint32_t* poff2 = (uint32_t*)(ws + L.off_poff2);
       uint32_t* psize2 = (uint32_t*)(ws + L.off_psize2);
       F = batch * L.nfinal;

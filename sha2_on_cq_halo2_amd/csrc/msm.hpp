@@ -117,5 +117,11 @@ int msm_multi_end(cq_ctx* c, MsmPending& pend, uint64_t* out_jac);
 constexpr uint32_t MSM_TABLE_C = 15, MSM_TABLE_C_MIN = 8, MSM_TABLE_C_MAX = 20;
 uint32_t msm_table_window_bits(size_t n);
 
-int msm_register_tables(cq_ctx* c, const cq::G1Affine* bases, size_t n);
+// Registry of the window tables (capi_msm.hip).  msm_register_tables: makes sure MSMs over [bases, bases + n) find a table --
+// of width `want_c` when given, else of the width the array's own length calls for (or the caller's override).  *held
+// (optional) tells whether the caller now holds a reference of an entry for exactly (bases, n, width) -- created, or found
+// and shared -- that it must give back with msm_release_table; false when the range is served by a larger array's table.
+// msm_unregister_tables drops every table of an array that is going away (its owner's call), whoever else held them.
+int msm_register_tables(cq_ctx* c, const cq::G1Affine* bases, size_t n, uint32_t want_c = 0, bool* held = nullptr);
+void msm_release_table(cq_ctx* c, const void* bases, size_t n, uint32_t c_bits);
 void msm_unregister_tables(cq_ctx* c, const void* bases);

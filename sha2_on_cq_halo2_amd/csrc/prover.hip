@@ -9,7 +9,7 @@
 //
 // Scope: one circuit with advice / fixed / instance columns, custom gates (postfix programs, plonk.hip), the
 // permutation argument, static (CQ) lookups whose inputs are arbitrary expressions, legacy plookup-style lookups
-// (grand product on the GPU, the sort of `permute_expression_pair` on the host), multi-phase circuits with user
+// (grand product and the sort of `permute_expression_pair` on the GPU, lksort.hip), multi-phase circuits with user
 // challenges (cq_create_proof_phases), ProverGWC or ProverSHPLONK.  One deliberate omission:
 // evaluation.rs:317-335 transforms every advice / instance polynomial to the extended coset even when no term
 // reads them (a CQ-only circuit); that dead work is skipped.

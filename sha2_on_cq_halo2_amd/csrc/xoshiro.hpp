@@ -7,6 +7,7 @@
 #pragma once
 #include <cstddef>
 #include <cstdint>
+#include <memory>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -65,10 +66,10 @@ struct XoshiroJump {
   // T^(2^j), built on demand
   static const Mat& pow2(unsigned j) {
     static std::mutex mu;
-    static std::vector<Mat*> cache;
+    static std::vector<std::unique_ptr<Mat>> cache;  // (owned: nothing is left behind for a leak checker at exit)
     std::lock_guard<std::mutex> lock(mu);
     while (cache.size() <= j) {
-      Mat* m = new Mat;
+      std::unique_ptr<Mat> m(new Mat);
       if (cache.empty()) {
         for (int b = 0; b < 256; b++) {
           uint64_t e[4] = {0, 0, 0, 0};
@@ -84,7 +85,7 @@ struct XoshiroJump {
           for (int w = 0; w < 4; w++) m->col[b].s[w] = v[w];
         }
       }
-      cache.push_back(m);
+      cache.push_back(std::move(m));
     }
     return *cache[j];
   }

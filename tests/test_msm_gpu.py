@@ -304,3 +304,73 @@ def test_msm_k18_round2_shaped_launch_matches_c_oracle(ctx):
     for j, i in enumerate(order):
         assert np.array_equal(OC.g1_to_affine(res[j]), exp[i]), "MSM %d of the launch differs from the oracle" % j
     params.close()
+
+
+def test_table_width_does_not_depend_on_construction_order():
+    """The window width of an array's tables comes from the array (and a key brings its small arrays to the width of its SRS
+    tables), not from whatever was registered first on the context: a table config built under another width, then params
+    and a key built normally, give the tables of a fresh context -- and the same proof bytes in every mix."""
+    import types
+
+    from sha2_on_cq_halo2_amd import Context, ParamsKZG
+    from sha2_on_cq_halo2_amd.api import fr_to_mont
+    from sha2_on_cq_halo2_amd.sha_circuit import ShaCqWorkload
+
+    k, n = 11, 1 << 11
+    c0 = Context(0)
+    base = ShaCqWorkload(c0, k, pairs=2)
+    p0 = base.prove(seed=3)
+    assert c0.msm_table_width(base.params.g_dev, n) == 15
+    c0.close()
+
+    c1 = Context(0)
+    c1.set_msm_table_window(12)
+    narrow = ShaCqWorkload(c1, k, pairs=2)  # every table of this one: 12 bits
+    assert c1.msm_table_width(narrow.params.g_dev, n) == 12
+    assert narrow.prove(seed=3) == p0
+    c1.set_msm_table_window(0)
+    seed = 0x5348413243515F
+    params = ParamsKZG.setup_from_toxic_waste(c1, k, fr_to_mont(seed * 0x9E3779B97F4A7C15 + 12345))
+    assert c1.msm_table_width(params.g_dev, n) == 15  # its own length decides, not the 12-bit tables built before it
+    mixed = ShaCqWorkload(c1, k, pairs=2, share=types.SimpleNamespace(k=k, params=params, cfg=narrow.cfg, dense=narrow.dense, spread=narrow.spread))
+    assert mixed.prove(seed=3) == p0      # table SRS built at 12 bits, SRS at 15: the key added 15-bit tables for the small arrays
+    assert narrow.prove(seed=3) == p0     # ... next to the 12-bit ones the first key still uses
+    mixed.pk.close()
+    assert narrow.prove(seed=3) == p0
+    c1.close()
+
+
+def test_sharded_key_leaves_the_tables_of_shared_srs_objects_alone():
+    """cq_pk_set_sharding builds window tables for the rank's slices; the whole-array tables of params / table config are
+    given up for that only while the key is their one user, and come back with world = 1 or when the key is destroyed."""
+    import ctypes as C
+
+    from sha2_on_cq_halo2_amd import Context
+    from sha2_on_cq_halo2_amd.api import _ALLGATHER_T
+    from sha2_on_cq_halo2_amd.sha_circuit import ShaCqWorkload
+
+    k, n = 11, 1 << 11
+    c = Context(0)
+    a = ShaCqWorkload(c, k, pairs=2)
+    b = ShaCqWorkload(c, k, pairs=2, share=a)
+    p0 = a.prove(seed=4)
+    never = _ALLGATHER_T(lambda *_: -1)  # no proof is made with the sharded key here: the registry is what is checked
+
+    def shard(wl, rank, world):
+        c._chk(c.lib.cq_pk_set_sharding(wl.pk.h, rank, world, C.cast(never, C.c_void_p) if world > 1 else None, None))
+
+    g = a.params.g_dev
+    shard(b, 1, 2)
+    assert c.msm_table_width(g, n) == 15            # `a` shares the params: its whole-array tables stay
+    assert a.prove(seed=4) == p0
+    b.pk.close()                                    # destroying the sharded key takes nothing of a's with it
+    assert c.msm_table_width(g, n) == 15 and a.prove(seed=4) == p0
+    shard(a, 1, 2)                                  # now the only user: slices only
+    lo = n // 2
+    assert c.msm_table_width(g, n) == 0 and c.msm_table_width(g + 64 * lo, n - lo) == 15
+    shard(a, 0, 1)
+    assert c.msm_table_width(g, n) == 15 and a.prove(seed=4) == p0
+    shard(a, 0, 2)
+    a.pk.close()                                    # a sharded key that goes away restores what it had dropped
+    assert c.msm_table_width(g, n) == 15
+    c.close()

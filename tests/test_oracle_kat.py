@@ -39,10 +39,32 @@ def test_fq_constants_and_curve():
     assert neg_one == (q - 1) * B.FQ_R % q  # NEGATIVE_ONE is stored in Montgomery form (fq.rs:61-66)
     assert pow(B.FQ_ZETA, 3, q) == 1 and B.FQ_ZETA != 1
     assert B.is_on_curve(B.G1_GEN)
-    # endomorphism check, curve.rs:266-270: g * (-ENDO_BETA... ) -- here: zeta_q * x stays on the curve
     x, y = B.G1_GEN
     assert B.is_on_curve((B.FQ_ZETA * x % q, y))
     assert B.g1_mul(B.G1_GEN, B.R_MOD) is None  # group order
+
+
+def test_endo_consistency():
+    """bn256/curve.rs:266-270 `test_endo_consistency`: g * (-ENDO_BETA) == g.endo(), with endo() = (ZETA_q * x, -y, z)
+    (curve.rs:137-143) and ENDO_BETA the raw limbs of curve.rs:78-83 (stored in tests/golden/reference_kats.json)."""
+    import json
+    import os
+
+    kat = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_kats.json")))["g1_endomorphism"]
+    endo_beta = sum(int(h, 16) << (64 * i) for i, h in enumerate(kat["endo_beta_raw_limbs"]))
+    x, y = B.G1_GEN
+    assert B.g1_mul(B.G1_GEN, (-endo_beta) % B.R_MOD) == (B.FQ_ZETA * x % B.Q_MOD, (-y) % B.Q_MOD)
+    assert pow(endo_beta, 3, B.R_MOD) == 1 and endo_beta != 1  # a cube root of unity in Fr, as the identity requires
+
+
+def test_toy_sha_round_kat():
+    """sha-reference/src/lib.rs:53-80: the one KAT of the toy bit-vector round (2-bit words, `+` is XOR)."""
+    import json
+    import os
+
+    kat = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_kats.json")))["toy_sha_round_2bit"]
+    out = ST.toy_sha_round(tuple(list(w) for w in kat["input_a_to_h"]))
+    assert [list(w) for w in out] == kat["expected_a_to_h"]
 
 
 def test_sha_table_kats():

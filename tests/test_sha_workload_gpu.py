@@ -13,6 +13,7 @@ from oracle import cq_verifier as CV
 from oracle import sha_tables as ST
 
 pytestmark = pytest.mark.gpu
+SC_BLOCKS = {14: 1, 16: 16, 18: 64, 20: 256, 22: 1024}  # BASELINE.json configs: SHA-256 blocks per circuit size
 
 
 def _spread(x):
@@ -62,10 +63,12 @@ def test_witness_fill_matches_decomposition_table(ctx):
     assert all(v == 0 for v in cols[0][rows_used:wl.pk.usable_rows])
 
 
-@pytest.mark.parametrize("k,pairs", [(10, 2), (12, 2), (16, 4)])
+@pytest.mark.parametrize("k,pairs", [(10, 2), (12, 2), (16, 4), (18, 4), (20, 4)])
 def test_proof_bytes_equal_c_reference_restatement(ctx, k, pairs):
-    """k = 16 with 4 pairs is BASELINE configs[1] (16 SHA blocks, 8 advice columns): byte for byte against the C
-    restatement of the reference prover ("parity unpinned" against the Rust prover itself: it holds no fixture)."""
+    """Byte for byte against the C restatement of the reference prover (plonk/prover.rs:51-779 and what it calls) at the
+    BASELINE sizes: k = 16 with 4 pairs is configs[1] (16 SHA blocks, 8 advice columns), k = 18 configs[2] -- the metric's
+    own size, 64 blocks --, k = 20 configs[3] (256 blocks; about a minute of CPU).  "Parity unpinned" against the Rust
+    prover itself: it holds no fixture."""
     from sha2_on_cq_halo2_amd.api import fr_to_mont
     from sha2_on_cq_halo2_amd.sha_circuit import ShaCqWorkload, small_to_mont, spread16
 
@@ -81,9 +84,14 @@ def test_proof_bytes_equal_c_reference_restatement(ctx, k, pairs):
     advice = [c.download((n, 4)) for c in wl.cols]
     lookups = [[(2 * p, 0), (2 * p + 1, 1)] for p in range(wl.pairs)]
     la = OC.keygen_l_active(k, 5)
-    cproof = OC.create_proof(k, 2 * wl.pairs, lookups, tvals, tqs, g, gl, tl, t0, g[1:], la, fr_to_mont(0xC0FFEE + k), advice, 5)
+    blocks, size = wl.blocks, wl.pk.proof_size
+    if k >= 18:  # give the window tables back before the CPU leg (and the next test)
+        wl.close()
+    cproof = OC.create_proof(k, 2 * pairs, lookups, tvals, tqs, g, gl, tl, t0, g[1:], la, fr_to_mont(0xC0FFEE + k), advice, 5)
     assert proof == cproof
-    assert len(proof) == wl.pk.proof_size
+    assert len(proof) == size
+    if k in SC_BLOCKS:
+        assert blocks == SC_BLOCKS[k]
 
 
 def _verify_workload_proof(wl, proof, seed_s, pairing=False):
@@ -146,10 +154,13 @@ def test_large_k_proof_is_accepted_and_deterministic(ctx, k):
         assert wl.pk.create_proof_dev([c.ptr for c in wl.cols], seed=31, opaque_rng=True) == p1
         s = (seed * 0x9E3779B97F4A7C15 + 12345) % B.R_MOD
         assert _verify_workload_proof(wl, p1, s)
+        # ... and with REAL pairings (the C restatement of the BN254 pairing): the GWC opening and the seven-term CQ
+        # equations of every lookup (static_lookup/verifier.rs:138-177)
+        assert _verify_workload_proof(wl, p1, s, pairing="c")
         bad = bytearray(p1)
         bad[40] ^= 0x02  # inside the second advice commitment
         try:
-            assert not _verify_workload_proof(wl, bytes(bad), s)
+            assert not _verify_workload_proof(wl, bytes(bad), s, pairing="c")
         except ValueError:
             pass
     finally:  # 4.3 GiB of window tables per SRS array at k = 22: give them back before the next test
