@@ -34,10 +34,86 @@ import numpy as np  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 MSM_BYTES_PER_SCALAR = 96  # 32 B scalar + 64 B affine base
 NTT_BYTES_PER_ELEM = 64  # read once + write once
-CPU_BASELINE_K = 18  # the metric's own configuration, proven once by the CPU restatement (~30 s on 16 threads)
+CPU_BASELINE_K = 18  # the metric's own configuration, proven once by the CPU restatement (~20 s on 16 threads)
 CPU_BASELINE_SMALL_K = 16  # kept beside it: BASELINE configs[1] (16 SHA blocks)
-PMC_TRAFFIC_FILE = "profiles/r02_pmc_traffic_k18_proof.json"
-PMC_SQ_FILE = "profiles/r02_pmc_sq_accumulate_k18.json"
+PMC_TRAFFIC_FILE = "profiles/r03_pmc_traffic_k18_proof.json"
+PMC_SQ_FILE = "profiles/r03_pmc_sq_accumulate_k18.json"
+PMC_FALLBACK = {"profiles/r03_pmc_traffic_k18_proof.json": "profiles/r02_pmc_traffic_k18_proof.json",
+                "profiles/r03_pmc_sq_accumulate_k18.json": "profiles/r02_pmc_sq_accumulate_k18.json"}
+
+
+def _pmc_path(name):
+    """The committed PMC summary of this round, or the previous round's when this round's is not there yet."""
+    path = os.path.join(ROOT, name)
+    return (path, name) if os.path.exists(path) else (os.path.join(ROOT, PMC_FALLBACK[name]), PMC_FALLBACK[name])
+
+
+class Dist:
+    """The job's process group.  Default: "nccl" (= RCCL over xGMI), one rank per GPU, the library's own RCCL transport
+    for the sharded legs.  CQ_BENCH_DIST_BACKEND=gloo: the SAME code path on ONE GPU -- every rank on cuda:0, the timing
+    reductions on CPU tensors, the sharded legs through the library's host-callback transport -- so that
+    `torchrun --nproc-per-node 2 bench.py --gpus 2` can be rehearsed (and is tested, tests/test_bench_multirank_gpu.py) on a
+    box with one card; it measures nothing about xGMI."""
+
+    def __init__(self):
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.backend = os.environ.get("CQ_BENCH_DIST_BACKEND", "nccl")
+        assert self.backend in ("nccl", "gloo"), self.backend
+        self.device_index = 0 if self.backend == "gloo" else self.local_rank
+        self.transport = "rccl" if self.backend == "nccl" else "callback"
+
+    def init(self):
+        import torch
+        import torch.distributed as dist
+
+        torch.cuda.set_device(self.device_index)
+        if self.world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if self.backend == "nccl":
+                dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=torch.device("cuda", self.device_index))
+            else:
+                dist.init_process_group("gloo", rank=self.rank, world_size=self.world)
+
+    def barrier(self):
+        import torch
+
+        if self.world > 1:
+            import torch.distributed as dist
+
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def max_over_ranks(self, values):
+        """element-wise MAX of a list of floats over the ranks"""
+        if self.world == 1:
+            return list(values)
+        import torch
+        import torch.distributed as dist
+
+        t = torch.tensor(list(values), dtype=torch.float64, device=f"cuda:{self.device_index}" if self.backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return [float(x) for x in t.cpu()]
+
+    def shard(self, ctx, pk, columns=True, resident=False):
+        """one proof over all ranks: MSM point ranges + column transforms (multi-GPU)"""
+        import torch
+
+        if self.transport == "rccl":
+            if not getattr(ctx, "_bench_comm", False):
+                ctx.comm_init_from_torch(device=torch.device("cuda", self.device_index))
+                ctx.comm_selftest()
+                ctx._bench_comm = True
+            pk.set_sharding(self.rank, self.world, transport="rccl", columns=columns, resident=resident)
+        else:
+            pk.set_sharding(self.rank, self.world, transport="callback", columns=columns, resident=resident)
+
+    def finish(self):
+        if self.world > 1:
+            import torch.distributed as dist
+
+            dist.destroy_process_group()
 
 
 def main():
@@ -50,23 +126,18 @@ def main():
     ap.add_argument("--no-plonk-variant", action="store_true")
     ap.add_argument("--no-in-flight", action="store_true")
     ap.add_argument("--no-generic-rng", action="store_true")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip host_advice / dense_witness / ntt_ext / msm_standalone / batched_k22")
     ap.add_argument("--no-k20", action="store_true", help="skip the BASELINE configs[3] leg (k=20, one proof over all ranks)")
     ap.add_argument("--k20-child", action="store_true", help=argparse.SUPPRESS)  # internal: the configs[3] leg in a process of its own
     args = ap.parse_args()
     if args.k20_child:
         return k20_child_main()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-
+    D = Dist()
+    rank, world, local_rank = D.rank, D.world, D.device_index
     import torch
-    import torch.distributed as dist
 
-    torch.cuda.set_device(local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    D.init()
 
     from sha2_on_cq_halo2_amd import Context
     from sha2_on_cq_halo2_amd.api import PROF_MSM_ACCUMULATE, PROF_MSM_ENTRIES, PROF_NTT_PASS
@@ -83,17 +154,13 @@ def main():
     shard = os.environ.get("CQ_BENCH_MODE", "replicas") == "shard" and world > 1
     wl = ShaCqWorkload(ctx, k, seed=0x5348413243515F + (0 if shard else rank))
     if shard:
-        ctx.comm_init_from_torch(device=torch.device("cuda", local_rank))
-        wl.pk.set_sharding(rank, world, transport="rccl")
+        D.shard(ctx, wl.pk)
 
     def step(i):
         wl.fill_witness()
         return wl.prove(seed=1000 + i)
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+    barrier = D.barrier
 
     proof = b""
     ctx.profile_enable(True)  # before the warm-up: the profiling events are created on first use, not in the timed region
@@ -121,10 +188,7 @@ def main():
     _, msm_entries = ctx.profile_read(PROF_MSM_ENTRIES)
     ctx.profile_enable(False)
 
-    if world > 1:
-        t = torch.tensor([elapsed], device=f"cuda:{local_rank}", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = D.max_over_ranks([elapsed])[0]
 
     scalars_per_step = wl.msm_scalars_per_proof()
     proofs = 1 if shard else world
@@ -153,6 +217,7 @@ def main():
             "ntt_elems_per_proof": wl.ntt_elems_per_proof(),
             "parallelism": (f"one proof, MSM point ranges and column transforms sharded x{world} (RCCL all-gather / broadcast)" if shard else
                             f"replicas x{world} (one independent proof per GPU, no collective)"),
+            "dist_backend": D.backend if world > 1 else None,
         },
         "proof_wall_s": elapsed / args.steps,
         "step_ms_all_this_rank": [round(x, 3) for x in step_ms],
@@ -169,7 +234,7 @@ def main():
     if not args.no_k20 and k == 18:
         if world == 1 and os.environ.get("CQ_BENCH_K20_CHILD", "0") != "1":  # (the env switch: the child path on one GPU, for testing)
             try:
-                k20 = config3_k20(ctx, rank, world, local_rank)
+                k20 = config3_k20(ctx, D)
             except Exception as e:  # noqa: BLE001
                 k20 = {"error": f"{type(e).__name__}: {e}"}
         else:
@@ -179,8 +244,7 @@ def main():
             out["config3_k20"] = k20
         _finish_line(out, ctx, wl, args, k, acc_ms, acc_calls, ntt_ms, ntt_calls, msm_entries, world)
     ctx.close()
-    if world > 1:
-        dist.destroy_process_group()
+    D.finish()
 
 
 def _finish_line(out, ctx, wl, args, k, acc_ms, acc_calls, ntt_ms, ntt_calls, msm_entries, world, light=False):
@@ -206,9 +270,9 @@ def _finish_line(out, ctx, wl, args, k, acc_ms, acc_calls, ntt_ms, ntt_calls, ms
             "frac": achieved / HBM_PEAK_GBS,
             # PMC figures are NOT measured by this run: they are read from the committed rocprofv3 --pmc passes
             "traffic": pmc_traffic("msm_accumulate_kernel") if k == 18 else None,
-            "traffic_source": f"{PMC_TRAFFIC_FILE} (committed rocprofv3 --pmc pass over the same k=18 proof, not this run)" if k == 18 else None,
+            "traffic_source": f"{_pmc_path(PMC_TRAFFIC_FILE)[1]} (committed rocprofv3 --pmc pass over the same k=18 proof, not this run)" if k == 18 else None,
             "valu_issue_utilisation_pmc": pmc_valu_issue() if k == 18 else None,
-            "valu_issue_utilisation_source": f"{PMC_SQ_FILE} (committed rocprofv3 --pmc pass, not this run)" if k == 18 else None,
+            "valu_issue_utilisation_source": f"{_pmc_path(PMC_SQ_FILE)[1]} (committed rocprofv3 --pmc pass, not this run)" if k == 18 else None,
             "launches": int(acc_calls),
             "avg_launch_ms": acc_ms / max(acc_calls, 1),
             "msm_kernel_mscalar_per_s": units / acc_s / 1e6 if acc_s > 0 else 0.0,
@@ -241,7 +305,7 @@ def _finish_line(out, ctx, wl, args, k, acc_ms, acc_calls, ntt_ms, ntt_calls, ms
             "unit": "GB/s",
             "frac": ntt_ach / HBM_PEAK_GBS,
             "traffic": pmc_traffic("ntt_pass_kernel<6u, 4u>") if k == 18 else None,  # the 2^18 transform's passes
-            "traffic_source": f"{PMC_TRAFFIC_FILE} (committed rocprofv3 --pmc pass, not this run)" if k == 18 else None,
+            "traffic_source": f"{_pmc_path(PMC_TRAFFIC_FILE)[1]} (committed rocprofv3 --pmc pass, not this run)" if k == 18 else None,
             "error": sa_error,
             "launches": int(sa_calls),
             "melem_per_s": sa_elems / (sa_ms / 1e3) / 1e6 if sa_ms > 0 else 0.0,
@@ -266,6 +330,12 @@ def _finish_line(out, ctx, wl, args, k, acc_ms, acc_calls, ntt_ms, ntt_calls, ms
             leg("two_in_flight", lambda: two_in_flight(ctx, wl, local_rank, max(10, args.steps)))
         if world == 1 and not args.no_plonk_variant:
             leg("plonk_variant", lambda: plonk_variant(ctx, wl, max(2, min(args.steps, 5))))
+        if world == 1 and not args.no_extra_legs:
+            leg("host_advice", lambda: host_advice(wl, max(5, min(args.steps, 10))))
+            leg("dense_witness", lambda: dense_witness(ctx, wl, max(5, min(args.steps, 10))))
+            leg("ntt_ext", lambda: ntt_ext(ctx, k))
+            leg("msm_standalone", lambda: msm_standalone(ctx))
+            leg("batched_k22", lambda: batched_k22(ctx))
         if world == 1 and not args.no_cpu_baseline:
             leg("cpu_baseline", lambda: cpu_baseline(ctx))
         print(json.dumps(out), flush=True)
@@ -309,17 +379,16 @@ def batched(ctx, wl, count):
     for lanes in (2, 3, 4):
         wl.pk.create_proof_batch(ptrs[:lanes], [1 + i for i in range(lanes)], lanes=lanes)  # warm the lanes (twiddles, arenas)
         torch.cuda.synchronize()
-        # three batches, the fastest reported (all listed): the lanes' host threads share the box's CPU quota with whatever
-        # else runs there, and one descheduled lane thread stalls a third of the GPU's work
+        # three batches, the median reported (all listed)
         samples = []
         for _ in range(3):
             t0 = time.perf_counter()
             proofs = wl.pk.create_proof_batch(ptrs, [500 + i for i in range(count)], lanes=lanes)
             samples.append(time.perf_counter() - t0)
-        dt = min(samples)
+        dt = sorted(samples)[1]
         res[f"lanes_{lanes}"] = {"proofs_per_s": count / dt, "ms_per_proof_effective": dt / count * 1e3,
                                  "mscalar_per_s": count * wl.msm_scalars_per_proof() / dt / 1e6,
-                                 "batch_wall_s_samples": samples, "reported": "fastest of 3 batches",
+                                 "batch_wall_s_samples": samples, "reported": "median of 3 batches",
                                  "first_proof_equals_single": proofs[0] == single}
     for mine in cols:
         for b in mine:
@@ -395,12 +464,178 @@ def plonk_variant(ctx, wl, steps):
     return res
 
 
+def _uniform_scalars(count, seed):
+    rs = np.random.RandomState(seed)
+    a = rs.randint(0, 2**63, size=(count, 4), dtype=np.int64).astype(np.uint64)
+    a[:, 3] &= np.uint64((1 << 60) - 1)  # below the modulus whatever the rest
+    return a
+
+
+def _median(xs):
+    return sorted(xs)[len(xs) // 2]
+
+
+def msm_standalone(ctx, sizes=(16, 18, 20, 22), reps=5):
+    """MSM throughput as the metric defines it -- m / t over the WALL time of one dense `best_multiexp`
+    (arithmetic.rs:132-159) with uniform scalars over a resident 2^m-point SRS (`commit`, kzg/commitment.rs:539-543):
+    digits, sort, bucket accumulation, bucket reduction, read-back and the host's fold, result on the host.  `single` = one
+    MSM per call (latency-bound at small m: the tail of a launch is a chain of dependent group additions), `batch8` = eight
+    MSMs over the same bases in one launch (cq_msm_batch_dev; what a round of create_proof issues)."""
+    from sha2_on_cq_halo2_amd import ParamsKZG
+    from sha2_on_cq_halo2_amd.api import fr_to_mont
+
+    res = {}
+    s = fr_to_mont(0x5348413243515F * 0x9E3779B97F4A7C15 + 12345)
+    for m in sizes:
+        n = 1 << m
+        params = ParamsKZG.setup_from_toxic_waste(ctx, m, s)
+        host = _uniform_scalars(n, 100 + m)
+        cols = [ctx.to_device(np.roll(host, 7 * j, axis=0)) for j in range(8)]
+        ctx.best_multiexp_dev(cols[0], _Ptr(params.g_dev), n)
+        ctx.msm_batch_dev([c.ptr for c in cols], params.g_dev, n)
+        single, batch = [], []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            ctx.best_multiexp_dev(cols[0], _Ptr(params.g_dev), n)
+            single.append(time.perf_counter() - t0)
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            ctx.msm_batch_dev([c.ptr for c in cols], params.g_dev, n)
+            batch.append(time.perf_counter() - t0)
+        res[f"2^{m}"] = {"single_ms": _median(single) * 1e3, "single_mscalar_per_s": n / _median(single) / 1e6,
+                         "batch8_ms": _median(batch) * 1e3, "batch8_mscalar_per_s": 8 * n / _median(batch) / 1e6,
+                         "table_window_bits": ctx.msm_table_width(params.g_dev, n)}
+        for c in cols:
+            c.free()
+        params.close()
+    res["note"] = "wall time per call, median of %d, scalars and bases resident in HBM, result (one Jacobian point per MSM) on the host" % reps
+    return res
+
+
+class _Ptr:
+    """a bare device pointer where the API takes a DevBuf"""
+
+    def __init__(self, ptr):
+        self.ptr = ptr
+
+
+def ntt_ext(ctx, k, batch=8, reps=10):
+    """SURVEY 8(d)(3) at the extended size: `coeff_to_extended` (poly/domain.rs:252-266: coset shift, zero padding to
+    2^extended_k, NTT) of `batch` columns of 2^k coefficients, and `extended_to_coeff` (:293-315) of one column; wall time
+    per call, nothing else on the GPU.  Elements counted at the transform size (2^extended_k)."""
+    from sha2_on_cq_halo2_amd.api import EvaluationDomain
+
+    dom = EvaluationDomain(ctx, 3, k)
+    n, ext = 1 << k, dom.extended_len
+    src = ctx.to_device(_uniform_scalars(batch * n, 11))
+    dst = ctx.alloc(batch * ext * 32)
+    out = {"extended_k": dom.extended_len.bit_length() - 1}
+    ctx._chk(ctx.lib.cq_coeff_to_extended_dev(dom.h, src.ptr, dst.ptr, batch))
+    ctx.sync()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        ctx._chk(ctx.lib.cq_coeff_to_extended_dev(dom.h, src.ptr, dst.ptr, batch))
+    ctx.sync()
+    dt = (time.perf_counter() - t0) / reps
+    out["coeff_to_extended"] = {"batch": batch, "ms_per_call": dt * 1e3, "melem_per_s": batch * ext / dt / 1e6,
+                                "algorithmic_gb_per_s": batch * (32 * n + 32 * ext) / dt / 1e9}
+    ctx._chk(ctx.lib.cq_extended_to_coeff_dev(dom.h, dst.ptr, src.ptr))
+    ctx.sync()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        ctx._chk(ctx.lib.cq_extended_to_coeff_dev(dom.h, dst.ptr, src.ptr))
+    ctx.sync()
+    dt = (time.perf_counter() - t0) / reps
+    out["extended_to_coeff"] = {"batch": 1, "ms_per_call": dt * 1e3, "melem_per_s": ext / dt / 1e6}
+    for b in (src, dst):
+        b.free()
+    dom.close()
+    return out
+
+
+def host_advice(wl, steps):
+    """The real caller's path: `WitnessCollection` hands over HOST advice columns (plonk/prover.rs:223-260), so the proof
+    starts with their upload (cq_create_proof_host; 8 x 8 MiB at k = 18 over PCIe).  Never `value`: the headline starts
+    with the columns resident in HBM."""
+    host = [c.download((wl.n, 4)) for c in wl.cols]
+    wl.pk.create_proof(host, seed=1)
+    ms = []
+    for i in range(steps):
+        t0 = time.perf_counter()
+        proof = wl.pk.create_proof(host, seed=1000 + i)
+        ms.append((time.perf_counter() - t0) * 1e3)
+    same = proof == wl.pk.create_proof_dev([c.ptr for c in wl.cols], seed=1000 + steps - 1)
+    return {"ms_per_step_median": _median(ms), "ms_per_step_mean": sum(ms) / len(ms), "steps": steps, "upload_bytes": sum(h.nbytes for h in host),
+            "proof_equals_device_resident": bool(same), "note": "pageable host columns -> pinned staging -> HBM inside the timed call"}
+
+
+def dense_witness(ctx, wl, steps):
+    """The same circuit with EVERY usable row assigned (the SHA trace of the headline fills 9.4 % of them): random table
+    rows, so the eight advice commitments are MSMs over 2^k non-zero 12- / 24-bit scalars each."""
+    from sha2_on_cq_halo2_amd.sha_circuit import small_to_mont, spread16
+
+    N, u = wl.cfg.size, wl.pk.usable_rows
+    idx = np.arange(N)
+    dense_m, spread_m = small_to_mont(idx), small_to_mont(spread16(idx))
+    rs = np.random.RandomState(5)
+    cols = []
+    for p in range(wl.pairs):
+        rows = rs.randint(0, N, size=u)
+        for tab in (dense_m, spread_m):
+            col = np.zeros((wl.n, 4), dtype=np.uint64)
+            col[:u] = tab[rows]
+            cols.append(ctx.to_device(col))
+    ptrs = [c.ptr for c in cols]
+    wl.pk.create_proof_dev(ptrs, seed=1)
+    ms = []
+    for i in range(steps):
+        t0 = time.perf_counter()
+        wl.pk.create_proof_dev(ptrs, seed=2000 + i)
+        ms.append((time.perf_counter() - t0) * 1e3)
+    for c in cols:
+        c.free()
+    return {"ms_per_step_median": _median(ms), "ms_per_step_mean": sum(ms) / len(ms), "steps": steps, "assigned_rows_per_column": int(u),
+            "mscalar_per_s": wl.msm_scalars_per_proof() / (_median(ms) / 1e3) / 1e6}
+
+
+def batched_k22(ctx, instances=2, lanes=2, batches=3):
+    """BASELINE configs[4] at its own size: the per-GPU unit of "k=22 batched proofs (16 independent SHA256 instances),
+    8 x MI355X" is two k = 22 (1024-block) instances; here through cq_create_proof_batch with two lanes."""
+    from sha2_on_cq_halo2_amd.sha_circuit import ShaCqWorkload
+
+    wl = ShaCqWorkload(ctx, 22, seed=0x5348413243515F)
+    try:
+        host = [c.download((wl.n, 4)) for c in wl.cols]
+        cols = [[ctx.to_device(h) for h in host] for _ in range(instances)]
+        ptrs = [[c.ptr for c in mine] for mine in cols]
+        single = wl.pk.create_proof_dev(ptrs[0], seed=500)
+        t0 = time.perf_counter()
+        wl.pk.create_proof_dev(ptrs[0], seed=500)
+        one = time.perf_counter() - t0
+        wl.pk.create_proof_batch(ptrs, [1 + i for i in range(instances)], lanes=lanes)
+        samples = []
+        for _ in range(batches):
+            t0 = time.perf_counter()
+            proofs = wl.pk.create_proof_batch(ptrs, [500 + i for i in range(instances)], lanes=lanes)
+            samples.append(time.perf_counter() - t0)
+        dt = _median(samples)
+        for mine in cols:
+            for b in mine:
+                b.free()
+        return {"k": 22, "blocks": wl.blocks, "instances": instances, "lanes": lanes, "ms_per_proof_effective": dt / instances * 1e3,
+                "proofs_per_s": instances / dt, "mscalar_per_s": instances * wl.msm_scalars_per_proof() / dt / 1e6,
+                "one_at_a_time_ms": one * 1e3, "batch_wall_s_samples": samples, "reported": "median of %d batches" % batches,
+                "first_proof_equals_single": proofs[0] == single}
+    finally:
+        wl.close()
+
+
 def pmc_traffic(kernel):
     """HBM bytes per launch from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over the same
     k=18 proof (profiles/README.md); None if the summary is missing.  FETCH_SIZE is taken at face value
     (the gather of 64-B points is not the wide coalesced stream the gfx950 x2 correction applies to); the
     doubled figure is kept alongside in the profile file."""
-    path = os.path.join(ROOT, PMC_TRAFFIC_FILE)
+    path, _ = _pmc_path(PMC_TRAFFIC_FILE)
     try:
         with open(path) as f:
             d = json.load(f)
@@ -442,7 +677,7 @@ def pmc_valu_issue():
     """VALU issue utilisation of the accumulate launch that holds most of a proof's additions (SQ_INSTS_VALU x 4
     cycles / (1024 SIMDs x GPU cycles)), from the committed rocprofv3 --pmc pass over the same k=18 proof
     (profiles/README.md); None if the summary is missing."""
-    path = os.path.join(ROOT, PMC_SQ_FILE)
+    path, _ = _pmc_path(PMC_SQ_FILE)
     try:
         with open(path) as f:
             rows = json.load(f)["kernels"]["msm_accumulate_kernel"]
@@ -458,12 +693,27 @@ def k20_in_children(rank):
     prints the block as JSON; a child that does not finish in time is killed (by pid) and reported as an error."""
     import subprocess
 
-    env = dict(os.environ)
+    # The child's rendezvous is its own: another port, and rank 0 of the children hosts the store itself -- under torchrun
+    # TORCHELASTIC_USE_AGENT_STORE tells c10d that the launcher's agent already serves MASTER_PORT, so with it inherited
+    # every child would wait as a client for a server nobody started (found by the two-ranks-on-one-GPU rehearsal).
+    env = {k: v for k, v in os.environ.items() if not k.startswith("TORCHELASTIC_")}
     env["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 1000 + int(os.environ.get("WORLD_SIZE", "1")))
     timeout = float(os.environ.get("CQ_BENCH_K20_TIMEOUT", "240"))
+    import tempfile
+
+    errlog = os.path.join(tempfile.gettempdir(), f"cq_bench_k20_child_rank{rank}.err")
+
+    def err_tail():
+        try:
+            with open(errlog, errors="replace") as f:
+                return f.read()[-600:].strip()
+        except OSError:
+            return ""
+
     try:
-        p = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--k20-child"], env=env, stdout=subprocess.PIPE,
-                             stderr=subprocess.DEVNULL, cwd=os.path.dirname(os.path.abspath(__file__)) or ".")
+        with open(errlog, "w") as ef:
+            p = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--k20-child"], env=env, stdout=subprocess.PIPE,
+                                 stderr=ef, cwd=os.path.dirname(os.path.abspath(__file__)) or ".")
     except OSError as e:
         return {"error": f"could not start the child process: {e}"}
     try:
@@ -471,7 +721,7 @@ def k20_in_children(rank):
     except subprocess.TimeoutExpired:
         p.kill()
         p.communicate()
-        return {"error": f"timed out after {timeout:.0f} s (a collective did not complete); headline unaffected"}
+        return {"error": f"timed out after {timeout:.0f} s (a collective did not complete); headline unaffected", "stderr_tail": err_tail()}
     if rank != 0:
         return None
     for line in reversed(stdout.decode(errors="replace").strip().splitlines()):
@@ -480,58 +730,47 @@ def k20_in_children(rank):
                 return json.loads(line)
             except ValueError:
                 break
-    return {"error": f"child exited with code {p.returncode} and no result; headline unaffected"}
+    return {"error": f"child exited with code {p.returncode} and no result; headline unaffected", "stderr_tail": err_tail()}
 
 
 def k20_child_main():
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    D = Dist()
     import torch
-    import torch.distributed as dist
 
-    torch.cuda.set_device(local_rank)
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    D.init()
     from sha2_on_cq_halo2_amd import Context
 
-    stream = torch.cuda.Stream(device=local_rank)
-    ctx = Context(local_rank, stream.cuda_stream)
+    stream = torch.cuda.Stream(device=D.device_index)
+    ctx = Context(D.device_index, stream.cuda_stream)
     try:
-        res = config3_k20(ctx, rank, world, local_rank)
+        res = config3_k20(ctx, D)
     except Exception as e:  # noqa: BLE001
         res = {"error": f"{type(e).__name__}: {e}"}
-    if rank == 0:
+    if D.rank == 0:
         print(json.dumps(res), flush=True)
     sys.stdout.flush()
     os._exit(0)  # no teardown of communicators whose peers may be gone
 
 
-def config3_k20(ctx, rank, world, local_rank, steps=4, warmup=2):
+def config3_k20(ctx, D, steps=None, warmup=2):
     """BASELINE configs[3]: one k = 20 (256-block) proof, proven by ALL ranks of the job together -- every MSM sharded by
     point range (ncclAllGather of the Jacobian partials), the independent column transforms sharded by owner
     (ncclBroadcast), both issued by the library on device buffers over the context's RCCL communicator.  At N = 1 the
     same proof unsharded: the driver's N = 1, 2, 4, 8 runs give the strong-scaling curve.  `msm_kernel_mscalar_per_s` =
     MSM scalars of the proof / the slowest rank's accumulate-kernel time (the figure the 1 -> 8 MSM-scaling target is
-    about); the end-to-end time is bounded by what stays replicated (multi-GPU)."""
-    import torch
-    import torch.distributed as dist
+    about); the end-to-end time is bounded by what stays replicated (multi-GPU).  CQ_BENCH_K20_K (default 20)
+    lets the tests run the same leg on a smaller circuit."""
+    import hashlib
 
     from sha2_on_cq_halo2_amd.api import PROF_MSM_ACCUMULATE
     from sha2_on_cq_halo2_amd.sha_circuit import ShaCqWorkload
 
-    kk = 20
-    # MSM tables of this workload: 17-bit windows when a rank's point range has 2^20 points (what a fresh context would pick
-    # by itself; this context built the k = 18 tables first and would keep their 15 bits)
-    ctx.set_msm_table_window(17 if (1 << kk) // world >= (1 << 20) else 15)
+    world = D.world
+    kk = int(os.environ.get("CQ_BENCH_K20_K", "20"))
+    steps = steps or int(os.environ.get("CQ_BENCH_K20_STEPS", "4"))
     wl = ShaCqWorkload(ctx, kk, seed=0x5348413243515F)  # the same instance on every rank
-    ctx.set_msm_table_window(0)
-    res = {"k": kk, "blocks": wl.blocks, "n_gpus": world, "scaling": "strong", "steps": steps,
+    res = {"k": kk, "blocks": wl.blocks, "n_gpus": world, "scaling": "strong", "steps": steps, "dist_backend": D.backend if world > 1 else None,
            "msm_scalars_in_gpu_launches": wl.msm_scalars_in_launches()}
-    if world > 1:
-        ctx.comm_init_from_torch(device=torch.device("cuda", local_rank))
-        ctx.comm_selftest()
 
     def run(label):
         for i in range(warmup):
@@ -539,25 +778,16 @@ def config3_k20(ctx, rank, world, local_rank, steps=4, warmup=2):
             wl.prove(seed=10 + i)
         ctx.profile_enable(True)
         ctx.profile_read(PROF_MSM_ACCUMULATE)
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+        D.barrier()
         t0 = time.perf_counter()
         for i in range(steps):
             wl.fill_witness()
             proof = wl.prove(seed=100 + i)
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+        D.barrier()
         dt = time.perf_counter() - t0
         acc_ms, _ = ctx.profile_read(PROF_MSM_ACCUMULATE)
         ctx.profile_enable(False)
-        if world > 1:
-            t = torch.tensor([dt, acc_ms], device=f"cuda:{local_rank}", dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt, acc_ms = float(t[0].item()), float(t[1].item())
-        import hashlib
-
+        dt, acc_ms = D.max_over_ranks([dt, acc_ms])
         res[label] = {"ms_per_proof": dt / steps * 1e3,
                       "msm_mscalar_per_s_wall": wl.msm_scalars_per_proof() * steps / dt / 1e6,
                       "msm_kernel_mscalar_per_s": wl.msm_scalars_in_launches() * steps / (acc_ms / 1e3) / 1e6 if acc_ms > 0 else 0.0,
@@ -567,12 +797,15 @@ def config3_k20(ctx, rank, world, local_rank, steps=4, warmup=2):
     if world == 1:
         run("unsharded")
     else:
-        wl.pk.set_sharding(rank, world, transport="rccl", columns=True)
+        D.shard(ctx, wl.pk, columns=True)
         run("msm_and_columns_sharded")
-        wl.pk.set_sharding(rank, world, transport="rccl", columns=False)
+        D.shard(ctx, wl.pk, columns=False)
         run("msm_sharded_only")
+        D.shard(ctx, wl.pk, columns=True, resident=True)  # columns stay on their owner, slices travel point to point
+        run("resident")
         res["parallelism"] = (f"one proof over {world} ranks: MSM point ranges /{world} (window tables for the rank's slices), "
-                              "column transforms by owner; RCCL all-gather of 96-B partials + grouped broadcasts of columns")
+                              "column transforms by owner (broadcast) or resident on their owner (point-to-point slices); " + ("RCCL all-gather of 96-B partials + grouped broadcasts of columns" if D.transport == "rccl"
+                                                                else "host-callback transport over gloo (one-GPU rehearsal of the N > 1 path)"))
     wl.close()
     return res
 
@@ -608,6 +841,8 @@ def cpu_baseline(ctx):
     the metric's own k = 18 instance once, and the k = 16 instance (BASELINE configs[1]) as `sample_small`; the GPU
     proves the same instances and the proofs are compared byte for byte."""
     from oracle import cbind as OC
+
+    OC.lib(native=True)  # -O3 -march=native, built on this host (BASELINE.md section 3)
 
     def _cpu_prove(ctx, k, threads):
         """(cpu seconds, gpu seconds, proofs identical, workload) for one create_proof of the bench circuit at 2^k rows."""

@@ -59,6 +59,12 @@ typedef int (*cq_allgather_fn)(void* user, const void* send, void* recv, size_t 
  * on the others; returns 0 on success. */
 typedef int (*cq_bcast_fn)(void* user, void* buf, size_t bytes, uint32_t root);
 
+/* Point-to-point hook for resident column sharding (cq_pk_set_resident_sharding): `count` transfers of HOST buffers
+ * between this rank and `peer`, `send` != 0 for outgoing ones.  Every rank is called with its part of one global list, in
+ * the same relative order, so the k-th send from a to b meets the k-th receive of b from a.  Returns 0 on success. */
+typedef struct { uint32_t peer; uint32_t send; void* buf; size_t bytes; } cq_xfer;
+typedef int (*cq_exchange_fn)(void* user, const cq_xfer* xfers, size_t count);
+
 /* ---- context ------------------------------------------------------------------------- */
 /* `hip_stream` may be NULL (the library creates its own stream) or an existing hipStream_t
  * (e.g. torch.cuda.current_stream().cuda_stream) that all work is then enqueued on. */
@@ -370,6 +376,17 @@ int cq_pk_set_sharding(cq_pk* pk, uint32_t rank, uint32_t world, cq_allgather_fn
  * of by every rank.  Transport: RCCL broadcasts on device buffers (`fn` = NULL, needs the context communicator), or the
  * caller's broadcast on host buffers.  `on` = 0 replicates the transforms on every rank. */
 int cq_pk_set_column_sharding(cq_pk* pk, int on, cq_bcast_fn fn, void* user);
+/* Resident column sharding: the next step after column sharding for the CQ-shaped circuits of the BASELINE configs (advice
+ * columns + static lookups on plain advice inputs, one phase, GWC): a transformed column STAYS on its owner -- lookup l's f
+ * and b polynomials and their extended cosets on the owner of lookup l, an advice polynomial on the owner of its column --
+ * and only what another rank consumes travels, by point range: the slices of b_0 each rank commits (static_lookup/prover.rs:
+ * 299,310), the per-owner partial quotients summed slice-wise into the h pieces each rank commits (evaluation.rs:533-548 is
+ * a sum over lookups, extended_to_coeff and commit are linear), partial evaluations (a 32-byte sum per query) and the
+ * slices of the GWC batch polynomial, whose kate_division runs per range with a carried Horner value.  Per proof and rank
+ * that is ~(3 + L / world) x 32 B x 2^k / world x (world - 1) received instead of ~(5 L + A) x 32 B x 2^k broadcast.
+ * Same proof bytes.  Transport: grouped ncclSend / ncclRecv on the context's communicator (`fn` = NULL) or the caller's
+ * point-to-point hook on host buffers.  Other circuits keep the column-sharding mode set above. */
+int cq_pk_set_resident_sharding(cq_pk* pk, int on, cq_exchange_fn fn, void* user);
 /* Multi-open scheme of cq_create_proof*: `P: Prover` of create_proof (prover.rs:55).
  * CQ_OPENER_GWC = ProverGWC (poly/kzg/multiopen/gwc/prover.rs:42-91, one witness commitment per distinct
  * point; the default, as in tests/my_test.rs), CQ_OPENER_SHPLONK = ProverSHPLONK

@@ -982,23 +982,36 @@ Context.comm_destroy = _ctx_comm_destroy
 Context.comm_selftest = lambda self: self._chk(self.lib.cq_ctx_comm_selftest(self.h))
 
 
-def _pk_set_sharding(self, rank: int, world: int, group=None, device=None, transport: str = "callback", columns: bool = True):
+class _CqXfer(C.Structure):
+    _fields_ = [("peer", C.c_uint32), ("send", C.c_uint32), ("buf", C.c_void_p), ("bytes", C.c_size_t)]
+
+
+_EXCHANGE_T = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(_CqXfer), C.c_size_t)
+
+
+def _pk_set_sharding(self, rank: int, world: int, group=None, device=None, transport: str = "callback", columns: bool = True,
+                     resident: bool = False):
     """Shards `create_proof` across the ranks of a job (cq_pk_set_sharding + cq_pk_set_column_sharding): every
     commitment by point range (all-gather of the per-rank Jacobian partials) and, with `columns`, the independent column
     transforms by owner (broadcast of the transformed columns).
     transport "rccl": the library's own ncclAllGather / ncclBroadcast on device buffers, on the context's communicator
     (Context.comm_init_rccl / comm_init_from_torch first); "callback": torch.distributed collectives of `group` on host
-    buffers (gloo on CPU tensors; with `device` the tensors travel through that device for the "nccl" backend)."""
+    buffers (gloo on CPU tensors; with `device` the tensors travel through that device for the "nccl" backend).
+    `resident`: cq_pk_set_resident_sharding -- transformed columns stay on their owner and slices travel point to point
+    (ncclSend / ncclRecv, or torch.distributed isend / irecv on host buffers)."""
+    lib = self.ctx.lib
     if world <= 1:
-        # (the column hook first: the library must not keep a pointer to a callback object that is about to be dropped)
-        self.ctx._chk(self.ctx.lib.cq_pk_set_column_sharding(self.h, 1 if columns else 0, None, None))
-        self.ctx._chk(self.ctx.lib.cq_pk_set_sharding(self.h, 0, 1, None, None))
-        self._allgather_cb = self._bcast_cb = None
+        # (the hooks first: the library must not keep a pointer to a callback object that is about to be dropped)
+        self.ctx._chk(lib.cq_pk_set_resident_sharding(self.h, 1 if resident else 0, None, None))
+        self.ctx._chk(lib.cq_pk_set_column_sharding(self.h, 1 if columns else 0, None, None))
+        self.ctx._chk(lib.cq_pk_set_sharding(self.h, 0, 1, None, None))
+        self._allgather_cb = self._bcast_cb = self._exchange_cb = None
         return
     if transport == "rccl":
-        self._allgather_cb = self._bcast_cb = None
-        self.ctx._chk(self.ctx.lib.cq_pk_set_column_sharding(self.h, 1 if columns else 0, None, None))
-        self.ctx._chk(self.ctx.lib.cq_pk_set_sharding(self.h, rank, world, None, None))
+        self._allgather_cb = self._bcast_cb = self._exchange_cb = None
+        self.ctx._chk(lib.cq_pk_set_resident_sharding(self.h, 1 if resident else 0, None, None))
+        self.ctx._chk(lib.cq_pk_set_column_sharding(self.h, 1 if columns else 0, None, None))
+        self.ctx._chk(lib.cq_pk_set_sharding(self.h, rank, world, None, None))
         return
     import torch
     import torch.distributed as dist
@@ -1032,8 +1045,36 @@ def _pk_set_sharding(self, rank: int, world: int, group=None, device=None, trans
         except Exception:
             return -1
 
+    def exchange(_user, xfers, count):
+        try:
+            ops, keep = [], []
+            for i in range(count):
+                x = xfers[i]
+                mem = (C.c_uint8 * x.bytes).from_address(x.buf)
+                t = torch.frombuffer(mem, dtype=torch.uint8)  # shares the library's host buffer
+                peer = dist.get_global_rank(group, x.peer) if group is not None else x.peer
+                if device is not None:
+                    d = t.to(device) if x.send else torch.empty(x.bytes, dtype=torch.uint8, device=device)
+                    keep.append((None if x.send else t, d))
+                    ops.append(dist.P2POp(dist.isend if x.send else dist.irecv, d, peer, group))
+                else:
+                    ops.append(dist.P2POp(dist.isend if x.send else dist.irecv, t, peer, group))
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+            for t, d in keep:
+                if t is not None:
+                    t.copy_(d.cpu())
+            return 0
+        except Exception:
+            import traceback
+
+            traceback.print_exc()
+            return -1
+
     self._allgather_cb = _ALLGATHER_T(allgather)
     self._bcast_cb = _BCAST_T(bcast)
+    self._exchange_cb = _EXCHANGE_T(exchange)
+    self.ctx._chk(self.ctx.lib.cq_pk_set_resident_sharding(self.h, 1 if resident else 0, C.cast(self._exchange_cb, C.c_void_p), None))
     self.ctx._chk(self.ctx.lib.cq_pk_set_column_sharding(self.h, 1 if columns else 0, C.cast(self._bcast_cb, C.c_void_p), None))
     self.ctx._chk(self.ctx.lib.cq_pk_set_sharding(self.h, rank, world, C.cast(self._allgather_cb, C.c_void_p), None))
 

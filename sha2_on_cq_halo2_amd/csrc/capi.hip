@@ -63,6 +63,7 @@ void cq_ctx_destroy(cq_ctx* c) {
   if (c->pinned_small) hipHostFree(c->pinned_small);
   cq::comm_rccl_destroy(c);
   if (c->pinned_comm) hipHostFree(c->pinned_comm);
+  if (c->comm_event) hipEventDestroy(c->comm_event);
   for (auto& g : c->graphs) hipGraphExecDestroy(g.exec);
   if (c->prof_entries) hipHostFree(c->prof_entries);
   if (c->copy_done) hipEventDestroy(c->copy_done);

@@ -785,6 +785,14 @@ int cq_pk_set_column_sharding(cq_pk* pk, int on, cq_bcast_fn fn, void* user) {
   return CQ_OK;
 }
 
+int cq_pk_set_resident_sharding(cq_pk* pk, int on, cq_exchange_fn fn, void* user) {
+  if (!pk) return CQ_ERR_ARG;
+  pk->shard_resident = on != 0;
+  pk->exchange = fn;
+  pk->exchange_user = user;
+  return CQ_OK;
+}
+
 void cq_pk_destroy(cq_pk* pk) {
   if (!pk) return;
   hipStreamSynchronize(pk->ctx->stream);
@@ -851,6 +859,16 @@ static int create_proof_any(cq_pk* pk, const uint64_t* const* advice_dev, const 
   // `overrun` counts the words THIS proof asked for beyond the stream (a caller's struct may hold anything there)
   if (rng == cq_buffer_rng_next_u64) ((cq_buffer_rng*)rng_state)->overrun = 0;
   int rc = create_proof_dev(pk, advice_dev, instances, instance_lens, phase_fn, phase_user, rng, rng_state, out);
+  // A sharded proof that fails on this rank (over RCCL) leaves its peers in, or heading for, a collective this rank will not
+  // join: give up the communicator, so that they fail too (asynchronous error or their wait's time-out) instead of
+  // hanging.  Not for the failures every rank runs into alike, at the same point of the same program, with nothing pending
+  // between them -- a witness value missing from a table, an identity commitment, a bad argument: those just return.
+  const bool rank_local = rc == CQ_ERR_HIP || rc == CQ_ERR_INTERNAL || rc == CQ_ERR_NO_DEVICE;
+  if (rank_local && pk->sharded() && !pk->allgather && c->rccl_comm && !pk->shard_single) {
+    const std::string keep = c->err;
+    cq::comm_rccl_abort(c);
+    c->err = keep + " (sharded proof: this rank's RCCL communicator was aborted so that its peers do not hang)";
+  }
   // An exhausted stream reads as zeros: the proof would not be zero-knowledge, and an all-zero random polynomial also
   // trips the transcript's identity-commitment check -- both are reported as what they are.  Any other error keeps its code.
   if (rng == cq_buffer_rng_next_u64 && ((cq_buffer_rng*)rng_state)->overrun && (rc == CQ_OK || rc == CQ_ERR_TRANSCRIPT))

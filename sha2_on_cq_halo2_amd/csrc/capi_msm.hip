@@ -121,7 +121,7 @@ int msm_multi_begin(cq_ctx* c, const Fr* const* scalars, const G1Affine* const* 
 }
 
 int msm_multi_end(cq_ctx* c, MsmPending& pend, uint64_t* out_jac) {
-  CQ_HIP(c, hipStreamSynchronize(c->stream));
+  if (int wrc = c->wait(c->stream, "msm: waiting for the launch")) return wrc;
   // the host's share of the reduction (msm_set_value: ~33 group operations per bucket set), spread over the context's
   // worker threads when a launch has many sets
   struct Item { const MsmPending::Launch* ln; uint32_t j; };

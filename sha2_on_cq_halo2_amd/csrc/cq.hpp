@@ -160,6 +160,10 @@ struct cq_pk {
   bool shard_columns = true;
   cq_bcast_fn bcast = nullptr;
   void* bcast_user = nullptr;
+  // resident column sharding (cq_pk_set_resident_sharding): columns stay on their owner, slices travel point to point
+  bool shard_resident = false;
+  cq_exchange_fn exchange = nullptr;  // host-buffer transport for it (nullptr: ncclSend / ncclRecv)
+  void* exchange_user = nullptr;
   // MSM window tables: the width this key's launches use (its SRS length decides; small arrays shared with keys of other
   // sizes get a second table of this width), the registry entries the key holds a reference of, and -- when sharded --
   // the tables of the rank's slices (capi_cq.hip: pk_shard_tables)

@@ -10,6 +10,10 @@
 #include "ntt.hpp"
 #include "hostpool.hpp"
 
+namespace cq {
+int comm_rccl_wait(cq_ctx* c, hipStream_t stream, const char* what);  // comm.hip
+}
+
 struct cq_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -75,6 +79,15 @@ struct cq_ctx {
   }
   void prof_end(hipEvent_t b) {
     if (b) hipEventRecord(b, stream);
+  }
+
+  // Host wait for `s` inside a proof: plain hipStreamSynchronize -- unless the context holds an RCCL communicator, whose
+  // collectives may be anywhere in the queue: then the wait has a time-out and watches the communicator (comm.hip), so that
+  // a rank whose peer failed returns an error instead of sitting in the driver for ever.
+  int wait(hipStream_t s, const char* what = "stream wait") {
+    if (rccl_comm) return cq::comm_rccl_wait(this, s, what);
+    const hipError_t e = hipStreamSynchronize(s);
+    return e == hipSuccess ? CQ_OK : hip_fail(e, what);
   }
 
   int fail(int code, const std::string& msg) {
@@ -226,6 +239,8 @@ struct cq_ctx {
   // RCCL communicator of the context (comm.hip; cq_ctx_comm_init_rccl) and the pinned staging of its small exchanges
   void* rccl_comm = nullptr;
   uint32_t rccl_rank = 0, rccl_world = 1;
+  bool rccl_aborted = false;        // the communicator was given up after a failure (comm_rccl_abort)
+  hipEvent_t comm_event = nullptr;  // polled by comm_rccl_wait
   void* pinned_comm = nullptr;
   size_t pinned_comm_bytes = 0;
   int ensure_pinned_comm(size_t bytes, void** out) {

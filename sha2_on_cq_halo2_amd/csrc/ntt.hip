@@ -278,6 +278,205 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(NttPassArgs a) {
   }
 }
 
+// ---- the same pass, software-pipelined over several tiles per workgroup -------------------------------------------------
+// The kernel above runs one tile per workgroup: load (HBM-bound), butterflies (VALU-bound), store (products + HBM), and the
+// four workgroups of a CU start in step, so a pass costs the SUM of its memory and arithmetic phases (25 + 53 us per pass of
+// a 2^18 x 8 batch).  Here a workgroup is persistent: it walks tiles blockIdx.x, blockIdx.x + gridDim.x, ... and holds the
+// NEXT tile's elements in registers (PER x 32 B per thread, issued right after the current tile has been written to LDS)
+// while it runs the current tile's butterflies and store.  What makes that work:
+//   * barriers are raw `s_barrier`s that wait for LDS traffic only (lgkmcnt): `__syncthreads()` also waits vmcnt(0), which
+//     would drain the prefetch at the first butterfly level and make the stores of a tile synchronous;
+//   * the per-pass constants (roots, load / store factors) go to LDS once per workgroup, not once per tile.
+// Same arithmetic, same element order, bit-identical output.
+#define CQ_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+template <uint32_t DEG, uint32_t LOG_T>
+#ifndef CQ_NTT_PIPE_WAVES
+#define CQ_NTT_PIPE_WAVES 0  // 4: cap the kernel at 128 registers (four waves per SIMD), at the price of spills
+#endif
+#ifndef CQ_NTT_PIPE_LATE
+#define CQ_NTT_PIPE_LATE 0   // 1: issue the next tile's loads before the store phase instead of before the butterflies
+#endif
+#if CQ_NTT_PIPE_WAVES
+#define CQ_NTT_PIPE_ATTR __attribute__((amdgpu_waves_per_eu(CQ_NTT_PIPE_WAVES, CQ_NTT_PIPE_WAVES)))
+#else
+#define CQ_NTT_PIPE_ATTR
+#endif
+__global__ __launch_bounds__(NTT_THREADS) CQ_NTT_PIPE_ATTR void ntt_pass_pipe_kernel(NttPassArgs a, uint32_t tiles_per_col, uint32_t total_tiles) {
+  extern __shared__ uint32_t smem29[];
+  constexpr uint32_t D = 1u << DEG, T = 1u << LOG_T, E = D * T, PER = E / NTT_THREADS, half = D >> 1;
+  static_assert(E % NTT_THREADS == 0 && PER >= 1 && PER <= 8, "tile elements per thread");
+  uint32_t* const tw29 = smem29 + 9 * E;
+  uint32_t* const cl29 = tw29 + 9 * (D / 2 + 1);
+  uint32_t* const cs29 = cl29 + 27;
+  const uint32_t n = 1u << a.log_n;
+  const uint32_t t = n >> DEG;
+  const uint32_t p = 1u << a.lgp;
+  const bool first = a.lgp == 0, last = a.next_deg == 0;
+  const bool load_mul = first && (a.flags & NTT_IN_COSET);
+
+  // ---- once per workgroup: constants and roots ----
+  if (load_mul && threadIdx.x < 3) {
+    Fr29 cl = const29(CONSTS29<FrP>.from256);
+    if (threadIdx.x) cl = Fr29::mul(Fr29::unpack(a.in_coset[threadIdx.x - 1].v.l), const29(CONSTS29<FrP>.c271));
+    CQ_UNROLL for (int l = 0; l < 9; l++) cl29[threadIdx.x * 9 + l] = cl.a[l];
+  }
+  if (last && threadIdx.x >= 64 && threadIdx.x < 67) {
+    const uint32_t m = threadIdx.x - 64;
+    const Fr one = Fr::one();
+    const uint32_t* src = (a.flags & NTT_OUT_MUL) ? ((a.flags & NTT_OUT_COSET) ? a.out_mul[m].v.l : a.out_mul[0].v.l) : one.v.l;
+    const Fr29 cm = Fr29::unpack(src);
+    CQ_UNROLL for (int l = 0; l < 9; l++) cs29[m * 9 + l] = cm.a[l];
+  }
+  for (uint32_t j = threadIdx.x; j < half; j += NTT_THREADS) {
+    const Fr29 w = g_load29(a.pq + ((size_t)j << a.pq_shift));
+    CQ_UNROLL for (int l = 0; l < 9; l++) tw29[l * half + j] = w.a[l];
+  }
+
+  // the next tile's elements, packed as they are in memory (zero where the input is shorter than the transform)
+  uint4 pre[PER][2];
+  auto issue = [&](uint32_t tile_id) {
+    const uint32_t batch = tile_id / tiles_per_col, index0 = (tile_id - batch * tiles_per_col) * T;
+    const Fr* in = a.in + (size_t)batch * a.in_stride;
+    CQ_UNROLL for (uint32_t q = 0; q < PER; q++) {
+      const uint32_t e = threadIdx.x + q * NTT_THREADS;
+      const uint32_t g = index0 + (e & (T - 1)) + (e >> LOG_T) * t;
+      if (g < a.in_len) {
+        const uint4* src = reinterpret_cast<const uint4*>(in + g);
+        pre[q][0] = src[0];
+        pre[q][1] = src[1];
+      } else {
+        pre[q][0] = make_uint4(0, 0, 0, 0);
+        pre[q][1] = make_uint4(0, 0, 0, 0);
+      }
+    }
+  };
+  uint32_t tile_id = blockIdx.x;
+  if (tile_id < total_tiles) issue(tile_id);
+  CQ_LDS_BARRIER();  // constants and roots in place
+
+  for (; tile_id < total_tiles; tile_id += gridDim.x) {
+    const uint32_t batch = tile_id / tiles_per_col, index0 = (tile_id - batch * tiles_per_col) * T;
+    Fr* out = a.out + (size_t)batch * a.out_stride;
+    // ---- registers -> LDS limb planes (the first pass of a coset transform converts and shifts here) ----
+    CQ_UNROLL for (uint32_t q = 0; q < PER; q++) {
+      const uint32_t e = threadIdx.x + q * NTT_THREADS;
+      const uint32_t w8[8] = {pre[q][0].x, pre[q][0].y, pre[q][0].z, pre[q][0].w, pre[q][1].x, pre[q][1].y, pre[q][1].z, pre[q][1].w};
+      Fr29 x = Fr29::unpack(w8);
+      if (load_mul) {
+        const uint32_t g = index0 + (e & (T - 1)) + (e >> LOG_T) * t;
+        if (g < a.in_len) x = Fr29::mul(x, lds_load29(cl29 + (g % 3) * 9, 1, 0));
+      }
+      lds_store29(smem29, E, e, x);  // row e >> LOG_T, column e & (T - 1)
+    }
+    CQ_LDS_BARRIER();
+#if !CQ_NTT_PIPE_LATE
+    {
+      const uint32_t next = tile_id + gridDim.x;  // in flight through the butterflies and the store of this tile
+      if (next < total_tiles) issue(next);
+    }
+#endif
+
+    // ---- 2^DEG-point DIF in LDS (as in ntt_pass_kernel) ----
+    constexpr uint32_t R4 = DEG / 2;
+#pragma unroll
+    for (uint32_t st = 0; st < R4; st++) {
+      const uint32_t rnd = 2 * st;
+      const uint32_t bit = half >> rnd;
+      const uint32_t hb = bit >> 1;
+      for (uint32_t w = threadIdx.x; w < (half >> 1) * T; w += NTT_THREADS) {
+        const uint32_t c = w & (T - 1);
+        const uint32_t wg = w >> LOG_T;
+        const uint32_t dj = wg >> rnd;
+        const uint32_t r0 = (((wg & ((1u << rnd) - 1u)) * bit) << 1) + dj;
+        const uint32_t o0 = r0 * T + c, o1 = o0 + hb * T, o2 = o0 + bit * T, o3 = o2 + hb * T;
+        const Fr29 x0 = lds_load29(smem29, E, o0), x1 = lds_load29(smem29, E, o1);
+        const Fr29 x2 = lds_load29(smem29, E, o2), x3 = lds_load29(smem29, E, o3);
+        const Fr29 s02 = x0 + x2, s13 = x1 + x3;
+        Fr29 d02 = sub_level(x0, x2, rnd);
+        if (dj) d02 = Fr29::mul(d02, lds_load29(tw29, half, dj << rnd));
+        const Fr29 d13 = Fr29::mul(sub_level(x1, x3, rnd), lds_load29(tw29, half, (dj + hb) << rnd));
+        Fr29 y0 = s02 + s13;
+        y0.normalise();
+        Fr29 y1 = sub_level(s02, s13, rnd + 1);
+        Fr29 y2 = d02 + d13;
+        y2.normalise();
+        Fr29 y3 = sub_level(d02, d13, rnd + 1);
+        if (dj) {
+          const Fr29 w2 = lds_load29(tw29, half, dj << (rnd + 1));
+          y1 = Fr29::mul(y1, w2);
+          y3 = Fr29::mul(y3, w2);
+        }
+        lds_store29(smem29, E, o0, y0);
+        lds_store29(smem29, E, o1, y1);
+        lds_store29(smem29, E, o2, y2);
+        lds_store29(smem29, E, o3, y3);
+      }
+      CQ_LDS_BARRIER();
+    }
+    if (DEG & 1) {  // odd DEG: the last level on its own
+      constexpr uint32_t rnd = DEG - 1;
+      const uint32_t bit = half >> rnd;
+      for (uint32_t w = threadIdx.x; w < half * T; w += NTT_THREADS) {
+        const uint32_t c = w & (T - 1);
+        const uint32_t wb = w >> LOG_T;
+        const uint32_t di = wb >> rnd;
+        const uint32_t b = ((wb & ((1u << rnd) - 1u)) * bit) | di;
+        const uint32_t i0 = (b << 1) - di;
+        const uint32_t i1 = i0 + bit;
+        const Fr29 u = lds_load29(smem29, E, i0 * T + c);
+        const Fr29 v = lds_load29(smem29, E, i1 * T + c);
+        Fr29 sm = u + v;
+        sm.normalise();
+        Fr29 d = sub_level(u, v, rnd);
+        if (di) d = Fr29::mul(d, lds_load29(tw29, half, di << rnd));
+        lds_store29(smem29, E, i0 * T + c, sm);
+        lds_store29(smem29, E, i1 * T + c, d);
+      }
+      CQ_LDS_BARRIER();
+    }
+
+#if CQ_NTT_PIPE_LATE
+    {
+      const uint32_t next = tile_id + gridDim.x;  // in flight through the store of this tile only (fewer live registers)
+      if (next < total_tiles) issue(next);
+    }
+#endif
+    // ---- store (as in ntt_pass_kernel) ----
+    const uint32_t lgp2 = a.lgp + DEG;
+    const uint32_t log_t2 = a.log_n - a.next_deg;
+    CQ_UNROLL for (uint32_t q = 0; q < PER; q++) {
+      const uint32_t e = threadIdx.x + q * NTT_THREADS;
+      const uint32_t c = e & (T - 1);
+      const uint32_t i = e >> LOG_T;
+      const uint32_t index = index0 + c;
+      const uint32_t k = index & (p - 1);
+      const uint32_t g = ((index - k) << DEG) + k + i * p;
+      if (g >= a.out_len) continue;
+      const Fr29 x = lds_load29(smem29, E, bitrev(i, DEG) * T + c);
+      if (last) {
+        const uint32_t m = (a.flags & NTT_OUT_COSET) ? g % 3 : 0;
+        g_store29(out + g, Fr29::mul(x, lds_load29(cs29 + m * 9, 1, 0)), true);
+        continue;
+      }
+      const uint32_t i2 = g >> log_t2, index2 = g & ((1u << log_t2) - 1);
+      const uint32_t ex = ((n >> lgp2) >> a.next_deg) * (index2 & ((1u << lgp2) - 1)) * i2;
+      Fr29 w;
+      if (!ex) {
+        w = const29(CONSTS29<FrP>.one);
+      } else if (a.tw_full) {
+        w = g_load29(a.tw_full + ex);
+      } else {
+        w = g_load29(a.tw_lo + (ex & ((1u << a.tw_l) - 1)));
+        const uint32_t h = ex >> a.tw_l;
+        if (h) w = canon29(Fr29::mul(w, g_load29(a.tw_hi + h)));
+      }
+      g_store29(out + g, Fr29::mul(x, w), false);
+    }
+    CQ_LDS_BARRIER();  // every read of this tile's LDS image is done (its stores stay in flight)
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 NttTables::~NttTables() {
   if (tw_lo) hipFree(tw_lo);
@@ -368,7 +567,9 @@ int ntt_run(const NttTables& tb, const Fr* in, Fr* out, Fr* scratch, const NttIo
     a.next_deg = last ? 0 : degs[ps + 1];
     const uint32_t t = n >> degs[ps];
     uint32_t log_t = 0;
-    while ((1u << (log_t + 1)) <= t && ((1u << (log_t + 1)) << degs[ps]) <= NTT_TILE_ELEMS) log_t++;
+    // (CQ_NTT_PIPE_TILE=512: half-size tiles for the pipelined kernel -- twice the tiles per persistent workgroup; A/B knob)
+    static const uint32_t tile_elems = (getenv("CQ_NTT_PIPE_TILE") && atoi(getenv("CQ_NTT_PIPE_TILE")) == 512 && NTT_TILE_ELEMS == 1024) ? 512u : NTT_TILE_ELEMS;
+    while ((1u << (log_t + 1)) <= t && ((1u << (log_t + 1)) << degs[ps]) <= tile_elems) log_t++;
     a.log_t = log_t;
     a.tw_lo = tb.tw_lo;
     a.tw_hi = tb.tw_hi;
@@ -408,7 +609,28 @@ int ntt_run(const NttTables& tb, const Fr* in, Fr* out, Fr* scratch, const NttIo
     // templated shapes: full tiles (2^LT elements) of 6-, 5- and 4-bit passes
     constexpr uint32_t LT = NTT_TILE_ELEMS == 512 ? 9 : NTT_TILE_ELEMS == 2048 ? 11 : 10;
     static_assert(NTT_TILE_ELEMS == (1u << LT), "NTT_TILE_ELEMS: 512, 1024 or 2048");
-    if (degs[ps] == 6 && log_t == LT - 6) ntt_pass_kernel<6, LT - 6><<<grid, NTT_THREADS, lds, stream>>>(a);
+    // CQ_NTT_PIPE=1: the pipelined kernel on a persistent grid for full tiles of the templated shapes.  OFF by default:
+    // measured on MI355X (tools/ab_ntt_pipe.sh, gpurun_out/r3d/ab_ntt.log) it is SLOWER than the plain kernel -- 2^18 x 8:
+    // 8.2-8.4 against 8.75 Gelem/s, 2^20 x 8: 7.3 against 7.6 -- because the 32 registers of the prefetch take the kernel
+    // from 95 to 138 VGPRs, i.e. from four to three waves per SIMD, and the LDS round trips of the butterflies need the
+    // waves more than the loads need hiding; capped at 128 registers it spills (7.6), with the loads issued only before
+    // the store phase 8.2-8.3, with half-size tiles 7.0.  Kept for the record and for A/B on other shapes.
+    static const bool pipe = getenv("CQ_NTT_PIPE") && getenv("CQ_NTT_PIPE")[0] == '1';
+    static const uint32_t resident = []() {
+      int dev = 0, cus = 256;
+      if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+      const char* e = getenv("CQ_NTT_PIPE_WG_PER_CU");
+      return (uint32_t)cus * (uint32_t)(e ? atoi(e) : 4);
+    }();
+    const uint32_t tiles_per_col = t / T, total_tiles = tiles_per_col * io.batch;
+    const uint32_t pgrid = total_tiles < resident ? total_tiles : resident;
+    if (pipe && tile_elems == 512 && degs[ps] == 6 && log_t == 3) ntt_pass_pipe_kernel<6, 3><<<pgrid, NTT_THREADS, lds, stream>>>(a, tiles_per_col, total_tiles);
+    else if (pipe && tile_elems == 512 && degs[ps] == 5 && log_t == 4) ntt_pass_pipe_kernel<5, 4><<<pgrid, NTT_THREADS, lds, stream>>>(a, tiles_per_col, total_tiles);
+    else if (pipe && tile_elems == 512 && degs[ps] == 4 && log_t == 5) ntt_pass_pipe_kernel<4, 5><<<pgrid, NTT_THREADS, lds, stream>>>(a, tiles_per_col, total_tiles);
+    else if (pipe && degs[ps] == 6 && log_t == LT - 6) ntt_pass_pipe_kernel<6, LT - 6><<<pgrid, NTT_THREADS, lds, stream>>>(a, tiles_per_col, total_tiles);
+    else if (pipe && degs[ps] == 5 && log_t == LT - 5) ntt_pass_pipe_kernel<5, LT - 5><<<pgrid, NTT_THREADS, lds, stream>>>(a, tiles_per_col, total_tiles);
+    else if (pipe && degs[ps] == 4 && log_t == LT - 4) ntt_pass_pipe_kernel<4, LT - 4><<<pgrid, NTT_THREADS, lds, stream>>>(a, tiles_per_col, total_tiles);
+    else if (degs[ps] == 6 && log_t == LT - 6) ntt_pass_kernel<6, LT - 6><<<grid, NTT_THREADS, lds, stream>>>(a);
     else if (degs[ps] == 5 && log_t == LT - 5) ntt_pass_kernel<5, LT - 5><<<grid, NTT_THREADS, lds, stream>>>(a);
     else if (degs[ps] == 4 && log_t == LT - 4) ntt_pass_kernel<4, LT - 4><<<grid, NTT_THREADS, lds, stream>>>(a);
     else ntt_pass_kernel<0, 0><<<grid, NTT_THREADS, lds, stream>>>(a);

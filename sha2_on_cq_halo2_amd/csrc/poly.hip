@@ -212,6 +212,7 @@ __global__ __launch_bounds__(256) void cq_quotient_kernel(CqQuotientArgs args, u
     const Fr b = ld(args.b[l] + i), f = ld(args.f[l] + i);
     acc = acc * args.y + (b * (f * la + args.beta) - one);
   }
+  if (args.has_scale) acc = acc * args.scale;
   if (args.t_len) acc = acc * ld(args.t_evals + (i & (args.t_len - 1)));  // t_len = 0: evaluate_h alone, no division
   st(h + i, acc);
 }
@@ -294,7 +295,7 @@ int poly_eval_batch(cq_ctx* c, const Fr* const* p, const uint32_t* len, uint32_t
   static_assert(4096 + EVAL_MAX_BATCH * sizeof(Fr) <= cq_ctx::PINNED_SMALL_BYTES, "pinned page layout");
   if (hipMemcpyAsync(stage, level_in, (size_t)count * sizeof(Fr), hipMemcpyDeviceToHost, c->stream) != hipSuccess)
     return c->fail(CQ_ERR_HIP, "eval: D2H failed");
-  if (hipStreamSynchronize(c->stream) != hipSuccess) return c->fail(CQ_ERR_HIP, "eval: sync failed");
+  if (int wrc = c->wait(c->stream, "eval: sync failed")) return wrc;
   memcpy(out_host, stage, (size_t)count * sizeof(Fr));
   // empty polynomials evaluate to zero (their blocks wrote zero already)
   return CQ_OK;

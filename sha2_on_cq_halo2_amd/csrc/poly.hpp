@@ -42,6 +42,10 @@ struct CqQuotientArgs {
   const Fr* t_evals;
   uint32_t t_len;
   Fr y, beta;
+  // resident sharding: this rank folds a contiguous range of the lookups only; its Horner value is then multiplied by
+  // `scale` = y^(lookups after the range), so that the ranks' results add up to the whole sum (has_scale = 0: no factor)
+  Fr scale;
+  uint32_t has_scale = 0;
 };
 
 int poly_eval(cq_ctx* c, const Fr* a_dev, uint32_t n, const Fr& z, Fr* out_host);

@@ -459,9 +459,64 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, const uint64_
     if (trace_host) fprintf(stderr, "[cq host] %8.1f us  %s\n", std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_start).count(), what);
   };
 
-  // ---- carve the arena --------------------------------------------------------------------------
-  void* arena_v;
-  CQ_TRY(c->ensure_scratch(6, prover_arena_elems(pk) * sizeof(Fr), &arena_v));
+  // Resident column sharding (cq_pk_set_resident_sharding; DESIGN.md, multi-GPU): for the CQ-shaped circuits of the
+  // BASELINE configs -- advice columns, static lookups on plain advice inputs, one phase, ProverGWC -- a transformed
+  // column stays on its owner and only slices travel.  Ownership: contiguous ranges (shard_range) of the lookups and of
+  // the advice columns; consumers by point range, as the MSMs are cut.  Marked "resident:" below where the proof
+  // departs from the replicated flow; every rank still derives the same transcript.
+  bool resident = shard_resident_enabled(pk) && !general && PL == 0 && pk->num_phases == 1 && pk->challenge_phase.empty() && I == 0 &&
+                  L > 0 && pk->opener == CQ_OPENER_GWC && n >= (size_t)64 * pk->shard_world;
+  for (size_t l = 0; l < L && resident; l++)
+    for (int64_t pj : pk->lookups[l].prog) resident = resident && pj < 0;
+  const uint32_t SW = pk->shard_world, me = pk->shard_rank;
+  size_t lk_lo = 0, lk_hi = L, adv_lo = 0, adv_hi = A;  // the lookups / advice columns this rank owns
+  if (resident) {
+    shard_range(L, me, SW, lk_lo, lk_hi);
+    shard_range(A, me, SW, adv_lo, adv_hi);
+  }
+  auto owner_of = [&](size_t item, size_t count) -> uint32_t {
+    for (uint32_t r = 0; r < SW; r++) {
+      size_t lo, hi;
+      shard_range(count, r, SW, lo, hi);
+      if (item >= lo && item < hi) return r;
+    }
+    return 0;
+  };
+  const size_t lk_cnt = lk_hi - lk_lo;
+
+  // ---- set-up that can fail on this rank alone (allocations: arena, pinned staging, streams, twiddle tables) comes first,
+  //      and a sharded proof agrees on its outcome before anything else is exchanged: a rank that cannot start says so in
+  //      a one-word all-gather and every rank returns an error, instead of the others waiting in the first collective of a
+  //      proof one of them never joins.  (A failure later on one rank alone -- the MSM workspace, a HIP error -- aborts that
+  //      rank's communicator, and its peers' waits time out: capi_cq.hip, comm.hip.)
+  void *arena_v = nullptr, *small_v = nullptr, *pin = nullptr, *res_stage_v = nullptr;
+  // resident: staging for the slices a rank receives -- per exchange at most one slice from every rank (or every owner
+  // and piece), plus the rank's own range of the opening's batch polynomial with its two edge elements
+  const size_t res_slice_max = (n + pk->shard_world - 1) / pk->shard_world + 1;
+  const size_t res_stage_elems = (size_t)pk->shard_world * res_slice_max * (pk->cs_degree > 2 ? pk->cs_degree - 1 : 1) + res_slice_max + 64;
+  {
+    auto setup = [&]() -> int {
+      CQ_TRY(c->ensure_scratch(6, prover_arena_elems(pk) * sizeof(Fr), &arena_v));
+      CQ_TRY(c->ensure_pinned_small(&small_v));
+      CQ_TRY(c->ensure_pinned((size_t)64 * n + A * (n - u) * sizeof(Fr) + 64, &pin));
+      CQ_TRY(c->ensure_aux_stream());
+      CQ_TRY(c->ensure_copy_stream());
+      if (resident) CQ_TRY(c->ensure_scratch(7, res_stage_elems * sizeof(Fr), &res_stage_v));  // where received slices land
+      int trc = CQ_OK;
+      if (!c->tables_for(dom->k, dom->omega_inv, &trc) || !c->tables_for(dom->extended_k, dom->extended_omega, &trc)) return trc;
+      return CQ_OK;
+    };
+    const int setup_rc = getenv("CQ_TEST_FAIL_SETUP") && atoi(getenv("CQ_TEST_FAIL_SETUP")) == (int)pk->shard_rank + 1
+                             ? c->fail(CQ_ERR_HIP, "set-up failure injected by CQ_TEST_FAIL_SETUP") : setup();
+    if (pk->sharded()) {
+      bool any = false;
+      const std::string mine = c->err;
+      CQ_TRY(shard_any(pk, setup_rc != CQ_OK, any));
+      if (any) return setup_rc != CQ_OK ? c->fail(setup_rc, mine) : c->fail(CQ_ERR_INTERNAL, "sharded proof: another rank could not set up its proof (allocation failure there)");
+    } else if (setup_rc != CQ_OK) {
+      return setup_rc;
+    }
+  }
   Arena ar{(Fr*)arena_v};
   Buffers B;
   carve(pk, ar, B);
@@ -497,15 +552,10 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, const uint64_
   auto lagrange_to_coeff_cols = [&](const Fr* in, Fr* out, size_t batch) { return sharded_transform(false, in, out, (uint32_t)batch); };
   auto coeff_to_extended_cols = [&](const Fr* in, Fr* out, size_t batch) { return sharded_transform(true, in, out, (uint32_t)batch); };
 
-  // side stream: drain whatever an aborted proof may have left there; its NTTs must find their twiddle tables built
-  CQ_TRY(c->ensure_aux_stream());
+  // side stream: drain whatever an aborted proof may have left there (its NTTs find their twiddle tables built: set-up above)
   if (c->aux_pending) {
     CQ_HIP(c, hipStreamSynchronize(c->aux_stream));
     c->aux_pending = false;
-  }
-  {
-    int trc = CQ_OK;
-    if (!c->tables_for(dom->k, dom->omega_inv, &trc) || !c->tables_for(dom->extended_k, dom->extended_omega, &trc)) return trc;
   }
 
   // prover.rs:85 -- vk.hash_into(transcript)
@@ -594,8 +644,6 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, const uint64_
   //      not a linear combination of advice columns).  The points are WRITTEN where the reference writes them.
   uint32_t *m_counts_ = B.m_counts, *err_dev_ = B.err_dev;
   std::vector<std::array<const Fr*, CQ_MAX_WIDTH>> lk_input(L);
-  void* small_v;
-  CQ_TRY(c->ensure_pinned_small(&small_v));
   volatile uint32_t* herr = (volatile uint32_t*)small_v;             // lookup error flag
   Fr* small_fr = (Fr*)((char*)small_v + 64);                         // scalars read back (b(0), z values)
   auto count_multiplicities = [&]() -> int {
@@ -672,7 +720,7 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, const uint64_
       // the caller computes this phase's witness from the challenges of the earlier phases
       std::vector<uint64_t> ch(4 * std::max<size_t>(NC, 1), 0);
       for (size_t i = 0; i < NC; i++) user_challenges[i].to_limbs64(ch.data() + 4 * i);
-      CQ_HIP(c, hipStreamSynchronize(s));
+      CQ_TRY(c->wait(s));
       if (!phase_fn || phase_fn(phase_user, phase, ch.data(), (uint64_t* const*)advice_dev) != 0)
         return c->fail(CQ_ERR_ARG, "create_proof: the phase callback failed");
     }
@@ -683,10 +731,8 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, const uint64_
     for (size_t j = 0; j < AC; j++) (void)rng.fr();
     // pinned staging: [0, 64 n) the random polynomial's words (filled by the helper thread from the last phase on),
     // behind it this phase's blinding rows -- no part is reused within a proof, so nothing waits for a copy to finish
-    void* pin;
-    CQ_TRY(c->ensure_pinned((size_t)64 * n + A * (n - u) * sizeof(Fr) + 64, &pin));
     Fr* pin_tails = (Fr*)((char*)pin + (size_t)64 * n);
-    if (phase > 0) CQ_HIP(c, hipStreamSynchronize(s));  // the previous phase's upload out of the same bytes has been consumed
+    if (phase > 0) CQ_TRY(c->wait(s));  // the previous phase's upload out of the same bytes has been consumed
     memcpy(pin_tails, tails.data(), tails.size() * sizeof(Fr));
     if (AC) CQ_HIP(c, hipMemcpyAsync(B.tails, pin_tails, tails.size() * sizeof(Fr), hipMemcpyHostToDevice, s));
     for (size_t off = 0; off < AC; off += ADVICE_FILL_MAX) {  // rows [0, u) from the caller's columns, [u, n) the blinding rows
@@ -731,7 +777,6 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, const uint64_
       (void)rng.fr();
     }
     // the random polynomial's words: drawn and uploaded by the helper thread from here on (see RandomPolyDrawer)
-    CQ_TRY(c->ensure_copy_stream());
     drawer.start(c, &rng, (uint64_t*)pin, rng_dev, 8 * n);
     }
     // batch_normalize (:363-366), write (:370-374)
@@ -747,7 +792,7 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, const uint64_
       if (early_m)
         for (size_t l = 0; l < L; l++) m_commitments[l] = pts[AC + l];
     } else {
-      CQ_HIP(c, hipStreamSynchronize(s));
+      CQ_TRY(c->wait(s));
     }
     for (size_t i = 0; i < NC; i++)  // :383-389
       if (pk->challenge_phase[i] == phase) user_challenges[i] = tr.squeeze();
@@ -795,7 +840,7 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, const uint64_
       CQ_TRY(fr_from_canonical(c, stage + 2 * slot, u, plk_buf(l, 3)));
       CQ_HIP(c, hipMemcpyAsync(plk_buf(l, 2) + u, plk_tails.data() + l * 2 * (bf + 1), (bf + 1) * sizeof(Fr), hipMemcpyHostToDevice, s));
       CQ_HIP(c, hipMemcpyAsync(plk_buf(l, 3) + u, plk_tails.data() + l * 2 * (bf + 1) + (bf + 1), (bf + 1) * sizeof(Fr), hipMemcpyHostToDevice, s));
-      CQ_HIP(c, hipStreamSynchronize(s));  // the staging arrays are reused by the next lookup
+      CQ_TRY(c->wait(s));  // the staging arrays are reused by the next lookup
       if (lk_status_host[0] != 0 || lk_status_host[1] != lk_status_host[2])
         return c->fail(CQ_ERR_LOOKUP, "lookup input not in table (Error::ConstraintSystemFailure)");
     }
@@ -805,10 +850,11 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, const uint64_
   bool adv_is_coeff = false;
   if (L && !early_m) {
     CQ_TRY(count_multiplicities());
-    CQ_HIP(c, hipStreamSynchronize(s));
+    CQ_TRY(c->wait(s));
     CQ_TRY(lookup_error());
   }
   for (size_t l = 0; l < L; l++) {
+    if (resident && (l < lk_lo || l >= lk_hi)) continue;  // resident: f_l exists on the owner of lookup l only
     // f = sum_j theta^(w-1-j) * e_j   (:108-116, Horner with the first expression first)
     const uint32_t w = (uint32_t)pk->lookups[l].cols.size();
     LincombArgs la;
@@ -871,6 +917,15 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, const uint64_
       // extended coset (evaluation.rs:533-548 reads it), the instance cosets -- none of them depends on beta / gamma
       AuxFork fork(c);
       CQ_TRY(fork.begin(seq));
+      if (resident) {
+        // resident: the owner transforms its lookups' f and its advice columns; nobody else ever reads them
+        if (lk_cnt) {
+          CQ_TRY(domain_lagrange_to_coeff(dom, f_lag + lk_lo * n, f_coeff + lk_lo * n, (uint32_t)lk_cnt, n, n));
+          CQ_TRY(domain_coeff_to_extended(dom, f_coeff + lk_lo * n, cosets + (L + lk_lo) * ext, (uint32_t)lk_cnt, n, ext));
+        }
+        if (adv_hi > adv_lo) CQ_TRY(domain_lagrange_to_coeff(dom, adv + adv_lo * n, adv + adv_lo * n, (uint32_t)(adv_hi - adv_lo), n, n));
+        adv_is_coeff = true;
+      } else {
       if (L) {
         CQ_TRY(lagrange_to_coeff_cols(f_lag, f_coeff, L));
         CQ_TRY(coeff_to_extended_cols(f_coeff, cosets + L * ext, L));
@@ -881,6 +936,7 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, const uint64_
         // Lagrange values after round 1, and the round-2 inversions leave room for it
         CQ_TRY(lagrange_to_coeff_cols(adv, adv, A));
         adv_is_coeff = true;
+      }
       }
       CQ_TRY(fork.end());
     }
@@ -932,7 +988,7 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, const uint64_
     std::vector<Fr> at_u(S);
     for (size_t st = 0; st < S; st++)
       CQ_HIP(c, hipMemcpyAsync(&at_u[st], B.z + st * n + u, sizeof(Fr), hipMemcpyDeviceToHost, s));
-    CQ_HIP(c, hipStreamSynchronize(s));
+    CQ_TRY(c->wait(s));
     PermScaleArgs sa;
     Fr last_z = Fr::one();
     for (size_t st = 0; st < S; st++) {
@@ -980,9 +1036,13 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, const uint64_
       CQ_TRY(poly_lincomb(c, la, (uint32_t)N, t_comp));
       CQ_TRY(cq_a_denominators(c, t_comp, m_counts + l * N, (uint32_t)N, beta, den + l * N));
       // B_r = f_r + beta, r < u ; beta on the blinding rows (:261-269)
-      CQ_TRY(poly_cq_b_denominators(c, f_lag + l * n, (uint32_t)n, u, beta, bpoly + l * n));
+      if (!resident || (l >= lk_lo && l < lk_hi))  // resident: b_l on the owner of lookup l only
+        CQ_TRY(poly_cq_b_denominators(c, f_lag + l * n, (uint32_t)n, u, beta, bpoly + l * n));
     }
-    if (L) {
+    if (L && resident) {
+      if (lk_cnt) CQ_TRY(poly_batch_invert(c, bpoly + lk_lo * n, (uint32_t)(lk_cnt * n)));
+      CQ_TRY(poly_batch_invert(c, den, (uint32_t)(L * N)));  // the table side is small and stays replicated
+    } else if (L) {
       // all inversions of the round in two launches (one Fermat inversion per lane dominates the latency)
       CQ_TRY(poly_batch_invert(c, bpoly, (uint32_t)(L * n + L * N)));  // bpoly and den are adjacent
     }
@@ -999,7 +1059,30 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, const uint64_
       CQ_TRY(cq_a_values(c, den + l * N, m_counts + l * N, (uint32_t)N, tp, a_val + l * N, a_scaled + woff * N));
       woff += w;
     }
-    if (L) {
+    if (L && resident) {
+      // resident: the owner turns its b_l into coefficients; every rank commits its point range of b_0 = (b - b(0)) / X
+      // (:279, 299, 310: the same coefficients over two base arrays), so slice r of b_l[1..n) goes from the owner to rank r
+      if (lk_cnt) CQ_TRY(domain_lagrange_to_coeff(dom, bpoly + lk_lo * n, bpoly + lk_lo * n, (uint32_t)lk_cnt, n, n));
+      for (size_t l = 0; l < L; l++) small_fr[l] = Fr::zero();
+      if (lk_cnt) {
+        GatherArgs ga;
+        ga.count = (uint32_t)lk_cnt;
+        for (size_t l = lk_lo; l < lk_hi; l++) ga.src[l - lk_lo] = bpoly + l * n;
+        CQ_TRY(poly_gather_scalars(c, ga, B.gather));
+        CQ_HIP(c, hipMemcpyAsync(small_fr + lk_lo, B.gather, lk_cnt * sizeof(Fr), hipMemcpyDeviceToHost, s));  // summed over the ranks below
+      }
+      std::vector<Xfer> xf;
+      for (size_t l = 0; l < L; l++) {
+        const uint32_t own = owner_of(l, L);
+        for (uint32_t r = 0; r < SW; r++) {
+          size_t lo, hi;
+          shard_range(n - 1, r, SW, lo, hi);
+          Fr* p = bpoly + l * n + 1 + lo;
+          if (hi > lo) xf.push_back({p, p, (hi - lo) * sizeof(Fr), own, r});
+        }
+      }
+      CQ_TRY(shard_exchange(pk, xf.data(), xf.size(), s));
+    } else if (L) {
       CQ_TRY(lagrange_to_coeff_cols(bpoly, bpoly, L));  // f: under round 1's launch
       // b(0) of every lookup (for a(0), :318-324): on its way to the host while the round's MSMs run
       GatherArgs ga;
@@ -1059,7 +1142,9 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, const uint64_
         AuxFork fork(c);
         CQ_TRY(fork.begin(seq));
         if (A && !adv_is_coeff) CQ_TRY(lagrange_to_coeff_cols(adv, adv, A));
-        if (L) CQ_TRY(coeff_to_extended_cols(bpoly, cosets, L));
+        if (L && resident) {  // resident: b_l's coset stays with the owner of lookup l (the quotient is folded there)
+          if (lk_cnt) CQ_TRY(domain_coeff_to_extended(dom, bpoly + lk_lo * n, cosets + lk_lo * ext, (uint32_t)lk_cnt, n, ext));
+        } else if (L) CQ_TRY(coeff_to_extended_cols(bpoly, cosets, L));
         if (general && A) CQ_TRY(coeff_to_extended_cols(adv, B.adv_cosets, A));
         CQ_TRY(fork.end());
       }
@@ -1090,6 +1175,7 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, const uint64_
     random_cm = r2[S + PL + 5 * L];
     // a(0) = (n*b(0) - (bf+1)/beta) / N   (:318-324)
     if (L) {  // the copy of b(0) was queued before the launch; r2cm.end() has drained the stream
+      if (resident) CQ_TRY(shard_sum_scalars(pk, small_fr, L));  // resident: every b_l(0) from its owner
       const Fr n_table_inv = Fr::from_u64(N).inv();
       for (size_t l = 0; l < L; l++)
         a_at_zero[l] = (small_fr[l] * Fr::from_u64(n) - Fr::from_u64(bf + 1) * beta_inv) * n_table_inv;
@@ -1196,10 +1282,10 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, const uint64_
     }
     // CQ terms (:533-548), then the division by X^n - 1 (vanishing/prover.rs:84, domain.rs:319-338)
     CqQuotientArgs qa;
-    qa.count = (uint32_t)L;
-    for (size_t l = 0; l < L; l++) {
-      qa.b[l] = cosets + l * ext;
-      qa.f[l] = cosets + (L + l) * ext;
+    qa.count = (uint32_t)(resident ? lk_cnt : L);
+    for (size_t l = 0; l < qa.count; l++) {
+      qa.b[l] = cosets + ((resident ? lk_lo : 0) + l) * ext;
+      qa.f[l] = cosets + (L + (resident ? lk_lo : 0) + l) * ext;
     }
     qa.h_in = general ? h_ext : nullptr;
     qa.l_active = pk->l_active_row;
@@ -1207,11 +1293,48 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, const uint64_
     qa.t_len = (uint32_t)dom->t_evaluations.size();
     qa.y = y;
     qa.beta = beta;
-    CQ_TRY(poly_cq_quotient(c, qa, (uint32_t)ext, h_ext));
+    if (resident) {
+      // resident: the numerator is a sum over lookups (evaluation.rs:533-548 folds them with powers of y), each owner
+      // folds its own range and multiplies by the power of y the lookups after its range contribute
+      qa.scale = y.pow_u64(L - lk_hi);
+      qa.has_scale = 1;
+    }
+    if (!resident || lk_cnt) CQ_TRY(poly_cq_quotient(c, qa, (uint32_t)ext, h_ext));
   }
   // vanishing.construct (vanishing/prover.rs:69-120): coefficients, n-sized pieces, blinds, commitments
   const size_t pieces = dom->quotient_poly_degree;
-  CQ_TRY(domain_extended_to_coeff(dom, h_ext, h_coeff));
+  if (!resident || lk_cnt) CQ_TRY(domain_extended_to_coeff(dom, h_ext, h_coeff));
+  if (resident) {
+    // resident: division by X^n - 1, extended_to_coeff and the commitments are all linear, so each owner transformed its
+    // PARTIAL quotient; rank r now collects slice r of every piece from every owner and adds them up -- it holds the
+    // coefficients of h on its own point range only (which is all its share of the commitments, evaluations and the
+    // opening reads).  Staging: the buffer reserved at set-up.
+    const size_t slice_max = res_slice_max;
+    Fr* const stage = (Fr*)res_stage_v;
+    std::vector<uint32_t> owners;  // ranks that own a lookup
+    for (uint32_t q = 0; q < SW; q++) {
+      size_t lo, hi;
+      shard_range(L, q, SW, lo, hi);
+      if (hi > lo) owners.push_back(q);
+    }
+    if (owners.size() * pieces * slice_max > res_stage_elems) return c->fail(CQ_ERR_INTERNAL, "resident sharding: staging too small");
+    std::vector<Xfer> xf;
+    for (size_t oi = 0; oi < owners.size(); oi++)
+      for (size_t i = 0; i < pieces; i++)
+        for (uint32_t r = 0; r < SW; r++) {
+          size_t lo, hi;
+          shard_range(n, r, SW, lo, hi);
+          if (hi > lo) xf.push_back({h_coeff + i * n + lo, stage + (oi * pieces + i) * slice_max, (hi - lo) * sizeof(Fr), owners[oi], r});
+        }
+    CQ_TRY(shard_exchange(pk, xf.data(), xf.size(), s));
+    size_t lo, hi;
+    shard_range(n, me, SW, lo, hi);
+    for (size_t i = 0; i < pieces && hi > lo; i++) {
+      std::vector<Term> terms;
+      for (size_t oi = 0; oi < owners.size(); oi++) terms.push_back({stage + (oi * pieces + i) * slice_max, (uint32_t)(hi - lo), Fr::one()});
+      CQ_TRY(lincomb_many(c, terms, Fr::zero(), (uint32_t)(hi - lo), h_coeff + i * n + lo));
+    }
+  }
   for (size_t i = 0; i < pieces; i++) (void)rng.fr();  // h_blinds (:95-98)
   {
     std::vector<const Fr*> sc(pieces);
@@ -1269,6 +1392,33 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, const uint64_
   for (auto& q : qs)
     if (std::find(rots.begin(), rots.end(), q.rot) == rots.end()) rots.push_back(q.rot);
   auto point_of = [&](int32_t rot) { return rot >= 0 ? x * dom->omega.pow_u64((uint64_t)rot) : x * dom->omega_inv.pow_u64((uint64_t)(-(int64_t)rot)); };
+  // resident: who holds what -- an advice polynomial on the owner of its column, b_0 / f of a lookup on its owner (whole
+  // polynomials, evaluated there), the h pieces and the random polynomial on every rank by point range (each rank
+  // evaluates its range and multiplies by x^lo).  qowner[i] = owning rank, or -1 for "by point range".
+  std::vector<int> qowner(qs.size(), -1);
+  size_t my_lo = 0, my_hi = n;  // this rank's point range of a length-n vector
+  if (resident) {
+    shard_range(n, me, SW, my_lo, my_hi);
+    for (size_t j = 0; j < q_advice.size(); j++) qowner[q_advice[j]] = (int)owner_of(pk->advice_queries[j].first, A);
+    for (size_t l = 0; l < L; l++) qowner[q_b0[l]] = qowner[q_f[l]] = (int)owner_of(l, L);
+    std::vector<const Fr*> ps;
+    std::vector<uint32_t> ls;
+    std::vector<size_t> idx;
+    for (size_t i = 0; i < qs.size(); i++) {
+      if (qowner[i] >= 0 && qowner[i] != (int)me) continue;
+      const bool whole = qowner[i] >= 0;
+      if (!whole && my_hi <= my_lo) continue;
+      ps.push_back(whole ? qs[i].p : qs[i].p + my_lo);
+      ls.push_back(whole ? qs[i].len : (uint32_t)(my_hi - my_lo));
+      idx.push_back(i);
+    }
+    std::vector<Fr> ev(ps.size()), contrib(qs.size(), Fr::zero());
+    if (!ps.empty()) CQ_TRY(eval_many(c, ps, ls, x, ev.data()));
+    const Fr x_lo = x.pow_u64(my_lo);
+    for (size_t j = 0; j < idx.size(); j++) contrib[idx[j]] = qowner[idx[j]] >= 0 ? ev[j] : ev[j] * x_lo;
+    CQ_TRY(shard_sum_scalars(pk, contrib.data(), contrib.size()));  // one all-gather: every evaluation is a sum over the ranks
+    for (size_t i = 0; i < qs.size(); i++) qs[i].eval = contrib[i];
+  } else
   for (int32_t rot : rots) {
     std::vector<const Fr*> ps;
     std::vector<uint32_t> ls;
@@ -1495,6 +1645,72 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, const uint64_
       }
       Fr* batch = B.gwc_batch + g * n;
       Fr* wit = B.gwc_wit + g * n;
+      if (resident) {
+        // resident: poly_batch = sum_j v^j p_j is assembled where the p_j live -- whole polynomials on their owner, the
+        // by-range ones on each rank's range -- as a partial sum P_r over all n coefficients; rank r then collects the
+        // slice of every P_q that its share of the witness polynomial needs and adds them up.  kate_division
+        // (q_i = a_(i+1) + z q_(i+1)) runs per range: the carry into a range from above is the Horner value of the
+        // slices above it, S_q = sum_t slice_q[t] z^t, exchanged as one field element per rank.
+        const Fr z = point_of(rots[g]);
+        std::vector<Term> whole, ranged;
+        size_t ti = 0;
+        for (size_t i = 0; i < qs.size(); i++) {
+          if (qs[i].rot != rots[g]) continue;
+          const Term& t = terms[ti++];
+          if (qowner[i] < 0) ranged.push_back({t.p + my_lo, (uint32_t)(my_hi - my_lo), t.coeff});
+          else if (qowner[i] == (int)me) whole.push_back(t);
+        }
+        if (whole.empty()) CQ_HIP(c, hipMemsetAsync(batch, 0, n * sizeof(Fr), s));
+        else CQ_TRY(lincomb_many(c, whole, Fr::zero(), (uint32_t)n, batch));
+        if (my_hi > my_lo) {  // the by-range terms on this rank's range; "- eval_batch" touches coefficient 0 only
+          std::vector<Term> tt{{batch + my_lo, (uint32_t)(my_hi - my_lo), Fr::one()}};
+          tt.insert(tt.end(), ranged.begin(), ranged.end());
+          CQ_TRY(lincomb_many(c, tt, my_lo == 0 ? eval_batch : Fr::zero(), (uint32_t)(my_hi - my_lo), batch + my_lo));
+        }
+        // rank r commits witness coefficients [wlo, whi) (its point range of the n - 1 term MSM) and needs a[wlo+1 .. whi]
+        const size_t slice_max = res_slice_max;
+        Fr* const stage = (Fr*)res_stage_v;
+        std::vector<Xfer> xf;
+        for (uint32_t q = 0; q < SW; q++)
+          for (uint32_t r = 0; r < SW; r++) {
+            size_t wlo, whi;
+            shard_range(n - 1, r, SW, wlo, whi);
+            if (whi > wlo) xf.push_back({batch + 1 + wlo, stage + (size_t)q * slice_max, (whi - wlo) * sizeof(Fr), q, r});
+          }
+        CQ_TRY(shard_exchange(pk, xf.data(), xf.size(), s));
+        size_t wlo, whi;
+        shard_range(n - 1, me, SW, wlo, whi);
+        const size_t len = whi - wlo;
+        // [0] unused, [1 .. len] the summed slice, [len + 1] the carry -- behind the received slices in the staging area
+        Fr* a_loc = stage + (size_t)SW * slice_max + 8;
+        if ((size_t)SW * slice_max + 8 + len + 2 > res_stage_elems) return c->fail(CQ_ERR_INTERNAL, "resident sharding: staging too small");
+        Fr slice_eval = Fr::zero();
+        if (len) {
+          std::vector<Term> tt;
+          for (uint32_t q = 0; q < SW; q++) tt.push_back({stage + (size_t)q * slice_max, (uint32_t)len, Fr::one()});
+          CQ_TRY(lincomb_many(c, tt, Fr::zero(), (uint32_t)len, a_loc + 1));
+          const Fr* pp = a_loc + 1;
+          const uint32_t ll = (uint32_t)len;
+          CQ_TRY(poly_eval_batch(c, &pp, &ll, 1, z, &slice_eval));
+        }
+        std::vector<Fr> all_s(SW);
+        CQ_TRY(shard_allgather_host(pk, &slice_eval, all_s.data(), sizeof(Fr)));
+        Fr carry = Fr::zero();  // q_(whi) = S_(r+1) + z^len_(r+1) (S_(r+2) + ...)
+        for (uint32_t q = SW; q-- > me + 1;) {
+          size_t qlo, qhi;
+          shard_range(n - 1, q, SW, qlo, qhi);
+          carry = all_s[q] + z.pow_u64(qhi - qlo) * carry;
+        }
+        if (len) {
+          Fr edge[2] = {Fr::zero(), carry};
+          CQ_HIP(c, hipMemcpyAsync(a_loc, &edge[0], sizeof(Fr), hipMemcpyHostToDevice, s));
+          CQ_HIP(c, hipMemcpyAsync(a_loc + len + 1, &edge[1], sizeof(Fr), hipMemcpyHostToDevice, s));
+          CQ_TRY(c->wait(s));  // `edge` is on this frame
+          CQ_TRY(poly_kate_division(c, a_loc, (uint32_t)(len + 2), z, wit + wlo));  // wit[wlo .. whi) (and the carry at [whi])
+        }
+        sc.push_back(wit);
+        continue;
+      }
       CQ_TRY(lincomb_many(c, terms, eval_batch, (uint32_t)n, batch));  // poly_batch - eval_batch (gwc/prover.rs:62-78)
       CQ_TRY(poly_kate_division(c, batch, (uint32_t)n, point_of(rots[g]), wit));  // :80
       sc.push_back(wit);

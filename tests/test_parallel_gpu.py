@@ -64,12 +64,32 @@ assert wl.prove(seed=9) == single, "sharded proof differs from the single-GPU pr
 wl.pk.set_sharding(rank, world, columns=True)
 sharded = wl.prove(seed=9)
 assert sharded == single, "column-sharded proof differs from the single-GPU proof"
+# resident mode: transformed columns stay on their owner (one lookup and two advice columns per rank here), slices of b_0,
+# of the partial quotients and of the GWC batch polynomial travel point to point (gloo isend / irecv through the host hook)
+wl.pk.set_sharding(rank, world, columns=True, resident=True)
+assert wl.prove(seed=9) == single, "resident-sharded proof differs from the single-GPU proof"
+one = ShaCqWorkload(ctx, 11, pairs=1)         # ONE lookup over two ranks: rank 1 owns no lookup (no partial quotient of its own)
+one_single = one.prove(seed=3)
+one.pk.set_sharding(rank, world, columns=True, resident=True)
+assert one.prove(seed=3) == one_single, "resident-sharded proof with a lookup-less rank differs"
+one.pk.set_sharding(0, 1); one.close()
+wl.pk.set_sharding(rank, world, columns=True)
 # The random polynomial is committed with round 2 or in a launch of its own, by a timing-dependent choice that the ranks
 # must make together (one launch more = one all-gather more): pin it differently per rank, then both ways.
 for late in (("1", "0"), ("0", "1"), ("1", "1"), ("0", "0")):
     os.environ["CQ_RANDOM_LATE"] = late[rank]
     assert wl.prove(seed=9) == single, "sharded proof differs with CQ_RANDOM_LATE=%%s" %% (late,)
 del os.environ["CQ_RANDOM_LATE"]
+# a rank that cannot set its proof up (injected on rank 1): BOTH ranks return an error, neither waits for the other
+from sha2_on_cq_halo2_amd import CqError
+os.environ["CQ_TEST_FAIL_SETUP"] = "2"
+try:
+    wl.prove(seed=9)
+    raise SystemExit("the injected set-up failure went unnoticed on rank %%d" %% rank)
+except CqError as e:
+    assert ("CQ_TEST_FAIL_SETUP" in str(e)) == (rank == 1) and ("another rank" in str(e)) == (rank == 0), str(e)
+del os.environ["CQ_TEST_FAIL_SETUP"]
+assert wl.prove(seed=9) == single, "proof after the agreed failure differs"
 wl.pk.set_sharding(0, 1)
 assert wl.prove(seed=9) == single
 dist.barrier(); dist.destroy_process_group(); ctx.close()
@@ -140,9 +160,82 @@ def test_rccl_path_single_rank(ctx):
         for late in ("0", "1"):
             os.environ["CQ_RANDOM_LATE"] = late
             assert wl.prove(seed=9) == plain
+        os.environ.pop("CQ_RANDOM_LATE", None)
+        wl.pk.set_sharding(0, 1, transport="rccl", resident=True)  # the resident flow over the one rank (its exchanges are local copies)
+        assert wl.prove(seed=9) == plain
     finally:
         os.environ.pop("CQ_RANDOM_LATE", None)
         ctx.comm_destroy()
         wl.pk.set_sharding(0, 1)
     assert wl.prove(seed=9) == plain
+    wl.close()
+
+
+BIG_SHARD_WORKER = r'''
+import os, sys, hashlib
+sys.path.insert(0, %(root)r)
+import torch.distributed as dist
+from sha2_on_cq_halo2_amd import Context
+from sha2_on_cq_halo2_amd.sha_circuit import ShaCqWorkload
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+k = %(k)d
+ctx = Context(0)
+wl = ShaCqWorkload(ctx, k)                      # BASELINE shape: 8 advice columns, 4 lookups, the SHA trace of that size
+n = 1 << k
+assert ctx.msm_table_width(wl.params.g_dev, n) == %(bits)d
+single = wl.prove(seed=21)
+for columns, resident in ((True, False), (False, False), (True, True)):
+    wl.pk.set_sharding(rank, world, columns=columns, resident=resident)
+    lo = 0 if rank == 0 else n // 2
+    # the rank's slice has tables of its own, at the width its length calls for; the whole-array tables are gone
+    assert ctx.msm_table_width(wl.params.g_dev + 64 * lo, n // 2) == 15 and ctx.msm_table_width(wl.params.g_dev, n) == 0
+    assert wl.prove(seed=21) == single, "sharded proof differs (columns=%%s, resident=%%s)" %% (columns, resident)
+wl.pk.set_sharding(0, 1)
+assert ctx.msm_table_width(wl.params.g_dev, n) == %(bits)d and wl.prove(seed=21) == single
+dist.barrier(); dist.destroy_process_group(); wl.close(); ctx.close()
+sys.stdout.write("rank %%d ok %%s\n" %% (rank, hashlib.sha256(single).hexdigest()[:12])); sys.stdout.flush()
+'''
+
+
+@pytest.mark.parametrize("k,bits", [(18, 15), (20, 17)])
+def test_sharded_create_proof_at_baseline_sizes(tmp_path, k, bits):
+    """BASELINE configs[2] / configs[3] sizes under 2-rank sharding (gloo callbacks, both ranks on this card): the k = 20 key
+    has 17-bit window tables unsharded and 15-bit ones for the 2^19-point slices; column transforms on and off; the proof
+    bytes equal the unsharded proof's on both ranks."""
+    script = tmp_path / "big_shard_worker.py"
+    script.write_text(BIG_SHARD_WORKER % {"root": ROOT, "k": k, "bits": bits})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(29660 + k), str(script)],
+                       capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert r.stdout.count("rank ") == 2 and r.stdout.count(" ok") == 2, r.stdout
+    digests = {ln.split()[-1] for ln in r.stdout.splitlines() if ln.startswith("rank ")}
+    assert len(digests) == 1, r.stdout
+
+
+def test_rank_local_setup_failure_is_agreed_not_hung(ctx):
+    """A rank that cannot set its proof up (allocation failure: injected with CQ_TEST_FAIL_SETUP) must not leave its peers in
+    a collective: the outcome of the set-up is agreed in a one-word all-gather before anything else is exchanged, and every
+    rank returns an error.  Exercised here over the one-rank RCCL communicator (the handshake itself is an ncclAllGather)."""
+    from sha2_on_cq_halo2_amd import CqError
+    from sha2_on_cq_halo2_amd.api import rccl_unique_id
+    from sha2_on_cq_halo2_amd.sha_circuit import ShaCqWorkload
+
+    wl = ShaCqWorkload(ctx, 10, pairs=2)
+    plain = wl.prove(seed=2)
+    ctx.comm_init_rccl(0, 1, rccl_unique_id())
+    try:
+        wl.pk.set_sharding(0, 1, transport="rccl")
+        os.environ["CQ_TEST_FAIL_SETUP"] = "1"  # rank 0 + 1
+        with pytest.raises(CqError) as e:
+            wl.prove(seed=2)
+        assert "CQ_TEST_FAIL_SETUP" in str(e.value)
+        del os.environ["CQ_TEST_FAIL_SETUP"]
+        assert wl.prove(seed=2) == plain  # the communicator is still good: nothing was left half-exchanged
+    finally:
+        os.environ.pop("CQ_TEST_FAIL_SETUP", None)
+        ctx.comm_destroy()
+        wl.pk.set_sharding(0, 1)
     wl.close()
