@@ -698,7 +698,8 @@ def k20_in_children(rank):
     # every child would wait as a client for a server nobody started (found by the two-ranks-on-one-GPU rehearsal).
     env = {k: v for k, v in os.environ.items() if not k.startswith("TORCHELASTIC_")}
     env["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 1000 + int(os.environ.get("WORLD_SIZE", "1")))
-    timeout = float(os.environ.get("CQ_BENCH_K20_TIMEOUT", "240"))
+    env.setdefault("CQ_COMM_TIMEOUT_S", "45")  # a collective that does not complete fails that leg (library-side time-out), not the child
+    timeout = float(os.environ.get("CQ_BENCH_K20_TIMEOUT", "300"))
     import tempfile
 
     errlog = os.path.join(tempfile.gettempdir(), f"cq_bench_k20_child_rank{rank}.err")
@@ -716,20 +717,27 @@ def k20_in_children(rank):
                                  stderr=ef, cwd=os.path.dirname(os.path.abspath(__file__)) or ".")
     except OSError as e:
         return {"error": f"could not start the child process: {e}"}
+    timed_out = False
     try:
         stdout, _ = p.communicate(timeout=timeout)
     except subprocess.TimeoutExpired:
+        timed_out = True
         p.kill()
-        p.communicate()
-        return {"error": f"timed out after {timeout:.0f} s (a collective did not complete); headline unaffected", "stderr_tail": err_tail()}
+        stdout, _ = p.communicate()  # what the child had printed: it reports after every leg
     if rank != 0:
         return None
     for line in reversed(stdout.decode(errors="replace").strip().splitlines()):
         if line.startswith("{"):
             try:
-                return json.loads(line)
+                res = json.loads(line)
             except ValueError:
-                break
+                continue
+            if timed_out:
+                res["error"] = f"timed out after {timeout:.0f} s in a later leg (a collective did not complete); the legs listed had finished; headline unaffected"
+                res["stderr_tail"] = err_tail()
+            return res
+    if timed_out:
+        return {"error": f"timed out after {timeout:.0f} s (a collective did not complete); headline unaffected", "stderr_tail": err_tail()}
     return {"error": f"child exited with code {p.returncode} and no result; headline unaffected", "stderr_tail": err_tail()}
 
 
@@ -772,7 +780,19 @@ def config3_k20(ctx, D, steps=None, warmup=2):
     res = {"k": kk, "blocks": wl.blocks, "n_gpus": world, "scaling": "strong", "steps": steps, "dist_backend": D.backend if world > 1 else None,
            "msm_scalars_in_gpu_launches": wl.msm_scalars_in_launches()}
 
+    def report():
+        if D.rank == 0 and os.environ.get("CQ_BENCH_K20_PROGRESS", "1") == "1" and world > 1:
+            print(json.dumps(res), flush=True)  # after every leg: a parent that has to kill the child keeps what was measured
+
     def run(label):
+        try:
+            run_leg(label)
+        except Exception as e:  # noqa: BLE001 -- this leg is lost (e.g. a collective timed out and the communicator was aborted); the next
+            res[label] = {"error": f"{type(e).__name__}: {e}"}  # one builds a new communicator
+            ctx._bench_comm = False
+        report()
+
+    def run_leg(label):
         for i in range(warmup):
             wl.fill_witness()
             wl.prove(seed=10 + i)
@@ -797,12 +817,17 @@ def config3_k20(ctx, D, steps=None, warmup=2):
     if world == 1:
         run("unsharded")
     else:
-        D.shard(ctx, wl.pk, columns=True)
-        run("msm_and_columns_sharded")
-        D.shard(ctx, wl.pk, columns=False)
-        run("msm_sharded_only")
-        D.shard(ctx, wl.pk, columns=True, resident=True)  # columns stay on their owner, slices travel point to point
-        run("resident")
+        # simplest exchange first (all-gathers only), so that a failure in a later mode costs the least
+        for label, kw in (("msm_sharded_only", dict(columns=False)), ("msm_and_columns_sharded", dict(columns=True)),
+                          ("resident", dict(columns=True, resident=True))):  # resident: columns stay on their owner, slices travel point to point
+            try:
+                D.shard(ctx, wl.pk, **kw)
+            except Exception as e:  # noqa: BLE001
+                res[label] = {"error": f"set-up: {type(e).__name__}: {e}"}
+                ctx._bench_comm = False
+                report()
+                continue
+            run(label)
         res["parallelism"] = (f"one proof over {world} ranks: MSM point ranges /{world} (window tables for the rank's slices), "
                               "column transforms by owner (broadcast) or resident on their owner (point-to-point slices); " + ("RCCL all-gather of 96-B partials + grouped broadcasts of columns" if D.transport == "rccl"
                                                                 else "host-callback transport over gloo (one-GPU rehearsal of the N > 1 path)"))

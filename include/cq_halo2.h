@@ -75,7 +75,11 @@ int cq_ctx_sync(cq_ctx* ctx);
 /* hipGraph replay of the MSM pipeline (BASELINE configs[4]: "hipGraph-captured rounds"): with `on` != 0 the kernel
  * sequences before and after the accumulate kernel of every MSM launch (sort + plan: ~12 launches; combine + bucket
  * reduction: ~6) are captured once per launch shape and replayed with one hipGraphLaunch each.  Same results; off by
- * default because on ROCm 7.2 it measured no faster than the plain launches. */
+ * default because on ROCm 7.2 it measured no faster than the plain launches.  This is SEGMENT capture: a whole
+ * Fiat-Shamir round cannot be one graph here, because a round ends in a host step the next round's kernels depend on --
+ * the commitments are normalised and absorbed by the Blake2b transcript on the host and the challenge comes back as a
+ * kernel argument -- and the measured idle time between rounds is that host step (fold, normalise, hash: 60-100 us per
+ * round, profiles/r03_host_trace_k18.txt), not launch overhead. */
 int cq_ctx_set_hip_graphs(cq_ctx* ctx, int on);
 /* RCCL communicator of the context (one process per GPU, xGMI within a node): rank 0 draws an id with
  * cq_rccl_unique_id and hands it to the other ranks by whatever means the application has (a torch.distributed
@@ -86,9 +90,17 @@ int cq_ctx_set_hip_graphs(cq_ctx* ctx, int on);
 int cq_rccl_unique_id(uint8_t id[CQ_RCCL_UNIQUE_ID_BYTES]);
 int cq_ctx_comm_init_rccl(cq_ctx* ctx, uint32_t rank, uint32_t world, const uint8_t id[CQ_RCCL_UNIQUE_ID_BYTES]);
 int cq_ctx_comm_destroy(cq_ctx* ctx);
-/* Collective self-check of the communicator: an ncclAllGather and a grouped launch of ncclBroadcasts (one root per
- * rank, unequal lengths) on device buffers with patterns every rank verifies -- the two exchanges the sharded prover
- * makes.  Every rank calls it. */
+/* Collective self-check of the communicator, issued the way the sharded prover issues its exchanges: an ncclAllGather
+ * on the context's stream; a grouped launch of ncclBroadcasts (one root per rank, unequal lengths of about 1 MiB) on the
+ * context's SIDE stream, ordered behind an event of the main stream; a second ncclAllGather on the main stream while the
+ * broadcasts are in flight; device buffers, patterns every rank verifies.  Every rank calls it.
+ *
+ * Failure behaviour of the RCCL transport: the staging its small exchanges need is allocated by cq_ctx_comm_init_rccl, not
+ * inside proofs; a sharded proof first agrees that every rank could set itself up (one status word per rank) and returns an
+ * error everywhere if one could not; host waits inside a proof poll the stream with a time-out (CQ_COMM_TIMEOUT_S, default
+ * 300 s, 0 = none) and ncclCommGetAsyncError; a rank that fails alone in the middle of a proof (CQ_ERR_HIP / _INTERNAL)
+ * aborts its communicator (ncclCommAbort) so that its peers fail -- asynchronous error or time-out -- instead of hanging.
+ * After an abort the context needs a new communicator (cq_ctx_comm_init_rccl). */
 int cq_ctx_comm_selftest(cq_ctx* ctx);
 void* cq_ctx_stream(cq_ctx* ctx);
 const char* cq_version(void);

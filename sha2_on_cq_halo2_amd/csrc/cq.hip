@@ -145,6 +145,34 @@ __global__ void cq_a_values_kernel(const Fr* __restrict__ den_inv, const uint32_
   st(a + i, ai);
   for (uint32_t j = 0; j < tp.width; j++) st(a_scaled + (size_t)j * N + i, mi ? ai * tp.pow[j] : Fr::zero());
 }
+// ---- the same front work for several lookups per launch (cq.hpp: CqFoldBatch) -------------------------------------------
+static __device__ __forceinline__ Fr fold_theta(const CqFoldBatch& b, uint32_t l, uint32_t i) {
+  const uint32_t w = b.width[l];
+  Fr acc = Fr::zero();
+  for (uint32_t j = 0; j < w; j++) acc = acc + ld(b.src[l][j] + i) * b.theta_pow[w - 1 - j];
+  return acc;
+}
+// f = sum_j theta^(w-1-j) e_j   (static_lookup/prover.rs:108-116)
+__global__ __launch_bounds__(256) void cq_fold_inputs_kernel(CqFoldBatch b, uint32_t n) {
+  const uint32_t l = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || !b.out[l]) return;
+  st(b.out[l] + i, fold_theta(b, l, i));
+}
+// B_r = f_r + beta (r < u) / beta (:261-269) and den_i = m_i ? t_i + beta : 0 with the compressed table t (:224-240, 245-247)
+__global__ __launch_bounds__(256) void cq_round2_prep_kernel(CqFoldBatch b, uint32_t n, uint32_t N, uint32_t u, Fr beta) {
+  const uint32_t l = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && b.f[l]) st(b.b[l] + i, i < u ? ld(b.f[l] + i) + beta : beta);
+  if (i < N) st(b.den[l] + i, b.m[l][i] ? fold_theta(b, l, i) + beta : Fr::zero());
+}
+__global__ __launch_bounds__(256) void cq_a_values_batch_kernel(CqAValuesBatch b, uint32_t N) {
+  const uint32_t l = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const uint32_t mi = b.m[l][i], w = b.width[l];
+  Fr ai = Fr::zero();
+  if (mi) ai = Fr::from_u64(mi) * ld(b.den_inv[l] + i);
+  st(b.a[l] + i, ai);
+  for (uint32_t j = 0; j < w; j++) st(b.a_scaled[l] + (size_t)j * N + i, mi ? ai * b.theta_pow[w - 1 - j] : Fr::zero());
+}
 // multiplicities as field elements (for m_cm)
 __global__ void cq_m_to_fr_kernel(const uint32_t* __restrict__ m, uint32_t N, Fr* __restrict__ out) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -242,6 +270,21 @@ int cq_a_denominators(cq_ctx* c, const Fr* t, const uint32_t* m, uint32_t N, con
 int cq_a_values(cq_ctx* c, const Fr* den_inv, const uint32_t* m, uint32_t N, const CqThetaPowers& tp, Fr* a, Fr* a_scaled) {
   cq_a_values_kernel<<<blocks_for(N), 256, 0, c->stream>>>(den_inv, m, N, tp, a, a_scaled);
   return hipGetLastError() == hipSuccess ? CQ_OK : c->fail(CQ_ERR_HIP, "cq_a_values launch failed");
+}
+int cq_fold_inputs(cq_ctx* c, const CqFoldBatch& b, uint32_t n) {
+  if (!b.count || !n) return CQ_OK;
+  cq_fold_inputs_kernel<<<dim3(blocks_for(n), b.count), 256, 0, c->stream>>>(b, n);
+  return hipGetLastError() == hipSuccess ? CQ_OK : c->fail(CQ_ERR_HIP, "cq_fold_inputs launch failed");
+}
+int cq_round2_prep(cq_ctx* c, const CqFoldBatch& b, uint32_t n, uint32_t N, uint32_t u, const Fr& beta) {
+  if (!b.count) return CQ_OK;
+  cq_round2_prep_kernel<<<dim3(blocks_for(n > N ? n : N), b.count), 256, 0, c->stream>>>(b, n, N, u, beta);
+  return hipGetLastError() == hipSuccess ? CQ_OK : c->fail(CQ_ERR_HIP, "cq_round2_prep launch failed");
+}
+int cq_a_values_batch(cq_ctx* c, const CqAValuesBatch& b, uint32_t N) {
+  if (!b.count || !N) return CQ_OK;
+  cq_a_values_batch_kernel<<<dim3(blocks_for(N), b.count), 256, 0, c->stream>>>(b, N);
+  return hipGetLastError() == hipSuccess ? CQ_OK : c->fail(CQ_ERR_HIP, "cq_a_values_batch launch failed");
 }
 int cq_m_to_fr(cq_ctx* c, const uint32_t* m, uint32_t N, Fr* out) {
   cq_m_to_fr_kernel<<<blocks_for(N), 256, 0, c->stream>>>(m, N, out);

@@ -32,6 +32,33 @@ struct CqThetaPowers {
   Fr pow[CQ_MAX_WIDTH];  // theta^(width-1-j)
   uint32_t width;
 };
+// Round-1 / round-2 front work of SEVERAL lookups in one launch (blockIdx.y = lookup): the per-lookup kernels are a few
+// microseconds of work each and queue behind one another (twelve launches between theta and the inversions at L = 4).
+constexpr uint32_t CQ_FOLD_BATCH = 8;
+struct CqFoldBatch {
+  const Fr* src[CQ_FOLD_BATCH][CQ_MAX_WIDTH];  // the w vectors folded with theta: lookup inputs (n each) or table columns (N each)
+  uint32_t width[CQ_FOLD_BATCH];
+  Fr* out[CQ_FOLD_BATCH];            // round 1: f = sum_j theta^(w-1-j) src_j (n elements); may be nullptr (skip)
+  const Fr* f[CQ_FOLD_BATCH];        // round 2: f (n), or nullptr when this rank does not hold b of that lookup
+  Fr* b[CQ_FOLD_BATCH];              // round 2: B_r = f_r + beta (r < u), beta (r >= u)                      (n)
+  const uint32_t* m[CQ_FOLD_BATCH];  // round 2: multiplicities                                              (N)
+  Fr* den[CQ_FOLD_BATCH];            // round 2: m ? t + beta : 0 with t = sum_j theta^(w-1-j) src_j          (N)
+  Fr theta_pow[CQ_MAX_WIDTH];        // theta^0 .. theta^(CQ_MAX_WIDTH - 1)
+  uint32_t count;
+};
+int cq_fold_inputs(cq_ctx* c, const CqFoldBatch& b, uint32_t n);
+int cq_round2_prep(cq_ctx* c, const CqFoldBatch& b, uint32_t n, uint32_t N, uint32_t u, const Fr& beta);
+struct CqAValuesBatch {
+  const Fr* den_inv[CQ_FOLD_BATCH];
+  const uint32_t* m[CQ_FOLD_BATCH];
+  Fr* a[CQ_FOLD_BATCH];
+  Fr* a_scaled[CQ_FOLD_BATCH];
+  uint32_t width[CQ_FOLD_BATCH];
+  Fr theta_pow[CQ_MAX_WIDTH];
+  uint32_t count;
+};
+int cq_a_values_batch(cq_ctx* c, const CqAValuesBatch& b, uint32_t N);
+
 struct ShaCols {
   Fr* p[16];
 };

@@ -317,7 +317,7 @@ struct Arena {
   }
 };
 struct Buffers {
-  Fr *adv, *inst_lag, *inst_coeff, *f_lag, *f_coeff, *bpoly, *random_poly, *z, *mv, *cosets, *adv_cosets, *inst_cosets,
+  Fr *adv, *adv_coeff, *inst_lag, *inst_coeff, *f_lag, *f_coeff, *bpoly, *random_poly, *z, *mv, *cosets, *adv_cosets, *inst_cosets,
       *z_cosets, *lk_inputs, *plk, *plk_cosets, *h_ext, *h_coeff, *gwc_batch, *gwc_wit, *shplonk, *t_comp, *den, *a_val, *m_fr, *a_scaled;
   Fr* challenges;  // user challenges (Expression::Challenge), uploaded as the phases complete
   Fr *tails, *gather;  // blinding rows of a phase's advice columns (staging); scalars on their way to the host
@@ -338,6 +338,10 @@ std::vector<int32_t> opening_rotations(const cq_pk* pk) {
   return rots;
 }
 
+bool early_advice_polys(const cq_pk* pk) {
+  return !pk->general() && pk->perm_sets() == 0 && pk->num_phases == 1 && pk->num_advice > 0 && !pk->lookups.empty();
+}
+
 void carve(const cq_pk* pk, Arena& ar, Buffers& b) {
   const size_t n = (size_t)1 << pk->k, ext = pk->domain->ext();
   const size_t L = pk->lookups.size(), A = pk->num_advice, I = pk->num_instance, S = pk->perm_sets();
@@ -347,6 +351,9 @@ void carve(const cq_pk* pk, Arena& ar, Buffers& b) {
   for (auto& lk : pk->lookups) wsum += lk.cols.size();
   const size_t npts = opening_rotations(pk).size();
   b.adv = ar.take(A * n);            // advice (lagrange -> coeff in place)
+  // CQ-only single-phase circuits: the coefficient forms go to a buffer of their own, so that the transform can start
+  // under the advice launch's tail while the Lagrange values are still needed (round 1 folds them into f)
+  b.adv_coeff = ar.take(early_advice_polys(pk) ? A * n : 0);
   b.inst_lag = ar.take(I * n);
   b.inst_coeff = ar.take(I * n);
   b.f_lag = ar.take(L * n);
@@ -525,6 +532,9 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, const uint64_
      *a_scaled = B.a_scaled;
   uint64_t* rng_dev = B.rng_dev;
   uint32_t* m_counts = B.m_counts;
+  const bool early_adv = early_advice_polys(pk);
+  Fr* const adv_poly = early_adv ? B.adv_coeff : adv;  // where the advice polynomials (coefficient form) live
+  bool adv_is_coeff = false;
 
   // Column sharding (cq_pk_set_column_sharding): a batch of independent column transforms is split
   // between the ranks by owner -- contiguous ranges of columns, cq::shard_range -- and every rank's output columns are
@@ -754,7 +764,22 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, const uint64_
       for (size_t l = 0; l < L; l++) { sc.push_back(B.m_fr + l * N); bs.push_back(pk->table_cfg->g1_lagrange); ln.push_back(N); }
     }
     Commit adv_cm;
+    const uint64_t seq_adv = c->msm_tail_seq;
     if (!sc.empty()) CQ_TRY(adv_cm.begin(pk, sc, bs, ln));
+    if (early_adv) {
+      // advice -> coefficients (prover.rs:587-603) on the side stream, behind this launch's accumulate kernel: it runs
+      // under the launch's tail and the host's round trip for theta, when the GPU has little else to do -- after theta
+      // it would compete with the critical path from beta to round 2's launch (round 3: -0.3 ms at k = 18)
+      AuxFork fork(c);
+      CQ_TRY(fork.begin(seq_adv));
+      if (resident) {
+        if (adv_hi > adv_lo) CQ_TRY(domain_lagrange_to_coeff(dom, adv + adv_lo * n, adv_poly + adv_lo * n, (uint32_t)(adv_hi - adv_lo), n, n));
+      } else {
+        CQ_TRY(lagrange_to_coeff_cols(adv, adv_poly, A));
+      }
+      CQ_TRY(fork.end());
+      adv_is_coeff = true;
+    }
     if (last_phase) {
     // The next draws from the RNG are, per permutation set, `bf` blinding rows of z and one blind
     // (permutation/prover.rs:169-175), then the vanishing argument's n coefficients + 1 blind
@@ -847,27 +872,29 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, const uint64_
   }
 
   // ---- CQ round 1 (static_lookup/prover.rs:51-183) ------------------------------------------------
-  bool adv_is_coeff = false;
   if (L && !early_m) {
     CQ_TRY(count_multiplicities());
     CQ_TRY(c->wait(s));
     CQ_TRY(lookup_error());
   }
-  for (size_t l = 0; l < L; l++) {
-    if (resident && (l < lk_lo || l >= lk_hi)) continue;  // resident: f_l exists on the owner of lookup l only
-    // f = sum_j theta^(w-1-j) * e_j   (:108-116, Horner with the first expression first)
-    const uint32_t w = (uint32_t)pk->lookups[l].cols.size();
-    LincombArgs la;
-    la.count = w;
-    la.sub_const = Fr::zero();
-    Fr p = Fr::one();
-    for (int j = (int)w - 1; j >= 0; j--) {
-      la.p[j] = lk_input[l][j];
-      la.len[j] = (uint32_t)n;
-      la.coeff[j] = p;
-      p = p * theta;
+  // powers of theta for the folds of this proof (theta^0 .. theta^(CQ_MAX_WIDTH - 1))
+  Fr theta_pow[CQ_MAX_WIDTH];
+  theta_pow[0] = Fr::one();
+  for (uint32_t j = 1; j < CQ_MAX_WIDTH; j++) theta_pow[j] = theta_pow[j - 1] * theta;
+  for (size_t l0 = 0; l0 < L; l0 += CQ_FOLD_BATCH) {
+    // f = sum_j theta^(w-1-j) * e_j   (:108-116, Horner with the first expression first), the lookups of a proof per launch
+    CqFoldBatch fb;
+    fb.count = (uint32_t)std::min<size_t>(CQ_FOLD_BATCH, L - l0);
+    for (uint32_t j = 0; j < CQ_MAX_WIDTH; j++) fb.theta_pow[j] = theta_pow[j];
+    for (uint32_t q = 0; q < fb.count; q++) {
+      const size_t l = l0 + q;
+      const uint32_t w = (uint32_t)pk->lookups[l].cols.size();
+      fb.width[q] = w;
+      for (uint32_t j = 0; j < w; j++) fb.src[q][j] = lk_input[l][j];
+      // resident: f_l exists on the owner of lookup l only
+      fb.out[q] = (resident && (l < lk_lo || l >= lk_hi)) ? nullptr : f_lag + l * n;
     }
-    CQ_TRY(poly_lincomb(c, la, (uint32_t)n, f_lag + l * n));
+    CQ_TRY(cq_fold_inputs(c, fb, (uint32_t)n));
   }
   if (L || PL) {
     // permuted input / table of every legacy lookup (lookup/prover.rs:136-151), then f_cm (:165) and, unless it went
@@ -923,7 +950,7 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, const uint64_
           CQ_TRY(domain_lagrange_to_coeff(dom, f_lag + lk_lo * n, f_coeff + lk_lo * n, (uint32_t)lk_cnt, n, n));
           CQ_TRY(domain_coeff_to_extended(dom, f_coeff + lk_lo * n, cosets + (L + lk_lo) * ext, (uint32_t)lk_cnt, n, ext));
         }
-        if (adv_hi > adv_lo) CQ_TRY(domain_lagrange_to_coeff(dom, adv + adv_lo * n, adv + adv_lo * n, (uint32_t)(adv_hi - adv_lo), n, n));
+        if (!adv_is_coeff && adv_hi > adv_lo) CQ_TRY(domain_lagrange_to_coeff(dom, adv + adv_lo * n, adv + adv_lo * n, (uint32_t)(adv_hi - adv_lo), n, n));
         adv_is_coeff = true;
       } else {
       if (L) {
@@ -931,7 +958,7 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, const uint64_
         CQ_TRY(coeff_to_extended_cols(f_coeff, cosets + L * ext, L));
       }
       if (general && I) CQ_TRY(coeff_to_extended_cols(B.inst_coeff, B.inst_cosets, I));
-      if (A && S == 0) {
+      if (A && S == 0 && !adv_is_coeff) {
         // advice -> coefficients (prover.rs:587-603), in place: without a permutation argument nothing reads the
         // Lagrange values after round 1, and the round-2 inversions leave room for it
         CQ_TRY(lagrange_to_coeff_cols(adv, adv, A));
@@ -1019,25 +1046,25 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, const uint64_
   G1Affine random_cm = G1Affine::identity();
   {
     size_t woff = 0;
-    for (size_t l = 0; l < L; l++) {
-      const cq_lookup_desc& lk = pk->lookups[l];
-      const uint32_t w = (uint32_t)lk.cols.size();
-      // t_i = sum_j theta^(w-1-j) T_j[i]  (compress_tables :224-240)
-      LincombArgs la;
-      la.count = w;
-      la.sub_const = Fr::zero();
-      Fr p = Fr::one();
-      for (int j = (int)w - 1; j >= 0; j--) {
-        la.p[j] = lk.tables[j]->values;
-        la.len[j] = (uint32_t)N;
-        la.coeff[j] = p;
-        p = p * theta;
+    for (size_t l0 = 0; l0 < L; l0 += CQ_FOLD_BATCH) {
+      // per lookup: t_i = sum_j theta^(w-1-j) T_j[i] (compress_tables :224-240), den_i = m_i ? t_i + beta : 0 (:245-247),
+      // B_r = f_r + beta for r < u, beta on the blinding rows (:261-269) -- one launch for the lookups of the proof
+      CqFoldBatch fb;
+      fb.count = (uint32_t)std::min<size_t>(CQ_FOLD_BATCH, L - l0);
+      for (uint32_t j = 0; j < CQ_MAX_WIDTH; j++) fb.theta_pow[j] = theta_pow[j];
+      for (uint32_t q = 0; q < fb.count; q++) {
+        const size_t l = l0 + q;
+        const cq_lookup_desc& lk = pk->lookups[l];
+        fb.width[q] = (uint32_t)lk.cols.size();
+        for (uint32_t j = 0; j < fb.width[q]; j++) fb.src[q][j] = lk.tables[j]->values;
+        fb.out[q] = nullptr;
+        const bool mine = !resident || (l >= lk_lo && l < lk_hi);  // resident: b_l on the owner of lookup l only
+        fb.f[q] = mine ? f_lag + l * n : nullptr;
+        fb.b[q] = bpoly + l * n;
+        fb.m[q] = m_counts + l * N;
+        fb.den[q] = den + l * N;
       }
-      CQ_TRY(poly_lincomb(c, la, (uint32_t)N, t_comp));
-      CQ_TRY(cq_a_denominators(c, t_comp, m_counts + l * N, (uint32_t)N, beta, den + l * N));
-      // B_r = f_r + beta, r < u ; beta on the blinding rows (:261-269)
-      if (!resident || (l >= lk_lo && l < lk_hi))  // resident: b_l on the owner of lookup l only
-        CQ_TRY(poly_cq_b_denominators(c, f_lag + l * n, (uint32_t)n, u, beta, bpoly + l * n));
+      CQ_TRY(cq_round2_prep(c, fb, (uint32_t)n, (uint32_t)N, u, beta));
     }
     if (L && resident) {
       if (lk_cnt) CQ_TRY(poly_batch_invert(c, bpoly + lk_lo * n, (uint32_t)(lk_cnt * n)));
@@ -1047,17 +1074,20 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, const uint64_
       CQ_TRY(poly_batch_invert(c, bpoly, (uint32_t)(L * n + L * N)));  // bpoly and den are adjacent
     }
     woff = 0;
-    for (size_t l = 0; l < L; l++) {
-      const uint32_t w = (uint32_t)pk->lookups[l].cols.size();
-      CqThetaPowers tp;
-      tp.width = w;
-      Fr p = Fr::one();
-      for (int j = (int)w - 1; j >= 0; j--) {
-        tp.pow[j] = p;
-        p = p * theta;
+    for (size_t l0 = 0; l0 < L; l0 += CQ_FOLD_BATCH) {  // a_i = m_i / (t_i + beta) and its theta-scaled copies for q_a (:247-256)
+      CqAValuesBatch ab;
+      ab.count = (uint32_t)std::min<size_t>(CQ_FOLD_BATCH, L - l0);
+      for (uint32_t j = 0; j < CQ_MAX_WIDTH; j++) ab.theta_pow[j] = theta_pow[j];
+      for (uint32_t q = 0; q < ab.count; q++) {
+        const size_t l = l0 + q;
+        ab.width[q] = (uint32_t)pk->lookups[l].cols.size();
+        ab.den_inv[q] = den + l * N;
+        ab.m[q] = m_counts + l * N;
+        ab.a[q] = a_val + l * N;
+        ab.a_scaled[q] = a_scaled + woff * N;
+        woff += ab.width[q];
       }
-      CQ_TRY(cq_a_values(c, den + l * N, m_counts + l * N, (uint32_t)N, tp, a_val + l * N, a_scaled + woff * N));
-      woff += w;
+      CQ_TRY(cq_a_values_batch(c, ab, (uint32_t)N));
     }
     if (L && resident) {
       // resident: the owner turns its b_l into coefficients; every rank commits its point range of b_0 = (b - b(0)) / X
@@ -1366,7 +1396,7 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, const uint64_
   };
   const int32_t rot_last = -(int32_t)(bf + 1);
   std::vector<size_t> q_advice, q_fixed, q_sigma, q_z, q_z_next, q_z_last(S, (size_t)-1), q_b0, q_f, q_h;
-  for (auto& q : pk->advice_queries) q_advice.push_back(add_query(adv + (size_t)q.first * n, n, q.second));
+  for (auto& q : pk->advice_queries) q_advice.push_back(add_query(adv_poly + (size_t)q.first * n, n, q.second));
   for (size_t st = 0; st < S; st++) {  // permutation::Evaluated::open (permutation/prover.rs:294-344)
     q_z.push_back(add_query(B.z + st * n, n, 0));
     q_z_next.push_back(add_query(B.z + st * n, n, 1));

@@ -239,3 +239,42 @@ def test_rank_local_setup_failure_is_agreed_not_hung(ctx):
         ctx.comm_destroy()
         wl.pk.set_sharding(0, 1)
     wl.close()
+
+
+RESIDENT_WORKER = r'''
+import os, sys, hashlib
+sys.path.insert(0, %(root)r)
+import torch.distributed as dist
+from sha2_on_cq_halo2_amd import Context
+from sha2_on_cq_halo2_amd.sha_circuit import ShaCqWorkload
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+ctx = Context(0)
+for k, pairs in ((11, 2), (12, 4), (10, 3)):
+    wl = ShaCqWorkload(ctx, k, pairs=pairs)
+    single = wl.prove(seed=7)
+    wl.pk.set_sharding(rank, world, columns=True, resident=True)
+    for late in ("0", "1"):
+        os.environ["CQ_RANDOM_LATE"] = late
+        assert wl.prove(seed=7) == single, "resident-sharded proof differs (world %%d, k %%d, %%d lookups, late %%s)" %% (world, k, pairs, late)
+    del os.environ["CQ_RANDOM_LATE"]
+    wl.pk.set_sharding(0, 1)
+    wl.close()
+dist.barrier(); dist.destroy_process_group(); ctx.close()
+sys.stdout.write("rank %%d ok\n" %% rank); sys.stdout.flush()
+'''
+
+
+@pytest.mark.parametrize("world", [3, 4])
+def test_resident_sharding_three_and_four_ranks_one_gpu(tmp_path, world):
+    """Resident column sharding over 3 ranks (point ranges of unequal length: 2^k and 2^k - 1 are not multiples of 3; one
+    rank without a lookup when there are two) and 4 ranks (one lookup per rank at pairs = 4; three lookups over four ranks),
+    gloo point-to-point through the host hook, every rank on this card: proof bytes equal the unsharded proof's."""
+    script = tmp_path / "resident_worker.py"
+    script.write_text(RESIDENT_WORKER % {"root": ROOT})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % world,
+                        "--master-addr", "127.0.0.1", "--master-port", str(29690 + world), str(script)],
+                       capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert r.stdout.count(" ok") == world, r.stdout
