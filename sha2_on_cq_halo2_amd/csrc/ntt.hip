@@ -125,6 +125,13 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(NttPassArgs a) {
   Fr* out = a.out + (size_t)batch * a.out_stride;
   const uint32_t index0 = tile * T;
   const bool first = a.lgp == 0, last = a.next_deg == 0;
+  // LDS image: element (row, column) at word at(row, column) of every limb plane.  With 16 columns a half-wave (what one
+  // ds_*_b32 cycle serves from the 64 banks) is two row groups, and in the second and third radix-4 steps and in the store
+  // their rows differ by a multiple of four rows = 64 words: the same 16 banks twice, every such access at half rate.
+  // XORing the low two bits of the row with bits 2-3 and 4-5 puts the four row groups of a wave on four bank groups in
+  // every phase (found by enumeration, tools/lds_bank_conflicts.py); wider tiles (32 / 64 columns) have no such conflicts.
+  constexpr bool SWZ = !DYN && LOG_T == 4;
+  auto at = [&](uint32_t row, uint32_t c) { return SWZ ? (((row ^ (((row >> 2) ^ (row >> 4)) & 3u)) << 4) + c) : row * T + c; };
 
   // ---- load tile: element (row i, col c) <- in[index0 + c + i*t] ----
   // first pass: R form -> R' form (times 2^266), with the coset factor zeta^(g mod 3) folded into the constant;
@@ -158,7 +165,7 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(NttPassArgs a) {
       x = g_load29(in + g);  // without a coset shift: canonical limbs read as the R' value of a / 32 (< p)
       if (load_mul) x = Fr29::mul(x, lds_load29(cl29 + (g % 3) * 9, 1, 0));  // 1 * 2
     }
-    lds_store29(smem29, E, i * T + c, x);
+    lds_store29(smem29, E, at(i, c), x);
   }
   __syncthreads();
 
@@ -187,7 +194,7 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(NttPassArgs a) {
       const uint32_t wg = w >> log_t;
       const uint32_t dj = wg >> rnd;
       const uint32_t r0 = (((wg & ((1u << rnd) - 1u)) * bit) << 1) + dj;
-      const uint32_t o0 = r0 * T + c, o1 = o0 + hb * T, o2 = o0 + bit * T, o3 = o2 + hb * T;
+      const uint32_t o0 = at(r0, c), o1 = at(r0 + hb, c), o2 = at(r0 + bit, c), o3 = at(r0 + bit + hb, c);
       const Fr29 x0 = lds_load29(smem29, E, o0), x1 = lds_load29(smem29, E, o1);
       const Fr29 x2 = lds_load29(smem29, E, o2), x3 = lds_load29(smem29, E, o3);
       const Fr29 s02 = x0 + x2, s13 = x1 + x3;  // < 2 B_r p, limbs < 2^30: not normalised (operands of + and sub only)
@@ -228,14 +235,14 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(NttPassArgs a) {
       const uint32_t b = ((wb & ((1u << lg_rest) - 1u)) * bit) | di;
       const uint32_t i0 = (b << 1) - di;
       const uint32_t i1 = i0 + bit;
-      const Fr29 u = lds_load29(smem29, E, i0 * T + c);
-      const Fr29 v = lds_load29(smem29, E, i1 * T + c);
+      const Fr29 u = lds_load29(smem29, E, at(i0, c));
+      const Fr29 v = lds_load29(smem29, E, at(i1, c));
       Fr29 s = u + v;  // < 2 B_r p
       s.normalise();
       Fr29 d = sub_level(u, v, rnd);  // < 2 B_r p
       if (di) d = Fr29::mul(d, lds_load29(tw29, half, di << rnd));  // 2 B_r * 1 <= 128
-      lds_store29(smem29, E, i0 * T + c, s);
-      lds_store29(smem29, E, i1 * T + c, d);
+      lds_store29(smem29, E, at(i0, c), s);
+      lds_store29(smem29, E, at(i1, c), d);
     }
     __syncthreads();
   }
@@ -250,7 +257,7 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(NttPassArgs a) {
     const uint32_t k = index & (p - 1);
     const uint32_t g = ((index - k) << deg) + k + i * p;
     if (g >= a.out_len) continue;
-    const Fr29 x = lds_load29(smem29, E, bitrev(i, deg) * T + c);  // < 128 p
+    const Fr29 x = lds_load29(smem29, E, at(bitrev(i, deg), c));  // < 128 p
 #ifdef CQ_NTT_EXP_NOTW  // timing experiment (wrong results): no twiddle load, no product at the store
     g_store29(out + g, x, false);
     continue;
@@ -275,6 +282,163 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(NttPassArgs a) {
       if (h) w = canon29(Fr29::mul(w, g_load29(a.tw_hi + h)));
     }
     g_store29(out + g, Fr29::mul(x, w), false);  // 128 * 1
+  }
+}
+
+// ---- wide passes: 7, 8 or 9 bits per pass ------------------------------------------------------------------------------
+// A 2^18 transform in TWO passes of nine bits (2^19..2^21 in three instead of four) saves a whole trip through HBM and one
+// inter-pass product per element.  Tile: 2^DEG rows x T columns = 2048 elements (73.7 KB of LDS as nine limb planes: two
+// workgroups of 512 threads per CU, the same sixteen waves as four 256-thread ones); T = 4 columns at nine bits, i.e.
+// every global access is a run of 128 B -- one cache line -- instead of 512 B.
+// The lazy bound B_r = 2^(r+1) of the butterflies reaches 128 p after six levels, the most a product's other operand (a
+// canonical root) allows.  So after the third radix-4 step every output that was not just multiplied by a root is reduced
+// with one product by the field's one (a quarter of the elements plus the groups with root index 0: ~0.34 products per
+// element), everything is below 4 p again, and the remaining levels run with the bounds of levels 1, 2, 3.
+constexpr uint32_t NTT_WIDE_THREADS = 512, NTT_WIDE_TILE_LOG = 11, NTT_WIDE_MAX_DEG = 9;
+
+template <uint32_t DEG, uint32_t LOG_T>
+__global__ __launch_bounds__(NTT_WIDE_THREADS) void ntt_pass_wide_kernel(NttPassArgs a) {
+  static_assert(DEG >= 7 && DEG <= NTT_WIDE_MAX_DEG && DEG + LOG_T == NTT_WIDE_TILE_LOG, "wide pass shapes");
+  extern __shared__ uint32_t smem29[];
+  constexpr uint32_t D = 1u << DEG, T = 1u << LOG_T, E = D * T, half = D >> 1, TH = NTT_WIDE_THREADS;
+  uint32_t* const cl29 = smem29 + 9 * E;  // per-residue constants of the load, then of the store (no room for the roots:
+  uint32_t* const cs29 = cl29 + 27;       // two 73.7-KB tiles per CU leave 12 KB -- they come from the L1 / L2-resident table)
+  // LDS image: element (row, column) at word  swz(row) * T + column  of every limb plane.  A ds_read_b32 serves 32 lanes per
+  // cycle from 64 banks; with T = 4 columns a half-wave is eight row groups, and the butterflies' rows differ by 128, 32
+  // or 8 rows between neighbouring groups -- multiples of 64 words, i.e. the same four banks eight times over.  XORing the
+  // low bits of the row with two higher bit fields spreads every one of those patterns (and the bit-reversed rows of the
+  // store phase) over all the banks; consecutive rows keep consecutive places, so the load phase stays conflict-free.
+  constexpr uint32_t GMASK = (64u >> LOG_T) - 1u;  // row groups per 64 words, minus one
+  auto at = [&](uint32_t row, uint32_t c) { return ((row ^ (((row >> 3) ^ (row >> 5)) & GMASK)) << LOG_T) + c; };
+  auto root = [&](uint32_t j) { return g_load29(a.pq + ((size_t)j << a.pq_shift)); };  // (w_n^(n / D))^j, canonical
+  const uint32_t n = 1u << a.log_n;
+  const uint32_t t = n >> DEG;
+  const uint32_t p = 1u << a.lgp;
+  const uint32_t batch = blockIdx.y;
+  const Fr* in = a.in + (size_t)batch * a.in_stride;
+  Fr* out = a.out + (size_t)batch * a.out_stride;
+  const uint32_t index0 = blockIdx.x * T;
+  const bool first = a.lgp == 0, last = a.next_deg == 0;
+  const bool load_mul = first && (a.flags & NTT_IN_COSET);
+  if (load_mul && threadIdx.x < 3) {
+    Fr29 cl = const29(CONSTS29<FrP>.from256);
+    if (threadIdx.x) cl = Fr29::mul(Fr29::unpack(a.in_coset[threadIdx.x - 1].v.l), const29(CONSTS29<FrP>.c271));
+    CQ_UNROLL for (int l = 0; l < 9; l++) cl29[threadIdx.x * 9 + l] = cl.a[l];
+  }
+  if (last && threadIdx.x >= 64 && threadIdx.x < 67) {
+    const uint32_t m = threadIdx.x - 64;
+    const Fr one = Fr::one();
+    const uint32_t* src = (a.flags & NTT_OUT_MUL) ? ((a.flags & NTT_OUT_COSET) ? a.out_mul[m].v.l : a.out_mul[0].v.l) : one.v.l;
+    const Fr29 cm = Fr29::unpack(src);
+    CQ_UNROLL for (int l = 0; l < 9; l++) cs29[m * 9 + l] = cm.a[l];
+  }
+  if (load_mul) __syncthreads();
+  for (uint32_t e = threadIdx.x; e < E; e += TH) {
+    const uint32_t g = index0 + (e & (T - 1)) + (e >> LOG_T) * t;
+    Fr29 x = Fr29::zero();
+    if (g < a.in_len) {
+      x = g_load29(in + g);
+      if (load_mul) x = Fr29::mul(x, lds_load29(cl29 + (g % 3) * 9, 1, 0));
+    }
+    lds_store29(smem29, E, at(e >> LOG_T, e & (T - 1)), x);
+  }
+  __syncthreads();
+
+  constexpr uint32_t R4 = DEG / 2;
+#pragma unroll
+  for (uint32_t st = 0; st < R4; st++) {
+    const uint32_t rnd = 2 * st;                      // structural level of the step's first half
+    const uint32_t brnd = st < 3 ? rnd : rnd - 5;     // level whose bounds apply: 0, 2, 4, then (after the reduction) 1
+    constexpr uint32_t RED_STEP = 2;                  // the step after which B would reach 128
+    const bool reduce = st == RED_STEP;
+    const uint32_t bit = half >> rnd;
+    const uint32_t hb = bit >> 1;
+    for (uint32_t w = threadIdx.x; w < (half >> 1) * T; w += TH) {
+      const uint32_t c = w & (T - 1);
+      const uint32_t wg = w >> LOG_T;
+      const uint32_t dj = wg >> rnd;
+      const uint32_t r0 = (((wg & ((1u << rnd) - 1u)) * bit) << 1) + dj;
+      const uint32_t o0 = at(r0, c), o1 = at(r0 + hb, c), o2 = at(r0 + bit, c), o3 = at(r0 + bit + hb, c);
+      const Fr29 x0 = lds_load29(smem29, E, o0), x1 = lds_load29(smem29, E, o1);
+      const Fr29 x2 = lds_load29(smem29, E, o2), x3 = lds_load29(smem29, E, o3);
+      const Fr29 s02 = x0 + x2, s13 = x1 + x3;
+      Fr29 d02 = sub_level(x0, x2, brnd);
+      if (dj) d02 = Fr29::mul(d02, root(dj << rnd));
+      const Fr29 d13 = Fr29::mul(sub_level(x1, x3, brnd), root((dj + hb) << rnd));
+      Fr29 y0 = s02 + s13;
+      y0.normalise();
+      Fr29 y1 = sub_level(s02, s13, brnd + 1);
+      Fr29 y2 = d02 + d13;
+      y2.normalise();
+      Fr29 y3 = sub_level(d02, d13, brnd + 1);
+      if (dj) {
+        const Fr29 w2 = root(dj << (rnd + 1));
+        y1 = Fr29::mul(y1, w2);
+        y3 = Fr29::mul(y3, w2);
+      } else if (reduce) {  // not multiplied by a root in this step: bring them back below 2 p by hand
+        y1 = y1.reduced();
+        y2 = y2.reduced();
+        y3 = y3.reduced();
+      }
+      if (reduce) y0 = y0.reduced();  // < 128 p -> < 2 p
+      lds_store29(smem29, E, o0, y0);
+      lds_store29(smem29, E, o1, y1);
+      lds_store29(smem29, E, o2, y2);
+      lds_store29(smem29, E, o3, y3);
+    }
+    __syncthreads();
+  }
+  if (DEG & 1) {  // odd DEG: the last level on its own (bounds: level 6 of a 7-bit pass = level 1, level 8 of a 9-bit pass = level 3)
+    constexpr uint32_t rnd = DEG - 1;
+    constexpr uint32_t brnd = rnd - 5;
+    const uint32_t bit = half >> rnd;
+    for (uint32_t w = threadIdx.x; w < half * T; w += TH) {
+      const uint32_t c = w & (T - 1);
+      const uint32_t wb = w >> LOG_T;
+      const uint32_t di = wb >> rnd;
+      const uint32_t b = ((wb & ((1u << rnd) - 1u)) * bit) | di;
+      const uint32_t i0 = (b << 1) - di;
+      const uint32_t i1 = i0 + bit;
+      const Fr29 u = lds_load29(smem29, E, at(i0, c));
+      const Fr29 v = lds_load29(smem29, E, at(i1, c));
+      Fr29 sm = u + v;
+      sm.normalise();
+      Fr29 d = sub_level(u, v, brnd);
+      if (di) d = Fr29::mul(d, root(di << rnd));
+      lds_store29(smem29, E, at(i0, c), sm);
+      lds_store29(smem29, E, at(i1, c), d);
+    }
+    __syncthreads();
+  }
+
+  const uint32_t lgp2 = a.lgp + DEG;
+  const uint32_t log_t2 = a.log_n - a.next_deg;
+  for (uint32_t e = threadIdx.x; e < E; e += TH) {
+    const uint32_t c = e & (T - 1);
+    const uint32_t i = e >> LOG_T;
+    const uint32_t index = index0 + c;
+    const uint32_t k = index & (p - 1);
+    const uint32_t g = ((index - k) << DEG) + k + i * p;
+    if (g >= a.out_len) continue;
+    const Fr29 x = lds_load29(smem29, E, at(bitrev(i, DEG), c));  // < 64 p
+    if (last) {
+      const uint32_t m = (a.flags & NTT_OUT_COSET) ? g % 3 : 0;
+      g_store29(out + g, Fr29::mul(x, lds_load29(cs29 + m * 9, 1, 0)), true);
+      continue;
+    }
+    const uint32_t i2 = g >> log_t2, index2 = g & ((1u << log_t2) - 1);
+    const uint32_t ex = ((n >> lgp2) >> a.next_deg) * (index2 & ((1u << lgp2) - 1)) * i2;
+    Fr29 w;
+    if (!ex) {
+      w = const29(CONSTS29<FrP>.one);
+    } else if (a.tw_full) {
+      w = g_load29(a.tw_full + ex);
+    } else {
+      w = g_load29(a.tw_lo + (ex & ((1u << a.tw_l) - 1)));
+      const uint32_t h = ex >> a.tw_l;
+      if (h) w = canon29(Fr29::mul(w, g_load29(a.tw_hi + h)));
+    }
+    g_store29(out + g, Fr29::mul(x, w), false);
   }
 }
 
@@ -491,7 +655,7 @@ int NttTables::build(uint32_t log_n_, const Fr& omega_, hipStream_t stream) {
   tw_l = (log_n + 1) / 2;
   const uint32_t lo_cnt = 1u << tw_l;
   const uint32_t hi_cnt = 1u << (log_n - tw_l);
-  pq_log = log_n < NTT_MAX_DEG ? log_n : NTT_MAX_DEG;
+  pq_log = log_n < NTT_WIDE_MAX_DEG ? log_n : NTT_WIDE_MAX_DEG;  // roots for the largest in-LDS FFT, wide passes included
   const uint32_t pq_cnt = pq_log ? (1u << (pq_log - 1)) : 1;
   if (hipMalloc(&tw_lo, sizeof(Fr) * lo_cnt) != hipSuccess) return -1;
   if (hipMalloc(&tw_hi, sizeof(Fr) * hi_cnt) != hipSuccess) return -1;
@@ -522,7 +686,23 @@ int ntt_run(const NttTables& tb, const Fr* in, Fr* out, Fr* scratch, const NttIo
   const uint32_t n = 1u << log_n;
   uint32_t npass = log_n == 0 ? 1 : (log_n + NTT_MAX_DEG - 1) / NTT_MAX_DEG;
   uint32_t degs[8];
-  {
+  // Wide passes (7..9 bits, ntt_pass_wide_kernel): fewer trips through HBM -- 2^18 in two passes (9 + 9), 2^19..2^21 in three
+  // (7 + 6 + 6 .. 7 + 7 + 7).  Measured on MI355X, 8 columns, Gelem/s wide / 4..6-bit plan (profiles/r03_ntt_wide_ab.txt):
+  // 2^17 8.7 / 8.3, 2^18 9.0 / 8.9, 2^19 7.8 / 7.6, 2^20 7.4 / 7.6, 2^21 7.4 / 7.9, 2^22 7.6 / 8.3 -- a pass is bound by VALU
+  // issue and LDS latency, not by HBM, so a saved trip is worth little and the nine-bit pass's 128-byte runs and extra
+  // reducing products take it back from 2^20 on.  Default: wide up to 2^19.  CQ_NTT_WIDE=0 / 1 forces never / always (A/B).
+  static const int wide_env = getenv("CQ_NTT_WIDE") ? atoi(getenv("CQ_NTT_WIDE")) : -1;
+  const bool wide_on = wide_env < 0 ? log_n <= 19 : wide_env != 0;
+  const uint32_t npass_wide = (log_n + NTT_WIDE_MAX_DEG - 1) / NTT_WIDE_MAX_DEG;
+  const bool wide = wide_on && NTT_MAX_DEG == 6 && NTT_TILE_ELEMS == 1024 && log_n >= 13 && npass_wide < npass;
+  if (wide) {
+    npass = npass_wide;
+    uint32_t rem = log_n;
+    for (uint32_t i = 0; i < npass; i++) {  // widest passes first: 19 = 7 + 6 + 6, 22 = 8 + 7 + 7
+      degs[i] = (rem + (npass - i) - 1) / (npass - i);
+      rem -= degs[i];
+    }
+  } else {
     uint32_t rem = log_n;
     for (uint32_t i = 0; i < npass; i++) {
       uint32_t d = (rem + (npass - i) - 1) / (npass - i);
@@ -567,9 +747,10 @@ int ntt_run(const NttTables& tb, const Fr* in, Fr* out, Fr* scratch, const NttIo
     a.next_deg = last ? 0 : degs[ps + 1];
     const uint32_t t = n >> degs[ps];
     uint32_t log_t = 0;
+    const bool wide_pass = degs[ps] > NTT_MAX_DEG;
     // (CQ_NTT_PIPE_TILE=512: half-size tiles for the pipelined kernel -- twice the tiles per persistent workgroup; A/B knob)
     static const uint32_t tile_elems = (getenv("CQ_NTT_PIPE_TILE") && atoi(getenv("CQ_NTT_PIPE_TILE")) == 512 && NTT_TILE_ELEMS == 1024) ? 512u : NTT_TILE_ELEMS;
-    while ((1u << (log_t + 1)) <= t && ((1u << (log_t + 1)) << degs[ps]) <= tile_elems) log_t++;
+    while ((1u << (log_t + 1)) <= t && ((1u << (log_t + 1)) << degs[ps]) <= (wide_pass ? (1u << NTT_WIDE_TILE_LOG) : tile_elems)) log_t++;
     a.log_t = log_t;
     a.tw_lo = tb.tw_lo;
     a.tw_hi = tb.tw_hi;
@@ -624,6 +805,21 @@ int ntt_run(const NttTables& tb, const Fr* in, Fr* out, Fr* scratch, const NttIo
     }();
     const uint32_t tiles_per_col = t / T, total_tiles = tiles_per_col * io.batch;
     const uint32_t pgrid = total_tiles < resident ? total_tiles : resident;
+    if (wide_pass) {
+      // (log_n >= 13 and deg <= 9: a full 2048-element tile always exists)  73.9 KB of dynamic LDS: above the 64-KB default
+      const size_t wlds = ((size_t)1 << NTT_WIDE_TILE_LOG) * 36 + 54 * 4;
+      static const bool attr_ok = []() {
+        const int bytes = (1 << NTT_WIDE_TILE_LOG) * 36 + 54 * 4;
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(&ntt_pass_wide_kernel<9, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess &&
+               hipFuncSetAttribute(reinterpret_cast<const void*>(&ntt_pass_wide_kernel<8, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess &&
+               hipFuncSetAttribute(reinterpret_cast<const void*>(&ntt_pass_wide_kernel<7, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess;
+      }();
+      if (!attr_ok) return -1;
+      if (degs[ps] == 9 && log_t == 2) ntt_pass_wide_kernel<9, 2><<<grid, NTT_WIDE_THREADS, wlds, stream>>>(a);
+      else if (degs[ps] == 8 && log_t == 3) ntt_pass_wide_kernel<8, 3><<<grid, NTT_WIDE_THREADS, wlds, stream>>>(a);
+      else if (degs[ps] == 7 && log_t == 4) ntt_pass_wide_kernel<7, 4><<<grid, NTT_WIDE_THREADS, wlds, stream>>>(a);
+      else return -1;
+    } else
     if (pipe && tile_elems == 512 && degs[ps] == 6 && log_t == 3) ntt_pass_pipe_kernel<6, 3><<<pgrid, NTT_THREADS, lds, stream>>>(a, tiles_per_col, total_tiles);
     else if (pipe && tile_elems == 512 && degs[ps] == 5 && log_t == 4) ntt_pass_pipe_kernel<5, 4><<<pgrid, NTT_THREADS, lds, stream>>>(a, tiles_per_col, total_tiles);
     else if (pipe && tile_elems == 512 && degs[ps] == 4 && log_t == 5) ntt_pass_pipe_kernel<4, 5><<<pgrid, NTT_THREADS, lds, stream>>>(a, tiles_per_col, total_tiles);

@@ -16,8 +16,12 @@ def test_pmc_summaries_parse():
     assert u is not None and 0.5 < u <= 1.0
 
 
-def test_committed_bench_line_has_the_contract_fields():
-    with open(os.path.join(ROOT, "profiles", "r02_bench_create_proof_k18_line_unprofiled.json")) as f:
+import pytest
+
+
+@pytest.mark.parametrize("name", ["r02_bench_create_proof_k18_line_unprofiled.json", "r03_bench_create_proof_k18_line_unprofiled.json"])
+def test_committed_bench_line_has_the_contract_fields(name):
+    with open(os.path.join(ROOT, "profiles", name)) as f:
         d = json.load(f)
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
@@ -32,3 +36,8 @@ def test_committed_bench_line_has_the_contract_fields():
     assert d["cpu_baseline"]["k"] == 18 and d["cpu_baseline"]["sample_small"]["k"] == 16  # the metric's own configuration
     assert d["roofline"]["bound"] == "valu" and "not this run" in d["roofline"]["traffic_source"]
     assert "per_word_callback" in d["generic_rng"] and "unsharded" in d["config3_k20"] and "lanes_3" in d["batched"]
+    if name.startswith("r03"):  # the legs SURVEY 8(d) asks for beside the headline
+        assert {"2^16", "2^18", "2^20", "2^22"} <= set(d["msm_standalone"]) and d["msm_standalone"]["2^18"]["single_mscalar_per_s"] > 100
+        assert d["ntt_ext"]["coeff_to_extended"]["melem_per_s"] > 1000 and d["host_advice"]["proof_equals_device_resident"] is True
+        assert d["batched_k22"]["k"] == 22 and d["batched_k22"]["first_proof_equals_single"] is True and "dense_witness" in d
+        assert d["batched"]["lanes_3"]["reported"].startswith("median") and d["dense_equivalent_mscalar_per_s"] < d["value"]
