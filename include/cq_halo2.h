@@ -354,7 +354,9 @@ int cq_permutation_assembly_copy(uint32_t columns, uint32_t n, uint32_t* mapping
  * the table config and `b0_g1_bound` (n-1 affine points; device pointer if b0_on_device != 0, else
  * host; may be NULL when the circuit has no static lookup, as may `cfg`).
  * Lifetimes: `params`, `cfg` and the static tables must outlive the key (as `ProvingKey<'params>` borrows them in the
- * reference); destroy keys first. */
+ * reference); destroy keys first.  (cq_params_destroy / cq_table_config_destroy called while a key still uses the object
+ * only mark it released -- the last such key frees it -- so a wrong order leaks nothing and touches no freed memory; the
+ * static tables have no such grace.) */
 int cq_pk_create(cq_ctx* ctx, cq_params* params, const cq_circuit* circuit, cq_table_config* cfg,
                  const uint64_t* b0_g1_bound, int b0_on_device, cq_pk** out);
 /* ProvingKey::write / ProvingKey::read, SerdeFormat::RawBytes / RawBytesUnchecked (plonk.rs:349-403).  Layout:

@@ -111,6 +111,10 @@ int cq_table_config_setup_from_toxic_waste(cq_ctx* c, size_t size, const uint64_
 
 void cq_table_config_destroy(cq_table_config* t) {
   if (!t) return;
+  if (t->key_users > 0) {  // a key still uses it: the last one frees it (see cq_params_destroy)
+    t->owner_released = true;
+    return;
+  }
   hipStreamSynchronize(t->ctx->stream);
   msm_unregister_tables(t->ctx, t->g1_lagrange);
   msm_unregister_tables(t->ctx, t->g_lagrange_opening_at_0);
@@ -818,8 +822,10 @@ void cq_pk_destroy(cq_pk* pk) {
     hipFree(p);
   }
   if (pk->counted_users) {
-    pk->params->key_users--;
-    if (pk->table_cfg) pk->table_cfg->key_users--;
+    cq_params* params = pk->params;
+    cq_table_config* cfg = pk->table_cfg;
+    if (--params->key_users == 0 && params->owner_released) cq_params_destroy(params);
+    if (cfg && --cfg->key_users == 0 && cfg->owner_released) cq_table_config_destroy(cfg);
   }
   delete pk;
 }

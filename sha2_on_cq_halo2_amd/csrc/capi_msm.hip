@@ -469,8 +469,15 @@ int cq_params_write_raw(cq_params* p, uint8_t* buf, size_t cap, size_t* written)
   return CQ_OK;
 }
 
+// A proving key refers to the params (and table config) it was built on for as long as it lives -- it counts itself as a
+// user, shares their window tables, restores them when it stops sharding.  The documented order is keys first; a caller
+// (or a garbage collector) that destroys the params first only marks them released, and the last key frees them.
 void cq_params_destroy(cq_params* p) {
   if (!p) return;
+  if (p->key_users > 0) {
+    p->owner_released = true;
+    return;
+  }
   hipStreamSynchronize(p->ctx->stream);
   if (p->g) msm_unregister_tables(p->ctx, p->g);
   if (p->g_lagrange) msm_unregister_tables(p->ctx, p->g_lagrange);

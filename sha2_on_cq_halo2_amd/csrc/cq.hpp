@@ -97,6 +97,7 @@ struct cq_params {
   cq::G1Affine* g;           // [s^i]_1
   cq::G1Affine* g_lagrange;  // [L_i(s)]_1
   uint32_t key_users = 0;    // proving keys built on this object (a sharded key drops the whole-array tables only when alone)
+  bool owner_released = false;  // cq_params_destroy was called while keys still used the object: the last key frees it
 };
 
 // StaticTableConfig (plonk/static_lookup.rs:47-66): Lagrange SRS of the table-sized domain
@@ -107,6 +108,7 @@ struct cq_table_config {
   cq::G1Affine* g1_lagrange = nullptr;
   cq::G1Affine* g_lagrange_opening_at_0 = nullptr;
   uint32_t key_users = 0;
+  bool owner_released = false;  // as for cq_params
 };
 
 // StaticTableValues (plonk/static_lookup.rs:68-75)

@@ -374,3 +374,25 @@ def test_sharded_key_leaves_the_tables_of_shared_srs_objects_alone():
     a.pk.close()                                    # a sharded key that goes away restores what it had dropped
     assert c.msm_table_width(g, n) == 15
     c.close()
+
+
+def test_srs_objects_destroyed_before_their_key():
+    """The documented order is keys first, but a garbage collector (or a careless caller) may destroy the params / table
+    config while a proving key still refers to them: they are then only marked released, the key keeps proving the same
+    bytes, and the last key frees them -- no freed memory is touched in either order."""
+    from sha2_on_cq_halo2_amd import Context
+    from sha2_on_cq_halo2_amd.sha_circuit import ShaCqWorkload
+
+    c = Context(0)
+    a = ShaCqWorkload(c, 10, pairs=2)
+    b = ShaCqWorkload(c, 10, pairs=2, share=a)
+    p0 = a.prove(seed=8)
+    a.params.close()  # while two keys use them
+    a.cfg.close()
+    assert a.prove(seed=8) == p0 and b.prove(seed=8) == p0
+    a.pk.close()
+    assert b.prove(seed=8) == p0
+    b.pk.close()      # the last user: frees the released params and table config
+    fresh = ShaCqWorkload(c, 10, pairs=2)
+    assert fresh.prove(seed=8) == p0
+    c.close()
