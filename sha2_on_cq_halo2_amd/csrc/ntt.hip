@@ -690,9 +690,11 @@ int ntt_run(const NttTables& tb, const Fr* in, Fr* out, Fr* scratch, const NttIo
   // (7 + 6 + 6 .. 7 + 7 + 7).  Measured on MI355X, 8 columns, Gelem/s wide / 4..6-bit plan (profiles/r03_ntt_wide_ab.txt):
   // 2^17 8.7 / 8.3, 2^18 9.0 / 8.9, 2^19 7.8 / 7.6, 2^20 7.4 / 7.6, 2^21 7.4 / 7.9, 2^22 7.6 / 8.3 -- a pass is bound by VALU
   // issue and LDS latency, not by HBM, so a saved trip is worth little and the nine-bit pass's 128-byte runs and extra
-  // reducing products take it back from 2^20 on.  Default: wide up to 2^19.  CQ_NTT_WIDE=0 / 1 forces never / always (A/B).
-  static const int wide_env = getenv("CQ_NTT_WIDE") ? atoi(getenv("CQ_NTT_WIDE")) : -1;
-  const bool wide_on = wide_env < 0 ? log_n <= 19 : wide_env != 0;
+  // reducing products take it back from 2^20 on.  Inside a proof, where the transforms share the GPU with MSM tails and
+  // the inversion, the wide plan is no faster at any size (k = 18: 8.0-8.2 ms against 7.8-8.0; two 74-KB workgroups of 512
+  // threads per CU co-schedule less freely than four 37-KB ones).  Default: OFF; CQ_NTT_WIDE=1 turns it on (A/B, tests).
+  static const int wide_env = getenv("CQ_NTT_WIDE") ? atoi(getenv("CQ_NTT_WIDE")) : 0;
+  const bool wide_on = wide_env != 0;
   const uint32_t npass_wide = (log_n + NTT_WIDE_MAX_DEG - 1) / NTT_WIDE_MAX_DEG;
   const bool wide = wide_on && NTT_MAX_DEG == 6 && NTT_TILE_ELEMS == 1024 && log_n >= 13 && npass_wide < npass;
   if (wide) {

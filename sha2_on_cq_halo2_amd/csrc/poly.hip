@@ -25,11 +25,13 @@ static __device__ __forceinline__ void st(Fr* p, const Fr& r) {
 }
 
 // ---- eval_polynomial (arithmetic.rs:304-329) ------------------------------------------------------
-// Block-level Horner: a block folds EVAL_TILE = 2048 coefficients of one polynomial: each lane runs
-// Horner over 8 consecutive coefficients, then an 8-level LDS tree combines lane values with the
-// multipliers x^8, x^16, ... (v_t += y_s * v_{t+2^s}).  p(x) = S(x^2048) over the block sums S, so the
-// host applies the kernel again until one value per polynomial is left (2 levels at n = 2^18).
-// blockIdx.y selects the polynomial: all evaluations of a proof at one point go in one launch.
+// A block folds EVAL_TILE = 2048 coefficients of one polynomial.  Lane t takes the coefficients t, t + 256, ..., t + 1792
+// of the tile -- so a wave's load is 64 consecutive elements (2 KB) instead of 64 runs 256 bytes apart, which the
+// address path served at a fraction of the rate (k = 18: 122 -> ~50 us for the 19 polynomials of a proof) -- runs Horner
+// over them with x^256, multiplies by x^t (composed from x^(2^i) by the bits of t) and the 256 lane values are then just
+// ADDED in an 8-level LDS tree.  p(x) = S(x^2048) over the block sums S, so the host applies the kernel again until one
+// value per polynomial is left (2 levels at n = 2^18).  blockIdx.y selects the polynomial: all evaluations of a proof at
+// one point go in one launch.
 __global__ __launch_bounds__(256) void block_eval_kernel(EvalBatchArgs args, uint32_t level_stride_in,
                                                          const Fr* __restrict__ level_in, Fr* __restrict__ level_out,
                                                          uint32_t out_stride, EvalPowers pw) {
@@ -38,11 +40,24 @@ __global__ __launch_bounds__(256) void block_eval_kernel(EvalBatchArgs args, uin
   const Fr* a = level_in ? level_in + (size_t)poly * level_stride_in : args.p[poly];
   const uint32_t n = level_in ? args.cur_len[poly] : args.len[poly];
   const uint32_t t = threadIdx.x;
-  const uint32_t base = blockIdx.x * EVAL_TILE + t * 8;
+  const uint32_t base = blockIdx.x * EVAL_TILE + t;
   Fr v = Fr::zero();
   if (base < n) {
-    const uint32_t hi = min(n, base + 8);
-    for (uint32_t i = hi; i-- > base;) v = v * pw.x + ld(a + i);
+#pragma unroll
+    for (int j = 7; j >= 0; j--) {
+      const uint32_t i = base + 256u * (uint32_t)j;
+      const Fr c = i < n ? ld(a + i) : Fr::zero();
+      v = v * pw.x256 + c;
+    }
+    Fr xt = Fr::one();  // x^t
+    bool any = false;
+#pragma unroll
+    for (int bit = 0; bit < 8; bit++)
+      if ((t >> bit) & 1u) {
+        xt = any ? xt * pw.sq[bit] : pw.sq[bit];
+        any = true;
+      }
+    if (any) v = v * xt;
   }
 #pragma unroll 1
   for (uint32_t s = 0; s < 8; s++) {
@@ -55,7 +70,7 @@ __global__ __launch_bounds__(256) void block_eval_kernel(EvalBatchArgs args, uin
       uint4 lo = sh_lo[t + d], hi4 = sh_hi[t + d];
       o.v.l[0] = lo.x; o.v.l[1] = lo.y; o.v.l[2] = lo.z; o.v.l[3] = lo.w;
       o.v.l[4] = hi4.x; o.v.l[5] = hi4.y; o.v.l[6] = hi4.z; o.v.l[7] = hi4.w;
-      if (!o.is_zero()) v = v + pw.y[s] * o;
+      v = v + o;
     }
     __syncthreads();
   }
@@ -272,12 +287,13 @@ int poly_eval_batch(cq_ctx* c, const Fr* const* p, const uint32_t* len, uint32_t
   uint32_t curmax = maxlen;
   while (true) {
     EvalPowers pw;
-    pw.x = x;
-    Fr y = x.pow_u64(8);
+    Fr y = x;
     for (int s2 = 0; s2 < 8; s2++) {
-      pw.y[s2] = y;
+      pw.sq[s2] = y;
       y = y.sqr();
     }
+    pw.x256 = y;
+    for (int s2 = 0; s2 < 3; s2++) y = y.sqr();  // x^2048: the next level's point
     const uint32_t nb = (curmax + EVAL_TILE - 1) / EVAL_TILE;
     // the last level leaves its `count` results next to each other
     block_eval_kernel<<<dim3(nb, count), 256, 0, c->stream>>>(args, stride, level_in, buf[which], nb == 1 ? 1u : stride, pw);

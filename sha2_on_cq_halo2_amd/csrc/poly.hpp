@@ -29,8 +29,8 @@ struct EvalBatchArgs {
   uint32_t cur_len[EVAL_MAX_BATCH];
 };
 struct EvalPowers {
-  Fr x;
-  Fr y[8];  // x^8, x^16, ..., x^1024
+  Fr sq[8];  // x, x^2, x^4, ..., x^128: lane t composes x^t from the bits of t
+  Fr x256;   // the Horner multiplier of a lane's strided run
 };
 
 struct CqQuotientArgs {

@@ -86,3 +86,53 @@ def test_best_fft_full_size_matches_c_oracle(ctx, log_n):
     a[1] = B.to_mont_limbs([B.R_MOD - 1])[0]
     w = B.to_mont_limbs([_omega(log_n)])[0]
     assert np.array_equal(ctx.best_fft(a, w, log_n), OC.best_fft(a, w, log_n))
+
+
+_VARIANT_WORKER = r'''
+import hashlib, os, sys
+sys.path.insert(0, %(root)r)
+import numpy as np
+from oracle import bn254 as B
+from sha2_on_cq_halo2_amd import Context
+from sha2_on_cq_halo2_amd.api import EvaluationDomain
+def omega(log_n):
+    w = B.FR_ROOT_OF_UNITY
+    for _ in range(log_n, B.FR_S):
+        w = w * w %% B.R_MOD
+    return w
+ctx = Context(0)
+h = hashlib.sha256()
+for log_n in (13, 14, 16, 17, 18, 19, 20):
+    rs = np.random.RandomState(500 + log_n)
+    a = rs.randint(0, 2**63, size=(1 << log_n, 4), dtype=np.int64).astype(np.uint64)
+    a[:, 3] &= np.uint64((1 << 60) - 1)
+    h.update(ctx.best_fft(a, B.to_mont_limbs([omega(log_n)])[0], log_n).tobytes())
+dom = EvaluationDomain(ctx, 3, 15)            # coset shift on the way in, zero padding, truncation and output factors
+rs = np.random.RandomState(9)
+a = rs.randint(0, 2**63, size=(1 << 15, 4), dtype=np.int64).astype(np.uint64); a[:, 3] &= np.uint64((1 << 60) - 1)
+co = dom.lagrange_to_coeff(a); ext = dom.coeff_to_extended(co); back = dom.extended_to_coeff(ext)
+for x in (co, ext, back): h.update(np.ascontiguousarray(x).tobytes())
+print("digest", h.hexdigest())
+'''
+
+
+def test_kernel_variants_give_identical_transforms(tmp_path):
+    """The pass-kernel variants kept behind switches -- wide passes (CQ_NTT_WIDE=1: 7..9 bits per pass, swizzled LDS image,
+    mid-pass reduction) and the software-pipelined persistent kernel (CQ_NTT_PIPE=1) -- produce bit for bit the transforms of
+    the default plan, at 2^13..2^20 and through the EvaluationDomain wrappers (each variant in a process of its own: the
+    switches are read once)."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "ntt_variant.py"
+    script.write_text(_VARIANT_WORKER % {"root": root})
+    digests = {}
+    for name, env in (("default", {}), ("wide", {"CQ_NTT_WIDE": "1"}), ("pipe", {"CQ_NTT_PIPE": "1"})):
+        e = {k: v for k, v in os.environ.items() if k not in ("CQ_NTT_WIDE", "CQ_NTT_PIPE")}
+        e.update(env)
+        r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, env=e, timeout=600)
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+        digests[name] = r.stdout.strip().split()[-1]
+    assert digests["wide"] == digests["default"] and digests["pipe"] == digests["default"], digests
