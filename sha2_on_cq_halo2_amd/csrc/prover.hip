@@ -378,7 +378,7 @@ void carve(const cq_pk* pk, Arena& ar, Buffers& b) {
   b.gwc_batch = ar.take(shplonk ? 0 : npts * n);
   b.gwc_wit = ar.take(shplonk ? 0 : npts * n);
   b.shplonk = ar.take(shplonk ? 5 * n + 64 * 8 : 0);  // h, two division buffers, h_x, l_x, low-degree remainders
-  b.t_comp = ar.take(N);
+  b.t_comp = ar.take(0);             // (the compressed table is folded inside cq_round2_prep since round 3)
   b.a_val = ar.take(L * N);
   b.m_fr = ar.take(L * N);
   b.a_scaled = ar.take(wsum * N);
@@ -528,7 +528,7 @@ int create_proof_dev(cq_pk* pk, const uint64_t* const* advice_dev, const uint64_
   Buffers B;
   carve(pk, ar, B);
   Fr *adv = B.adv, *f_lag = B.f_lag, *f_coeff = B.f_coeff, *bpoly = B.bpoly, *random_poly = B.random_poly, *cosets = B.cosets,
-     *h_ext = B.h_ext, *h_coeff = B.h_coeff, *t_comp = B.t_comp, *den = B.den, *a_val = B.a_val, *m_fr = B.m_fr,
+     *h_ext = B.h_ext, *h_coeff = B.h_coeff, *den = B.den, *a_val = B.a_val, *m_fr = B.m_fr,
      *a_scaled = B.a_scaled;
   uint64_t* rng_dev = B.rng_dev;
   uint32_t* m_counts = B.m_counts;
