@@ -125,24 +125,23 @@ static __device__ __forceinline__ void xyzz29_add_affine(XYZZ29& acc, const Affi
     acc = {a.x, a.y, Fq29::one(), Fq29::one()};
     return;
   }
-  const Fq29 u2 = a.x * acc.zz;                // 4
-  const Fq29 s2 = a.y * acc.zzz;               // 4
+  // the independent products go in pairs (Fp29::mul_pair: 17 instructions fewer per product than one at a time)
+  Fq29 u2, s2, pp, rr, ppp, q;
+  Fq29::mul_pair(a.x, acc.zz, a.y, acc.zzz, u2, s2);  // 4, 4
   const Fq29 p = Fq29::sub<8>(u2, acc.x);      // < 10
   const Fq29 r = Fq29::sub<4>(s2, acc.y);      // < 6
-  const Fq29 pp = p.sqr();                     // 100
+  Fq29::sqr_pair(p, r, pp, rr);                // 100, 36
   if (pp.is_zero_mod_p()) {                    // same x: doubling or cancellation
-    if (r.sqr().is_zero_mod_p()) acc = xyzz29_dbl_affine(a);
+    if (rr.is_zero_mod_p()) acc = xyzz29_dbl_affine(a);
     else acc = XYZZ29::identity();
     return;
   }
-  const Fq29 ppp = p * pp;                     // 20
-  const Fq29 q = acc.x * pp;                   // 16
-  const Fq29 x3 = Fq29::sub<6, 31>(r.sqr(), ppp + q + q);               // 36; subtrahend < 6, limbs < 3 * 2^29  ->  x3 < 8
+  Fq29::mul_pair(p, pp, acc.x, pp, ppp, q);    // 20, 16
+  const Fq29 x3 = Fq29::sub<6, 31>(rr, ppp + q + q);                    // subtrahend < 6, limbs < 3 * 2^29  ->  x3 < 8
   const Fq29 y3 = Fq29::mul2(r, Fq29::sub<8>(q, x3), Fq29::neg<4>(acc.y), ppp);  // r (q - x3) - y1 ppp, one reduction: 6 * 10 + 4 * 2 = 68  ->  y3 < 2
   acc.x = x3;
   acc.y = y3;
-  acc.zz = acc.zz * pp;                        // 4
-  acc.zzz = acc.zzz * ppp;                     // 4
+  Fq29::mul_pair(acc.zz, pp, acc.zzz, ppp, acc.zz, acc.zzz);  // 4, 4
 }
 
 // acc += b, complete
@@ -152,26 +151,24 @@ static __device__ __forceinline__ void xyzz29_add(XYZZ29& acc, const XYZZ29& b) 
     acc = b;
     return;
   }
-  const Fq29 u1 = acc.x * b.zz;                // 16
-  const Fq29 u2 = b.x * acc.zz;                // 16
-  const Fq29 s1 = acc.y * b.zzz;               // 8
-  const Fq29 s2 = b.y * acc.zzz;               // 8
+  Fq29 u1, u2, s1, s2, pp, rr, ppp, q, zz, zzz;
+  Fq29::mul_pair(acc.x, b.zz, b.x, acc.zz, u1, u2);      // 16, 16
+  Fq29::mul_pair(acc.y, b.zzz, b.y, acc.zzz, s1, s2);    // 8, 8
   const Fq29 p = Fq29::sub<2>(u2, u1);         // < 4
   const Fq29 r = Fq29::sub<2>(s2, s1);         // < 4
-  const Fq29 pp = p.sqr();                     // 16
+  Fq29::sqr_pair(p, r, pp, rr);                // 16, 16
   if (pp.is_zero_mod_p()) {
-    if (r.sqr().is_zero_mod_p()) acc = xyzz29_dbl(acc);
+    if (rr.is_zero_mod_p()) acc = xyzz29_dbl(acc);
     else acc = XYZZ29::identity();
     return;
   }
-  const Fq29 ppp = p * pp;                     // 8
-  const Fq29 q = u1 * pp;                      // 4
-  const Fq29 x3 = Fq29::sub<6, 31>(r.sqr(), ppp + q + q);              // x3 < 8
+  Fq29::mul_pair(p, pp, u1, pp, ppp, q);       // 8, 4
+  Fq29::mul_pair(acc.zz, b.zz, acc.zzz, b.zzz, zz, zzz);  // 4, 4
+  const Fq29 x3 = Fq29::sub<6, 31>(rr, ppp + q + q);                   // x3 < 8
   const Fq29 y3 = Fq29::mul2(r, Fq29::sub<8>(q, x3), Fq29::neg<2>(s1), ppp);  // 4 * 10 + 2 * 2 = 44  ->  y3 < 2
   acc.x = x3;
   acc.y = y3;
-  acc.zz = acc.zz * b.zz * pp;                 // 4, 4
-  acc.zzz = acc.zzz * b.zzz * ppp;
+  Fq29::mul_pair(zz, pp, zzz, ppp, acc.zz, acc.zzz);     // 4, 4
 }
 
 // Jacobian representative (X ZZ, Y ZZZ, ZZ) in the reference's layout: canonical R = 2^256 Montgomery values

@@ -16,7 +16,21 @@
 // product on load (from_mont256) / store (to_mont256); library-internal arrays (window tables, partial sums)
 // hold the R' form packed into 8 x u32 (values < 2^256 there).
 #pragma once
+#include <type_traits>
 #include "field.hpp"
+
+// acc += a * b as the NEXT link of a chain of v_mad_u64_u32 (mul_pair / sqr_pair below): the empty asm makes the sum
+// opaque, so the compiler cannot re-associate a column's additions (it would sum the products first and bring the
+// carry in with a separate 64-bit addition -- the very instruction the chains are there to save)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define CQ_CHAIN(acc, a, b)       \
+  do {                            \
+    (acc) += (uint64_t)(a) * (b); \
+    asm("" : "+v"(acc));          \
+  } while (0)
+#else
+#define CQ_CHAIN(acc, a, b) ((acc) += (uint64_t)(a) * (b))
+#endif
 
 namespace cq {
 
@@ -181,6 +195,109 @@ struct Fp29 {
     return r;
   }
   __device__ __forceinline__ Fp29 operator*(const Fp29& o) const { return mul(*this, o); }
+  // ---- two independent products at once, column by column ------------------------------------------------------
+  // mul() above is written row by row (c[i + j] += x_i y_j over eighteen column registers): the carry of every column is
+  // a shift and a 64-bit addition, 2 x 17 instructions per product.  Column by column (product scanning) ONE 64-bit
+  // accumulator takes the column's limb products, the reduction's products m_i p_(k-i) of the digits already chosen, its
+  // own digit's m_k p_0, and is shifted down into the next column: every addition is the addend of a v_mad_u64_u32, and
+  // the 17 additions go (222 -> 205 instructions per product).  But such a chain is one long dependence, and hipcc pads a
+  // v_mad_u64_u32 that accumulates in place right behind another one with s_nop (gfx950 hazard recogniser): one product
+  // written that way came out as 1 467 multiply-adds + 1 237 s_nop in the accumulate kernel's addition.  Two independent
+  // products with their links alternating need a sixth of those -- and the group law and the radix-4 butterfly offer their
+  // products in pairs (curve29.hpp, ntt.hip).  Measured on one MI355X, same box (tools/ab_pairs.sh, round 3): accumulate
+  // kernel -2.0 % at k = 18 and -4.5 % at k = 22, NTT +3 %, proofs 7.9 -> 7.75 / 25.2 -> 24.2 / 91.3 -> 88.2 ms.
+  // CQ_MUL_NO_PAIRS falls back to two plain products (the A/B).  Bounds per product exactly as for mul() / sqr(): the
+  // columns hold the same sums.
+  // (compile-time loops: with the asm statements in the body the unroller gives up on ordinary ones)
+  template <int I, int N, class F>
+  static __device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+      f(std::integral_constant<int, I>{});
+      static_for<I + 1, N>(f);
+    }
+  }
+  // the reduction's share of column K and the column's digit, for both chains
+  template <int K>
+  static __device__ __forceinline__ void pair_digit(uint64_t& a1, uint64_t& a2, uint32_t* m1, uint32_t* m2, Fp29& r1, Fp29& r2) {
+    static_for<0, 9>([&](auto I) {
+      constexpr int i = decltype(I)::value, j = K - i;
+      if constexpr (j >= 1 && j <= 8 && i < K) {
+        CQ_CHAIN(a1, m1[i], pl(j));
+        CQ_CHAIN(a2, m2[i], pl(j));
+      }
+    });
+    if constexpr (K < 9) {
+      m1[K] = ((uint32_t)a1 * NINV) & M29;
+      m2[K] = ((uint32_t)a2 * NINV) & M29;
+      CQ_CHAIN(a1, m1[K], pl(0));
+      CQ_CHAIN(a2, m2[K], pl(0));
+    } else {
+      r1.a[K - 9] = (uint32_t)a1 & M29;
+      r2.a[K - 9] = (uint32_t)a2 & M29;
+    }
+    a1 >>= 29;
+    a2 >>= 29;
+  }
+  // r1 = x1 y1, r2 = x2 y2
+  static __device__ __forceinline__ void mul_pair(const Fp29& x1, const Fp29& y1, const Fp29& x2, const Fp29& y2, Fp29& r1, Fp29& r2) {
+#ifdef CQ_MUL_NO_PAIRS
+    r1 = mul(x1, y1);
+    r2 = mul(x2, y2);
+#else
+    uint64_t a1 = 0, a2 = 0;
+    uint32_t m1[9], m2[9];
+    Fp29 o1, o2;  // (the outputs may alias the inputs)
+    static_for<0, 17>([&](auto KK) {
+      constexpr int K = decltype(KK)::value;
+      static_for<0, 9>([&](auto I) {
+        constexpr int i = decltype(I)::value, j = K - i;
+        if constexpr (j >= 0 && j <= 8) {
+          CQ_CHAIN(a1, x1.a[i], y1.a[j]);
+          CQ_CHAIN(a2, x2.a[i], y2.a[j]);
+        }
+      });
+      pair_digit<K>(a1, a2, m1, m2, o1, o2);
+    });
+    o1.a[8] = (uint32_t)a1;
+    o2.a[8] = (uint32_t)a2;
+    r1 = o1;
+    r2 = o2;
+#endif
+  }
+  // r1 = x1^2, r2 = x2^2 (cross products once, against doubled limbs, as in sqr())
+  static __device__ __forceinline__ void sqr_pair(const Fp29& x1, const Fp29& x2, Fp29& r1, Fp29& r2) {
+#if defined(CQ_MUL_NO_PAIRS) || defined(CQ_NO_SQR)
+    r1 = x1.sqr();
+    r2 = x2.sqr();
+#else
+    uint64_t a1 = 0, a2 = 0;
+    uint32_t m1[9], m2[9], d1[9], d2[9];
+    Fp29 o1, o2;
+    CQ_UNROLL for (int i = 0; i < 9; i++) {
+      d1[i] = x1.a[i] << 1;
+      d2[i] = x2.a[i] << 1;
+    }
+    static_for<0, 17>([&](auto KK) {
+      constexpr int K = decltype(KK)::value;
+      static_for<0, 9>([&](auto I) {
+        constexpr int i = decltype(I)::value, j = K - i;
+        if constexpr (j > i && j <= 8) {
+          CQ_CHAIN(a1, x1.a[i], d1[j]);
+          CQ_CHAIN(a2, x2.a[i], d2[j]);
+        }
+        if constexpr (j == i) {
+          CQ_CHAIN(a1, x1.a[i], x1.a[i]);
+          CQ_CHAIN(a2, x2.a[i], x2.a[i]);
+        }
+      });
+      pair_digit<K>(a1, a2, m1, m2, o1, o2);
+    });
+    o1.a[8] = (uint32_t)a1;
+    o2.a[8] = (uint32_t)a2;
+    r1 = o1;
+    r2 = o2;
+#endif
+  }
   // x^2: the 36 cross products once, against doubled limbs (45 multiplies instead of 81).  Limbs < 2^30 as for mul():
   // a column holds at most 4 cross products < 2^61, a square < 2^60 and the reduction's 9 * 2^58 -- below 2^64.
   __device__ __forceinline__ Fp29 sqr() const {

@@ -199,8 +199,10 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(NttPassArgs a) {
       const Fr29 x2 = lds_load29(smem29, E, o2), x3 = lds_load29(smem29, E, o3);
       const Fr29 s02 = x0 + x2, s13 = x1 + x3;  // < 2 B_r p, limbs < 2^30: not normalised (operands of + and sub only)
       Fr29 d02 = sub_level(x0, x2, rnd);        // < 2 B_r p
-      if (dj) d02 = Fr29::mul(d02, lds_load29(tw29, half, dj << rnd));
-      const Fr29 d13 = Fr29::mul(sub_level(x1, x3, rnd), lds_load29(tw29, half, (dj + hb) << rnd));  // < 2 p
+      Fr29 d13 = sub_level(x1, x3, rnd);
+      // (independent products in pairs: Fp29::mul_pair, 17 instructions fewer per product)
+      if (dj) Fr29::mul_pair(d02, lds_load29(tw29, half, dj << rnd), d13, lds_load29(tw29, half, (dj + hb) << rnd), d02, d13);
+      else d13 = Fr29::mul(d13, lds_load29(tw29, half, (dj + hb) << rnd));  // < 2 p
       Fr29 y0 = s02 + s13;                      // < 4 B_r p = B_(r+2) p, limbs < 2^31
       y0.normalise();
       Fr29 y1 = sub_level(s02, s13, rnd + 1);   // < 4 B_r p
@@ -209,8 +211,7 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(NttPassArgs a) {
       Fr29 y3 = sub_level(d02, d13, rnd + 1);   // d13 < 2 p <= 2 B_r p: < 4 B_r p
       if (dj) {
         const Fr29 w2 = lds_load29(tw29, half, dj << (rnd + 1));
-        y1 = Fr29::mul(y1, w2);                 // 4 B_r * 1 <= 128
-        y3 = Fr29::mul(y3, w2);
+        Fr29::mul_pair(y1, w2, y3, w2, y1, y3);  // 4 B_r * 1 <= 128
       }
       lds_store29(smem29, E, o0, y0);
       lds_store29(smem29, E, o1, y1);
@@ -250,28 +251,26 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(NttPassArgs a) {
   // ---- store: output digit i' (bit-reversed LDS row) -> out[((index-k)<<deg) + k + i'*p], through one product ----
   const uint32_t lgp2 = a.lgp + deg;            // the next pass: p' = 2^lgp2, t' = n >> next_deg
   const uint32_t log_t2 = a.log_n - a.next_deg;
-  for (uint32_t e = threadIdx.x; e < E; e += NTT_THREADS) {
+  // Two elements per iteration (e and e + NTT_THREADS): their products -- by the next pass's twiddle, by 1, or by the output
+  // factor -- are independent and go through Fp29::mul_pair.
+  auto prepare = [&](uint32_t e, Fr29& x, Fr29& w, uint32_t& g) -> bool {
+    if (e >= E) return false;
     const uint32_t c = e & (T - 1);
     const uint32_t i = e >> log_t;
     const uint32_t index = index0 + c;
     const uint32_t k = index & (p - 1);
-    const uint32_t g = ((index - k) << deg) + k + i * p;
-    if (g >= a.out_len) continue;
-    const Fr29 x = lds_load29(smem29, E, at(bitrev(i, deg), c));  // < 128 p
-#ifdef CQ_NTT_EXP_NOTW  // timing experiment (wrong results): no twiddle load, no product at the store
-    g_store29(out + g, x, false);
-    continue;
-#endif
+    g = ((index - k) << deg) + k + i * p;
+    if (g >= a.out_len) return false;
+    x = lds_load29(smem29, E, at(bitrev(i, deg), c));  // < 128 p
     if (last) {
       const uint32_t m = (a.flags & NTT_OUT_COSET) ? g % 3 : 0;
-      g_store29(out + g, Fr29::mul(x, lds_load29(cs29 + m * 9, 1, 0)), true);
-      continue;
+      w = lds_load29(cs29 + m * 9, 1, 0);
+      return true;
     }
     // twiddle of the next pass for the element it will read at g: row i2 = g / t', index2 = g mod t',
     // exponent (n >> lgp2 >> next_deg) * (index2 mod 2^lgp2) * i2  < n
     const uint32_t i2 = g >> log_t2, index2 = g & ((1u << log_t2) - 1);
     const uint32_t ex = ((n >> lgp2) >> a.next_deg) * (index2 & ((1u << lgp2) - 1)) * i2;
-    Fr29 w;
     if (!ex) {
       w = const29(CONSTS29<FrP>.one);
     } else if (a.tw_full) {
@@ -281,7 +280,21 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(NttPassArgs a) {
       const uint32_t h = ex >> a.tw_l;
       if (h) w = canon29(Fr29::mul(w, g_load29(a.tw_hi + h)));
     }
-    g_store29(out + g, Fr29::mul(x, w), false);  // 128 * 1
+    return true;
+  };
+  for (uint32_t e = threadIdx.x; e < E; e += 2 * NTT_THREADS) {
+    Fr29 xa = Fr29::zero(), xb = Fr29::zero(), wa = Fr29::zero(), wb = Fr29::zero();
+    uint32_t ga = 0, gb = 0;
+    const bool oka = prepare(e, xa, wa, ga), okb = prepare(e + NTT_THREADS, xb, wb, gb);
+#ifdef CQ_NTT_EXP_NOTW  // timing experiment (wrong results): no product at the store
+    if (oka) g_store29(out + ga, xa, false);
+    if (okb) g_store29(out + gb, xb, false);
+    continue;
+#endif
+    Fr29 ra, rb;
+    Fr29::mul_pair(xa, wa, xb, wb, ra, rb);  // 128 * 1
+    if (oka) g_store29(out + ga, ra, last);  // the last pass leaves canonical values
+    if (okb) g_store29(out + gb, rb, last);
   }
 }
 
