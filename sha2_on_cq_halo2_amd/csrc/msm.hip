@@ -209,7 +209,14 @@ __global__ __launch_bounds__(DIGITS_LDS_THREADS) void msm_part_hist_kernel(const
 }
 
 // exclusive scan of P <= 4096 values in one block: poff[0..P], poff[P] = total
-__global__ __launch_bounds__(1024) void msm_part_scan_kernel(const uint32_t* __restrict__ psize, uint32_t P, uint32_t* __restrict__ poff) {
+// `s1_out` (first pass only): the sub-list length of the accumulate level for THIS launch's entries -- the host picks it from
+// the bound batch x windows x n, but a launch of sparse or small scalars (advice columns of 24-bit limbs on a tenth of the
+// rows, multiplicities) has a fiftieth of that, and its accumulate kernel is then a chain of s1 dependent additions on a
+// fraction of the SIMDs: msm_small_launch_s1 of the entries actually there (an MSM that reads another one's lists counts
+// with that one's), never more than the host's value.
+__global__ __launch_bounds__(1024) void msm_part_scan_kernel(const uint32_t* __restrict__ psize, uint32_t P, uint32_t* __restrict__ poff,
+                                                             const uint64_t* __restrict__ list_src = nullptr, uint32_t batch = 0,
+                                                             uint32_t npart = 0, uint32_t s1_host = 0, uint32_t* __restrict__ s1_out = nullptr) {
   __shared__ uint32_t part[1024];
   const uint32_t per = (P + 1023) / 1024;
   const uint32_t lo = min(threadIdx.x * per, P), hi = min(lo + per, P);
@@ -229,6 +236,18 @@ __global__ __launch_bounds__(1024) void msm_part_scan_kernel(const uint32_t* __r
     run += psize[j];
   }
   if (threadIdx.x == 1023) poff[P] = part[1023];
+  if (s1_out) {
+    __syncthreads();  // poff is complete (this block wrote all of it)
+    if (threadIdx.x == 0) {
+      uint64_t entries = 0;
+      for (uint32_t m = 0; m < batch; m++) {
+        const uint32_t src = (uint32_t)list_src[m];
+        entries += poff[(src + 1) * npart] - poff[src * npart];
+      }
+      const uint32_t s1 = msm_small_launch_s1(entries);  // (the host's value stands for a launch that is not small)
+      *s1_out = entries < (uint64_t)MSM_S1 * MSM_SMALL_LANES && s1 < s1_host ? s1 : s1_host;
+    }
+  }
 }
 
 // exclusive scan of N (128 or 256) histogram bins by the first wave: lane l owns bins l * N/64 .. (l + 1) * N/64 - 1
@@ -537,8 +556,10 @@ static __device__ __forceinline__ uint32_t block_excl_scan256(uint32_t v, uint32
 constexpr uint32_t SCAN_TILE = 2048;  // elements per block (8 per thread)
 
 __global__ __launch_bounds__(256) void msm_scan_reduce_kernel(const uint32_t* __restrict__ cnt, uint32_t Bt, uint32_t nseq, uint32_t s1,
+                                                              const uint32_t* __restrict__ s1_dev /* the launch's own choice, or null */,
                                                               uint32_t* __restrict__ blocksums /*[nseq][nblk]*/) {
   __shared__ uint32_t sh[4];
+  if (s1_dev) s1 = *s1_dev;
   const uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * 8;
   uint32_t c8[8];
   for (int k = 0; k < 8; k++) c8[k] = (base + k < Bt) ? cnt[base + k] : 0;
@@ -578,10 +599,12 @@ __global__ __launch_bounds__(1024) void msm_scan_spine_kernel(uint32_t* __restri
 }
 
 __global__ __launch_bounds__(256) void msm_scan_apply_kernel(const uint32_t* __restrict__ cnt, uint32_t Bt, uint32_t nseq, uint32_t s1,
+                                                             const uint32_t* __restrict__ s1_dev,
                                                              const uint32_t* __restrict__ blocksums,
                                                              uint32_t* __restrict__ off /*[nseq][Bt+1]*/,
                                                              uint32_t* __restrict__ tk /*[nseq-1][Bt]*/) {
   __shared__ uint32_t sh[4];
+  if (s1_dev) s1 = *s1_dev;
   const uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * 8;
   uint32_t c8[8];
   for (int k = 0; k < 8; k++) c8[k] = (base + k < Bt) ? cnt[base + k] : 0;
@@ -893,6 +916,11 @@ MsmLayout::MsmLayout(uint32_t n_, uint32_t c_, uint32_t batch_, bool pre_) : n(n
     uint64_t cap = msm_small_launch_s1((uint64_t)batch * W * n);
     const uint64_t maxlist = pre ? (uint64_t)n * W : n;  // longest possible bucket list
     while (cap < maxlist) { cap *= MSM_S2; levels++; }
+    // a launch that turns out to hold few entries cuts shorter sub-lists (msm_part_scan_kernel): a list is then at most
+    // MSM_SMALL_PARTIALS partial sums long whatever its length
+    uint32_t lv2 = 1;
+    for (uint64_t t = std::min<uint64_t>((maxlist + MSM_S1_MIN - 1) / MSM_S1_MIN, MSM_SMALL_PARTIALS); t > 1; t = (t + MSM_S2 - 1) / MSM_S2) lv2++;
+    levels = std::max(levels, lv2);
   }
   nseq = levels + 1;
   nblk = (Bt + 2047) / 2048;
@@ -919,7 +947,7 @@ MsmLayout::MsmLayout(uint32_t n_, uint32_t c_, uint32_t batch_, bool pre_) : n(n
   off_psize2 = o;  o = up(o + (mid ? (size_t)2 * batch * nfinal : 0) * sizeof(uint32_t));
   off_buckets = o; o = up(o + (size_t)Bt * sizeof(XYZZ));  // counts..buckets zeroed by one memset
   zero_end = o;
-  off_blocksums = o; o = up(o + (size_t)nseq * nblk * sizeof(uint32_t));
+  off_blocksums = o; o = up(o + ((size_t)nseq * nblk + 1) * sizeof(uint32_t));  // + the launch's own s1 (msm_part_scan_kernel)
   off_off = o;     o = up(o + (size_t)nseq * (Bt + 1) * sizeof(uint32_t));
   off_tk = o;      o = up(o + (size_t)levels * Bt * sizeof(uint32_t));
   off_sorted = o;  o = up(o + (size_t)E * sizeof(uint32_t));
@@ -927,7 +955,7 @@ MsmLayout::MsmLayout(uint32_t n_, uint32_t c_, uint32_t batch_, bool pre_) : n(n
   // than MSM_SHORT_MIN items, so at most items/S2 + items/SHORT_MIN + 1 sub-lists
   for (uint32_t k = 0; k < 8; k++) tmax[k] = 0;
   const uint32_t s1_min = msm_small_launch_s1(E);  // MSM_S1 unless the launch is small (msm.hpp)
-  tmax[0] = (E + s1_min - 1) / s1_min + Bt;
+  tmax[0] = std::max<uint64_t>((E + s1_min - 1) / s1_min, std::min<uint64_t>((E + MSM_S1_MIN - 1) / MSM_S1_MIN, MSM_SMALL_PARTIALS)) + Bt;
   for (uint32_t k = 1; k < levels; k++) tmax[k] = tmax[k - 1] / MSM_S2 + tmax[k - 1] / MSM_SHORT_MIN + 1;
   off_part[0] = o;
   o = up(o + (size_t)tmax[0] * sizeof(XYZZ));
@@ -951,6 +979,7 @@ int msm_run(cq_ctx* ctx, const Fr* const* scalars_host_ptrs, const G1Affine* con
   uint32_t* counts = (uint32_t*)(ws + L.off_counts);
   XYZZ* buckets = (XYZZ*)(ws + L.off_buckets);
   uint32_t* blocksums = (uint32_t*)(ws + L.off_blocksums);
+  uint32_t* s1_dev = blocksums + (size_t)L.nseq * L.nblk;  // table mode: the sub-list length the launch settles on
   uint32_t* off = (uint32_t*)(ws + L.off_off);
   uint32_t* tk = (uint32_t*)(ws + L.off_tk);
   uint32_t* sorted = (uint32_t*)(ws + L.off_sorted);
@@ -1028,7 +1057,7 @@ int msm_run(cq_ctx* ctx, const Fr* const* scalars_host_ptrs, const G1Affine* con
 #define CQ_PART_PASS1(CW, NW, LOWT)                                                                                               \
   do {                                                                                                                            \
     msm_part_hist_kernel<CW, NW><<<hgrid, DIGITS_LDS_THREADS, 0, s>>>(d_scalars, d_lens, c, W, L.npart, per_lane, psize);          \
-    msm_part_scan_kernel<<<1, 1024, 0, s>>>(psize, P, poff);                                                                      \
+    msm_part_scan_kernel<<<1, 1024, 0, s>>>(psize, P, poff, d_src, batch, L.npart, s1, s1_dev);                                  \
     msm_part_scatter_kernel<CW, NW, LOWT><<<sgrid, PSC_THREADS, 0, s>>>(d_scalars, d_lens, c, W, L.npart, poff, pcursor, part_pay, \
                                                                         (LOWT*)part_low);                                         \
   } while (0)
@@ -1070,16 +1099,16 @@ int msm_run(cq_ctx* ctx, const Fr* const* scalars_host_ptrs, const G1Affine* con
     if (wide) msm_bucket_count_kernel<PART_BITS_WIDE><<<dim3(F, split), PART_THREADS, 0, s>>>(flow, fpoff, counts);
     else msm_bucket_count_kernel<PART_BITS><<<dim3(F, split), PART_THREADS, 0, s>>>(flow, fpoff, counts);
     if (any_alias) msm_alias_counts_kernel<<<dim3((L.B + 255) / 256, batch), 256, 0, s>>>(counts, d_src, L.B);
-    msm_scan_reduce_kernel<<<L.nblk, 256, 0, s>>>(counts, Bt, L.nseq, s1, blocksums);
+    msm_scan_reduce_kernel<<<L.nblk, 256, 0, s>>>(counts, Bt, L.nseq, s1, s1_dev, blocksums);
     msm_scan_spine_kernel<<<1, 1024, 0, s>>>(blocksums, L.nblk, L.nseq);
-    msm_scan_apply_kernel<<<L.nblk, 256, 0, s>>>(counts, Bt, L.nseq, s1, blocksums, off, tk);
+    msm_scan_apply_kernel<<<L.nblk, 256, 0, s>>>(counts, Bt, L.nseq, s1, s1_dev, blocksums, off, tk);
     if (wide) msm_bucket_place_kernel<PART_BITS_WIDE><<<dim3(F, split), PART_THREADS, 0, s>>>(fpay, flow, fpoff, off0, cursor, sorted);
     else msm_bucket_place_kernel<PART_BITS><<<dim3(F, split), PART_THREADS, 0, s>>>(fpay, flow, fpoff, off0, cursor, sorted);
   } else {
     msm_digits_kernel<<<dim3((n + 255) / 256, batch), 256, 0, s>>>(d_scalars, d_lens, n, c, W, pre ? 1u : 0u, ranks, counts);
-    msm_scan_reduce_kernel<<<L.nblk, 256, 0, s>>>(counts, Bt, L.nseq, s1, blocksums);
+    msm_scan_reduce_kernel<<<L.nblk, 256, 0, s>>>(counts, Bt, L.nseq, s1, nullptr, blocksums);
     msm_scan_spine_kernel<<<1, 1024, 0, s>>>(blocksums, L.nblk, L.nseq);
-    msm_scan_apply_kernel<<<L.nblk, 256, 0, s>>>(counts, Bt, L.nseq, s1, blocksums, off, tk);
+    msm_scan_apply_kernel<<<L.nblk, 256, 0, s>>>(counts, Bt, L.nseq, s1, nullptr, blocksums, off, tk);
     msm_scatter_kernel<<<dim3((n + 255) / 256, batch), 256, 0, s>>>(d_scalars, d_lens, n, c, W, pre ? 1u : 0u, ranks, off0, sorted);
   }
   return 0;

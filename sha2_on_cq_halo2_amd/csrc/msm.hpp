@@ -36,11 +36,14 @@ static_assert(MSM_S1_BIG >= MSM_S1, "the workspace is sized for MSM_S1");
 #endif
 constexpr uint32_t MSM_S1_MIN = 4;
 constexpr uint64_t MSM_SMALL_LANES = CQ_MSM_SMALL_LANES;
-inline uint32_t msm_small_launch_s1(uint64_t entry_bound) {
+__host__ __device__ inline uint32_t msm_small_launch_s1(uint64_t entry_bound) {
   if (entry_bound >= (uint64_t)MSM_S1 * MSM_SMALL_LANES) return MSM_S1;
   const uint64_t s = entry_bound / MSM_SMALL_LANES;
   return (uint32_t)(s < MSM_S1_MIN ? MSM_S1_MIN : s);
 }
+// sub-lists of a launch whose entry COUNT (known on the device only) is small: at most 65536 x (s1 + 1) / s1 <= 1.25 x 65536
+// lanes' worth, plus an MSM that reads another one's lists (counted once more); 3 x 65536 bounds both
+constexpr uint64_t MSM_SMALL_PARTIALS = 3 * MSM_SMALL_LANES;
 constexpr uint32_t MSM_S2 = 64;         // max partial sums summed by one wave (levels >= 2): one load per lane, six shuffle levels
 constexpr uint32_t MSM_SHORT = 64;       // level >= 2 lists up to this long are summed by a lane group when the launch is throughput-bound
 constexpr uint32_t MSM_SHORT_MIN = 16;   // ... and lists up to this long always; the ones in between go to a wave each when they are few
