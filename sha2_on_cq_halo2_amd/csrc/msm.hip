@@ -837,19 +837,24 @@ int msm_precompute_tables(cq_ctx* ctx, const G1Affine* bases, uint32_t n, uint32
 // useful and the kernel was VALU-throughput bound at batch 16; SEG = 64 (depth 2 + 6) for launches of a few sets,
 // which are latency-bound and leave most SIMDs idle anyway.
 template <uint32_t SEG>
-__global__ __launch_bounds__(64) void msm_rowcol_kernel(const XYZZ* __restrict__ buckets, uint32_t M, uint32_t rows, uint32_t cols,
-                                                        XYZZ* __restrict__ sums /*[sets][rows + cols]*/) {
+__global__ __launch_bounds__(64) void msm_rowcol_kernel(const XYZZ* __restrict__ buckets, const uint32_t* __restrict__ t1, uint32_t M,
+                                                        uint32_t rows, uint32_t cols, XYZZ* __restrict__ sums /*[sets][rows + cols]*/) {
   constexpr uint32_t LINES = 64 / SEG;
   const uint32_t set = blockIdx.y, lane = threadIdx.x;
   const uint32_t q = blockIdx.x * LINES + lane / SEG, seg = lane % SEG;  // line: row q or column q - rows
   const XYZZ* Bk = buckets + (size_t)set * M;
+  // a bucket without entries (no level-1 sub-list) was never written -- the workspace's buckets are not cleared, 128 bytes
+  // each: 180 MB per round-2 launch at k >= 20 -- and stands for the identity
+  const uint32_t* Tk = t1 + (size_t)set * M;
   XYZZ29 acc = XYZZ29::identity();
   if (q < rows) {  // R_q = sum_lo B[q][lo]
     const uint32_t per = (cols + SEG - 1) / SEG;
-    for (uint32_t lo = seg * per; lo < min(cols, (seg + 1) * per); lo++) xyzz29_add(acc, load_xyzz29(Bk + (size_t)q * cols + lo));
+    for (uint32_t lo = seg * per; lo < min(cols, (seg + 1) * per); lo++)
+      if (Tk[(size_t)q * cols + lo]) xyzz29_add(acc, load_xyzz29(Bk + (size_t)q * cols + lo));
   } else if (q < rows + cols) {  // C_lo = sum_hi B[hi][lo]
     const uint32_t lo = q - rows, per = (rows + SEG - 1) / SEG;
-    for (uint32_t hi = seg * per; hi < min(rows, (seg + 1) * per); hi++) xyzz29_add(acc, load_xyzz29(Bk + (size_t)hi * cols + lo));
+    for (uint32_t hi = seg * per; hi < min(rows, (seg + 1) * per); hi++)
+      if (Tk[(size_t)hi * cols + lo]) xyzz29_add(acc, load_xyzz29(Bk + (size_t)hi * cols + lo));
   }
 #pragma unroll 1
   for (int delta = SEG / 2; delta >= 1; delta >>= 1) {
@@ -945,8 +950,8 @@ MsmLayout::MsmLayout(uint32_t n_, uint32_t c_, uint32_t batch_, bool pre_) : n(n
   off_cursor = o;  o = up(o + (part_sort ? (size_t)Bt : 0) * sizeof(uint32_t));        // per-bucket fill cursors
   off_psize = o;   o = up(o + (size_t)2 * batch * npart * sizeof(uint32_t));          // partition sizes, cursors
   off_psize2 = o;  o = up(o + (mid ? (size_t)2 * batch * nfinal : 0) * sizeof(uint32_t));
-  off_buckets = o; o = up(o + (size_t)Bt * sizeof(XYZZ));  // counts..buckets zeroed by one memset
-  zero_end = o;
+  zero_end = o;    // counts .. partition cursors are cleared by one memset per launch; the buckets are not (msm_rowcol_kernel)
+  off_buckets = o; o = up(o + (size_t)Bt * sizeof(XYZZ));
   off_blocksums = o; o = up(o + ((size_t)nseq * nblk + 1) * sizeof(uint32_t));  // + the launch's own s1 (msm_part_scan_kernel)
   off_off = o;     o = up(o + (size_t)nseq * (Bt + 1) * sizeof(uint32_t));
   off_tk = o;      o = up(o + (size_t)levels * Bt * sizeof(uint32_t));
@@ -1035,7 +1040,7 @@ int msm_run(cq_ctx* ctx, const Fr* const* scalars_host_ptrs, const G1Affine* con
   // launch between them so that the profiling events and the side-stream hand-over (msm_tail_event) bracket it.
   auto front = [&]() -> int {
   msm_set_ptrs_kernel<<<1, 64, 0, s>>>(sp, bp, stv, lnv, srcv, (const void**)d_scalars, batch);
-  // counts and buckets (identity = all zero) are adjacent: one memset
+  // counts and the sort's cursors are adjacent: one memset
   if (hipMemsetAsync(counts, 0, L.zero_end - L.off_counts, s) != hipSuccess) return -1;
   if (L.part_sort) {
     const uint32_t P = batch * L.npart;
@@ -1148,11 +1153,11 @@ int msm_run(cq_ctx* ctx, const Fr* const* scalars_host_ptrs, const G1Affine* con
   }
   const uint32_t sets = batch * L.Wb;
   if (sets <= 4)
-    msm_rowcol_kernel<64><<<dim3(L.rows + L.cols, sets), 64, 0, s>>>(buckets, M, L.rows, L.cols, pairs);
+    msm_rowcol_kernel<64><<<dim3(L.rows + L.cols, sets), 64, 0, s>>>(buckets, tk, M, L.rows, L.cols, pairs);
   else if (sets <= 12)
-    msm_rowcol_kernel<32><<<dim3((L.rows + L.cols + 1) / 2, sets), 64, 0, s>>>(buckets, M, L.rows, L.cols, pairs);
+    msm_rowcol_kernel<32><<<dim3((L.rows + L.cols + 1) / 2, sets), 64, 0, s>>>(buckets, tk, M, L.rows, L.cols, pairs);
   else
-    msm_rowcol_kernel<16><<<dim3((L.rows + L.cols + 3) / 4, sets), 64, 0, s>>>(buckets, M, L.rows, L.cols, pairs);
+    msm_rowcol_kernel<16><<<dim3((L.rows + L.cols + 3) / 4, sets), 64, 0, s>>>(buckets, tk, M, L.rows, L.cols, pairs);
   msm_weighted_kernel<<<MSM_SET_POINTS * sets, 64, 0, s>>>(pairs, L.rows, L.cols, window_sums_dev);
   return 0;
   };
@@ -1160,26 +1165,38 @@ int msm_run(cq_ctx* ctx, const Fr* const* scalars_host_ptrs, const G1Affine* con
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
-// cols * V + U from the bit-plane sums of msm_weighted_kernel: V = sum_t 2^t R_t, U = sum_t 2^t C_t + C_total
+// cols * V + U from the bit-plane sums of msm_weighted_kernel: V = sum_t 2^t R_t, U = sum_t 2^t C_t + C_total.
+// With cols = 2^7 (every set of 2^14 buckets) the two Horner chains are one: 2^7 V + sum_t 2^t C_t is the Horner over
+// R_6 .. R_0, C_6 .. C_0 -- 13 doublings and 13 additions instead of 19 and 12.
 G1Jac msm_set_value(const G1Jac* planes, uint32_t cols) {
-  G1Jac v = planes[6], u = planes[13];
-  for (int t = 5; t >= 0; t--) {
-    v = jac_add(jac_dbl(v), planes[t]);
-    u = jac_add(jac_dbl(u), planes[7 + t]);
+  G1Jac v = planes[6];
+  for (int t = 5; t >= 0; t--) v = jac_add(jac_dbl(v), planes[t]);
+  if (cols == 128) {
+    for (int t = 6; t >= 0; t--) v = jac_add(jac_dbl(v), planes[7 + t]);
+    return jac_add(v, planes[14]);
   }
+  G1Jac u = planes[13];
+  for (int t = 5; t >= 0; t--) u = jac_add(jac_dbl(u), planes[7 + t]);
   for (uint32_t l = cols; l > 1; l >>= 1) v = jac_dbl(v);
   return jac_add(jac_add(v, u), planes[14]);
 }
 
+// sum_s ( value(set s) + s * M * total(set s) ).  The value of a set is linear in its fifteen points, so the sets' points
+// are added plane by plane first and folded ONCE (15 (Wb - 1) additions + 27 operations instead of 27 Wb: the host's
+// share per 17-bit-window MSM goes from ~155 group operations to ~95 -- at k >= 20 the two largest host gaps of a proof).
 G1Jac msm_fold_sets(const G1Jac* pairs, uint32_t Wb, uint32_t M, uint32_t cols) {
-  G1Jac acc = msm_set_value(pairs, cols);
-  if (Wb == 1) return acc;
+  if (Wb == 1) return msm_set_value(pairs, cols);
+  G1Jac planes[MSM_SET_POINTS];
+  for (uint32_t q = 0; q < MSM_SET_POINTS; q++) {
+    planes[q] = pairs[q];
+    for (uint32_t s = 1; s < Wb; s++) planes[q] = jac_add(planes[q], pairs[(size_t)MSM_SET_POINTS * s + q]);
+  }
+  G1Jac acc = msm_set_value(planes, cols);
   // sum_s s * T_s by suffix sums (T_s: the set's plain total, its last point), then "* M" by doublings
   G1Jac run = G1Jac::identity(), weighted = G1Jac::identity();
   for (uint32_t s = Wb - 1; s >= 1; s--) {
     run = jac_add(run, pairs[(size_t)MSM_SET_POINTS * s + MSM_SET_POINTS - 1]);
     weighted = jac_add(weighted, run);
-    acc = jac_add(acc, msm_set_value(pairs + (size_t)MSM_SET_POINTS * s, cols));
   }
   for (uint32_t l = M; l > 1; l >>= 1) weighted = jac_dbl(weighted);
   return jac_add(acc, weighted);
