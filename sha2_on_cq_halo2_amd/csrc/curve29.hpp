@@ -189,4 +189,85 @@ static __device__ __forceinline__ XYZZ29 xyzz29_shfl_down(const XYZZ29& a, int d
   return r;
 }
 
+// ---- one addition by FOUR lanes ----------------------------------------------------------------------------------
+// The tails of an MSM launch (row / column sums, bit-plane trees) are chains of dependent general additions on a handful
+// of waves: what counts there is the length of ONE addition -- 14 products one after the other for a lone wave, ~5 us --
+// not the work.  But the 14 products are only four deep.  A QUAD (four adjacent lanes) holds a point one coordinate per
+// lane -- lane r of the quad: x, y, zz, zzz for r = 0..3 -- and computes P1 + P2 in four steps of ONE product each, every
+// lane multiplying a different pair of operands it picked up from its neighbours with DPP quad permutes:
+//     step 1   x1 zz2 | zz1 x2 | y1 zzz2 | zzz1 y2          = u1 | u2 | s1 | s2
+//     step 2   p p    | r r    | zz1 zz2 | zzz1 zzz2        p = u2 - u1,  r = s2 - s1
+//     step 3   p pp   | u1 pp  | zz12 pp | --               = ppp | q | zz3 | --
+//     step 4   s1 ppp | r (q - x3) | --  | zzz12 ppp        x3 = rr - ppp - 2 q (in lane 1);  = . | . | -- | zzz3
+//     y3 = r (q - x3) - s1 ppp (lane 1);  result x3 | y3 | zz3 | zzz3
+// ~1 300 instructions against ~2 700, at a quarter of the lanes' throughput -- for launches that leave the SIMDs idle.
+// Same formulas and bounds as xyzz29_add (every lane computes every line; the lanes a line is not meant for hold values
+// that are never used).  Identity operands are selected around; equal or opposite x (doubling, cancellation) falls back
+// to xyzz29_add on the gathered points, for the whole wave when any quad needs it (needs_slow is wave-uniform).
+template <int P0, int P1, int P2, int P3>
+static __device__ __forceinline__ Fq29 quad_perm(const Fq29& a) {
+  Fq29 r;
+  CQ_UNROLL for (int k = 0; k < 9; k++) {
+    r.a[k] = (uint32_t)__builtin_amdgcn_mov_dpp((int)a.a[k], P0 | (P1 << 2) | (P2 << 4) | (P3 << 6), 0xf, 0xf, true);
+    // (opaque: hipcc 7.2 folds the move into the instruction that uses it, and "a' - a''" with two DIFFERENT permutes of
+    // the same register came out with one of them applied to both -- tools/micro/quad_steps_test.hip)
+    asm volatile("" : "+v"(r.a[k]));
+  }
+  return r;
+}
+// one word from lane K of the quad to its four lanes
+template <int K>
+static __device__ __forceinline__ uint32_t quad_bcast(uint32_t v) {
+  uint32_t r = (uint32_t)__builtin_amdgcn_mov_dpp((int)v, K * 0x55, 0xf, 0xf, true);
+  asm volatile("" : "+v"(r));
+  return r;
+}
+static __device__ __forceinline__ Fq29 select29(bool c, const Fq29& a, const Fq29& b) {
+  Fq29 r;
+  CQ_UNROLL for (int k = 0; k < 9; k++) r.a[k] = c ? a.a[k] : b.a[k];
+  return r;
+}
+// F: this quad's point, G: the other point, both one coordinate per lane (x | y | zz | zzz).  Returns F + G in that form.
+static __device__ __forceinline__ Fq29 quad_add(const Fq29& F, const Fq29& G) {
+  const uint32_t role = threadIdx.x & 3u;
+  // identity <=> all limbs of zz (lane 2) are zero
+  uint32_t zf = 0, zg = 0;
+  CQ_UNROLL for (int k = 0; k < 9; k++) {
+    zf |= F.a[k];
+    zg |= G.a[k];
+  }
+  const bool id1 = quad_bcast<2>(zf) == 0;
+  const bool id2 = quad_bcast<2>(zg) == 0;
+  // step 1
+  const Fq29 A1 = quad_perm<0, 2, 1, 3>(F);   // x1 | zz1 | y1 | zzz1
+  const Fq29 B1 = quad_perm<2, 0, 3, 1>(G);   // zz2 | x2 | zzz2 | y2
+  const Fq29 T1 = Fq29::mul(A1, B1);          // u1 | u2 | s1 | s2     (16, 16, 8, 8)
+  // step 2
+  const Fq29 D = Fq29::sub<2>(quad_perm<1, 3, 1, 3>(T1), quad_perm<0, 2, 0, 2>(T1));  // p | r | (p | r), < 4
+  const Fq29 T2 = Fq29::mul(select29(role < 2, D, F), select29(role < 2, D, G));     // pp | rr | zz12 | zzz12   (16, 16, 4, 4)
+  const bool same_x = quad_bcast<0>(T2.is_zero_mod_p() ? 1u : 0u) != 0;
+  // step 3
+  const Fq29 PP = quad_perm<0, 0, 0, 0>(T2);
+  const Fq29 U1 = quad_perm<0, 0, 0, 0>(T1);
+  const Fq29 T3 = Fq29::mul(role == 0 ? D : role == 1 ? U1 : T2, PP);                // ppp | q | zz3 | (zzz12 pp)   (8, 4, 4)
+  // step 4
+  const Fq29 PPP = quad_perm<0, 0, 0, 0>(T3);
+  const Fq29 X3 = Fq29::sub<6, 31>(T2, PPP + T3 + T3);                               // lane 1: rr - ppp - 2 q, < 8
+  const Fq29 W = Fq29::sub<8>(T3, X3);                                               // lane 1: q - x3, < 10
+  const Fq29 S1 = quad_perm<2, 2, 2, 2>(T1);
+  const Fq29 T4 = Fq29::mul(role == 0 ? S1 : role == 1 ? D : T2, role == 0 ? T3 : role == 1 ? W : PPP);  // s1 ppp | r (q - x3) | . | zzz3   (4, 40, ., 8)
+  const Fq29 Y3 = Fq29::sub<2>(T4, quad_perm<0, 0, 0, 0>(T4));                       // lane 1: < 4
+  const Fq29 X3all = quad_perm<1, 1, 1, 1>(X3);  // (every lane must execute a permute: not inside the conditional below)
+  Fq29 R = role == 0 ? X3all : role == 1 ? Y3 : role == 2 ? T3 : T4;
+  const bool needs_slow = same_x && !id1 && !id2;
+  if (__any(needs_slow)) {  // doubling or cancellation somewhere in the wave: the plain formulas on the gathered points
+    XYZZ29 a = {quad_perm<0, 0, 0, 0>(F), quad_perm<1, 1, 1, 1>(F), quad_perm<2, 2, 2, 2>(F), quad_perm<3, 3, 3, 3>(F)};
+    const XYZZ29 b = {quad_perm<0, 0, 0, 0>(G), quad_perm<1, 1, 1, 1>(G), quad_perm<2, 2, 2, 2>(G), quad_perm<3, 3, 3, 3>(G)};
+    xyzz29_add(a, b);
+    const Fq29 S = role == 0 ? a.x : role == 1 ? a.y : role == 2 ? a.zz : a.zzz;
+    R = select29(needs_slow, S, R);
+  }
+  return select29(id2, F, select29(id1, G, R));
+}
+
 }  // namespace cq

@@ -896,6 +896,110 @@ __global__ __launch_bounds__(64) void msm_weighted_kernel(const XYZZ* __restrict
   if (lane == 0) out[(size_t)set * MSM_SET_POINTS + plane] = xyzz29_to_jac(v);
 }
 
+// Row / column sums with FOUR lanes per addition (quad_add), for launches of a few bucket sets: one 256-thread block per
+// line of <= 128 buckets -- quad q takes buckets q and q + 64 of the line (lane r of the quad their coordinate r), then the
+// same butterfly as msm_weighted_quad_kernel: seven additions of ~2.4 us deep instead of 2 + 6 of ~5 us.
+__global__ __launch_bounds__(256) void msm_rowcol_quad_kernel(const XYZZ* __restrict__ buckets, const uint32_t* __restrict__ t1, uint32_t M,
+                                                              uint32_t rows, uint32_t cols, XYZZ* __restrict__ sums /*[sets][rows + cols]*/) {
+  __shared__ uint32_t xs[4][4][9];
+  const uint32_t set = blockIdx.y, q = blockIdx.x;  // line: row q or column q - rows
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, role = threadIdx.x & 3u, quad = threadIdx.x >> 2;
+  const XYZZ* Bk = buckets + (size_t)set * M;
+  const uint32_t* Tk = t1 + (size_t)set * M;
+  const bool is_row = q < rows;
+  const uint32_t len = is_row ? cols : rows;
+  auto load_coord = [&](uint32_t e) {  // coordinate `role` of the line's e-th bucket; identity for a bucket without entries
+    Fq29 r = Fq29::zero();
+    if (e < len) {
+      const size_t idx = is_row ? (size_t)q * cols + e : (size_t)e * cols + (q - rows);
+      if (Tk[idx]) {
+        uint32_t w[8];
+        ld8(reinterpret_cast<const char*>(Bk + idx) + 32 * role, w);
+        r = Fq29::unpack(w);
+      }
+    }
+    return r;
+  };
+  const Fq29 F0 = load_coord(quad), G0 = load_coord(quad + 64);
+  Fq29 F = quad_add(F0, G0);
+  auto other = [&](const Fq29& a, int lanes) {
+    Fq29 r;
+    CQ_UNROLL for (int k = 0; k < 9; k++) r.a[k] = __shfl_xor(a.a[k], lanes, 64);
+    return r;
+  };
+#pragma unroll 1
+  for (int d = 32; d >= 4; d >>= 1) F = quad_add(F, other(F, d));
+  if (lane < 4) {
+    CQ_UNROLL for (int k = 0; k < 9; k++) xs[wave][role][k] = F.a[k];
+  }
+  __syncthreads();
+  if (wave != 0) return;
+  F = Fq29::zero();
+  if (lane < 16) {
+    CQ_UNROLL for (int k = 0; k < 9; k++) F.a[k] = xs[lane >> 2][role][k];
+  }
+#pragma unroll 1
+  for (int d = 8; d >= 4; d >>= 1) F = quad_add(F, other(F, d));
+  // packed form: x below 2^256 needs the reduction (8 p > 2^256); the other coordinates are below 4 p
+  const Fq29 red = F.reduced();
+  if (lane < 4) {
+    uint32_t w[8];
+    (role == 0 ? red : F).pack(w);
+    st8(reinterpret_cast<char*>(sums + (size_t)set * (rows + cols) + q) + 32 * role, w);
+  }
+}
+
+// The same bit-plane sums with FOUR lanes per addition (quad_add, curve29.hpp), for launches of a few bucket sets -- the
+// plain kernel's six tree levels are six dependent general additions of ~5 us each on a lone wave; a quad needs ~2.4.
+// 256 threads = 64 quads per plane: quad q takes the plane's q-th term (lane r of the quad its coordinate r), an XOR
+// butterfly over the 16 quads of a wave (4 levels, every quad ends with the wave's sum), the four waves' sums through
+// LDS, two more levels in wave 0.  Results are the same group elements as msm_weighted_kernel's (sums in another order).
+__global__ __launch_bounds__(256) void msm_weighted_quad_kernel(const XYZZ* __restrict__ sums, uint32_t rows, uint32_t cols,
+                                                                G1Jac* __restrict__ out) {
+  __shared__ uint32_t xs[4][4][9];
+  const uint32_t set = blockIdx.x / MSM_SET_POINTS, plane = blockIdx.x % MSM_SET_POINTS;
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, role = threadIdx.x & 3u, quad = threadIdx.x >> 2;
+  const uint32_t which = plane >= 7 ? 1u : 0u;
+  const XYZZ* X = sums + (size_t)set * (rows + cols) + (which ? rows : 0);
+  const uint32_t count = which ? cols : rows;
+  auto load_coord = [&](uint32_t j) {  // coordinate `role` of X[j]: 32 bytes of the packed form
+    uint32_t w[8];
+    ld8(reinterpret_cast<const char*>(X + j) + 32 * role, w);
+    return Fq29::unpack(w);
+  };
+  Fq29 F = Fq29::zero();
+  if (plane < 14) {
+    const uint32_t t = plane - 7 * which;
+    const uint32_t j = ((quad >> t) << (t + 1)) | (1u << t) | (quad & ((1u << t) - 1u));  // quad-th index with bit t set
+    if (j < count) F = load_coord(j);
+  } else {
+    if (quad < count) F = load_coord(quad);
+    Fq29 G = Fq29::zero();
+    if (quad + 64 < count) G = load_coord(quad + 64);
+    F = quad_add(F, G);
+  }
+  auto other = [&](const Fq29& a, int lanes) {
+    Fq29 r;
+    CQ_UNROLL for (int k = 0; k < 9; k++) r.a[k] = __shfl_xor(a.a[k], lanes, 64);
+    return r;
+  };
+#pragma unroll 1
+  for (int d = 32; d >= 4; d >>= 1) F = quad_add(F, other(F, d));  // 16 quads of the wave -> every quad holds their sum
+  if (lane < 4) {
+    CQ_UNROLL for (int k = 0; k < 9; k++) xs[wave][role][k] = F.a[k];
+  }
+  __syncthreads();
+  if (wave != 0) return;
+  F = Fq29::zero();
+  if (lane < 16) {
+    CQ_UNROLL for (int k = 0; k < 9; k++) F.a[k] = xs[lane >> 2][role][k];
+  }
+#pragma unroll 1
+  for (int d = 8; d >= 4; d >>= 1) F = quad_add(F, other(F, d));
+  const XYZZ29 v = {quad_perm<0, 0, 0, 0>(F), quad_perm<1, 1, 1, 1>(F), quad_perm<2, 2, 2, 2>(F), quad_perm<3, 3, 3, 3>(F)};
+  if (lane == 0) out[(size_t)set * MSM_SET_POINTS + plane] = xyzz29_to_jac(v);
+}
+
 // -------------------------------------------------------------------------------------------------
 uint32_t msm_window_bits(uint32_t n) {
   // Measured on MI355X (tests/perf/msm_sweep.py, uniform scalars).  15 is also the width whose top
@@ -1152,13 +1256,21 @@ int msm_run(cq_ctx* ctx, const Fr* const* scalars_host_ptrs, const G1Affine* con
     else msm_combine_level_kernel<1><<<cs_blocks + wv_blocks, 256, 0, s>>>(part[(k - 1) & 1], t_prev, off_prev, t_cur, off_cur, Bt, cs_blocks, part[k & 1], buckets);
   }
   const uint32_t sets = batch * L.Wb;
-  if (sets <= 4)
+  // (few sets: the launch waits for chains of dependent additions, and four lanes per addition shorten them; many sets: the
+  // SIMDs are busy, and one lane per addition is half the instructions.  CQ_MSM_QUAD=0/1 pins the choice.)
+  static const int quad_env = getenv("CQ_MSM_QUAD") ? atoi(getenv("CQ_MSM_QUAD")) : -1;
+  static const uint32_t quad_rowcol_sets = getenv("CQ_MSM_QUAD_ROWCOL_SETS") ? (uint32_t)atoi(getenv("CQ_MSM_QUAD_ROWCOL_SETS")) : 4u;
+  if (quad_env != 0 && sets <= quad_rowcol_sets)
+    msm_rowcol_quad_kernel<<<dim3(L.rows + L.cols, sets), 256, 0, s>>>(buckets, tk, M, L.rows, L.cols, pairs);
+  else if (sets <= 4)
     msm_rowcol_kernel<64><<<dim3(L.rows + L.cols, sets), 64, 0, s>>>(buckets, tk, M, L.rows, L.cols, pairs);
   else if (sets <= 12)
     msm_rowcol_kernel<32><<<dim3((L.rows + L.cols + 1) / 2, sets), 64, 0, s>>>(buckets, tk, M, L.rows, L.cols, pairs);
   else
     msm_rowcol_kernel<16><<<dim3((L.rows + L.cols + 3) / 4, sets), 64, 0, s>>>(buckets, tk, M, L.rows, L.cols, pairs);
-  msm_weighted_kernel<<<MSM_SET_POINTS * sets, 64, 0, s>>>(pairs, L.rows, L.cols, window_sums_dev);
+  const bool quad = quad_env >= 0 ? quad_env != 0 : sets * MSM_SET_POINTS * 4 <= 1024;
+  if (quad) msm_weighted_quad_kernel<<<MSM_SET_POINTS * sets, 256, 0, s>>>(pairs, L.rows, L.cols, window_sums_dev);
+  else msm_weighted_kernel<<<MSM_SET_POINTS * sets, 64, 0, s>>>(pairs, L.rows, L.cols, window_sums_dev);
   return 0;
   };
   if (ctx->run_graph(sig, 1, tail) != 0) return -1;

@@ -396,3 +396,22 @@ def test_srs_objects_destroyed_before_their_key():
     fresh = ShaCqWorkload(c, 10, pairs=2)
     assert fresh.prove(seed=8) == p0
     c.close()
+
+
+def test_quad_add_matches_lane_serial_addition(tmp_path):
+    """The four-lane addition of the launch tails (curve29.hpp quad_add; msm_rowcol_quad_kernel, msm_weighted_quad_kernel)
+    against xyzz29_add on every kind of operand pair: general, either or both the identity, equal points (doubling),
+    opposite points (cancellation).  Built from tools/micro/quad_add_test.hip with hipcc on the GPU box."""
+    import shutil
+    import subprocess
+
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "quad_add_test")
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-value", "-I", os.path.join(root, "include"),
+                        "-I", os.path.join(root, "sha2_on_cq_halo2_amd", "csrc"), os.path.join(root, "tools", "micro", "quad_add_test.hip"),
+                        "-o", exe], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout + r.stderr[-1000:]
+    assert r.stdout.count("0 of 64 lanes disagree") == 6, r.stdout
