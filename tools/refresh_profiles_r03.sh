@@ -10,8 +10,13 @@ python3 tools/kstats.py $O/timed > $O/r03_bench_timed_region_summary.txt
 cp $O/timed/run_kernel_stats.csv $O/r03_bench_timed_region_kernel_stats.csv
 echo "timed region done"
 # 2. timelines of one proof: k = 18 and k = 20
-rocprofv3 --kernel-trace --output-format csv -d $O/tl -o run -- python3 tools/prove_large.py 18 > $O/tl.log 2>&1
-python3 tools/timeline.py $O/tl/run_kernel_trace.csv 8.6 > $O/r03_timeline_k18_proof.txt
+# (three traces: the one-proof summary of each, cut from its chronological dump; the cleanest is the one committed)
+for i in 1 2 3; do
+  rocprofv3 --kernel-trace --output-format csv -d $O/tl -o run -- python3 tools/prove_large.py 18 > $O/tl.log 2>&1
+  python3 tools/timeline_dump.py $O/tl/run_kernel_trace.csv 9.0 > $O/r03_timeline_k18_chronological_$i.txt
+  python3 tools/timeline_one_proof.py $O/r03_timeline_k18_chronological_$i.txt > $O/r03_timeline_k18_proof_$i.txt
+  [ $i -lt 3 ] && rm -rf $O/tl
+done
 rocprofv3 --kernel-trace --output-format csv -d $O/tl20 -o run -- python3 tools/prove_large.py 20 > $O/tl20.log 2>&1
 python3 tools/timeline.py $O/tl20/run_kernel_trace.csv 26 > $O/r03_timeline_k20_proof.txt
 echo "timelines done"
