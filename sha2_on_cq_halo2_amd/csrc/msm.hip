@@ -1289,7 +1289,10 @@ int msm_run(cq_ctx* ctx, const Fr* const* scalars_host_ptrs, const G1Affine* con
     msm_rowcol_kernel<32><<<dim3((L.rows + L.cols + 1) / 2, sets), 64, 0, s>>>(buckets, tk, M, L.rows, L.cols, pairs);
   else
     msm_rowcol_kernel<16><<<dim3((L.rows + L.cols + 3) / 4, sets), 64, 0, s>>>(buckets, tk, M, L.rows, L.cols, pairs);
-  const bool quad = quad_env >= 0 ? quad_env != 0 : sets * MSM_SET_POINTS * 4 <= 1024;
+  // (measured at k = 18: 21 sets -- 1 260 four-wave blocks -- 88 -> 54 us; from ~2 waves per SIMD on the plain kernel's
+  // half-as-many instructions win)
+  static const uint32_t quad_weighted_waves = getenv("CQ_MSM_QUAD_WEIGHTED_WAVES") ? (uint32_t)atoi(getenv("CQ_MSM_QUAD_WEIGHTED_WAVES")) : 2048u;
+  const bool quad = quad_env >= 0 ? quad_env != 0 : sets * MSM_SET_POINTS * 4 <= quad_weighted_waves;
   if (quad) msm_weighted_quad_kernel<<<MSM_SET_POINTS * sets, 256, 0, s>>>(pairs, L.rows, L.cols, window_sums_dev);
   else msm_weighted_kernel<<<MSM_SET_POINTS * sets, 64, 0, s>>>(pairs, L.rows, L.cols, window_sums_dev);
   return 0;

@@ -107,6 +107,87 @@ __global__ __launch_bounds__(256) void kate_fill_kernel(const Fr* __restrict__ a
   }
 }
 
+// ---- kate_division in three launches (round 3) ------------------------------------------------------------------------
+// The recursion above is nine launches at n = 2^18 (16-coefficient chunks, five levels), each ~16 us of one lane's sixteen
+// dependent products.  Here a 256-thread block owns 256 E consecutive coefficients (E = 4 .. 16 per thread):
+//   A  every thread folds its E coefficients (Horner), a suffix scan over the block with the multiplier z^E (eight steps in
+//      LDS) turns that into tail[t] = sum_{i >= lo_t, i in the block} a_i z^(i - lo_t); tail[0] is the block's total;
+//   C  one block: the carry into every block -- the suffix scan of the totals with the multiplier z^(256 E) -- and the powers
+//      z^(E k), k < 256;
+//   B  thread t starts from  tail[t + 1] + z^(E (255 - t)) carry(block)  = q at the top of its coefficients and writes its E
+//      quotient coefficients.
+// ~20 + 20 + 6 dependent products instead of ~9 x 16.  Same values as the recursion (field arithmetic is exact).
+static __device__ __forceinline__ void sh_put(uint4* lo, uint4* hi, uint32_t t, const Fr& v) {
+  lo[t] = make_uint4(v.v.l[0], v.v.l[1], v.v.l[2], v.v.l[3]);
+  hi[t] = make_uint4(v.v.l[4], v.v.l[5], v.v.l[6], v.v.l[7]);
+}
+static __device__ __forceinline__ Fr sh_get(const uint4* lo, const uint4* hi, uint32_t t) {
+  const uint4 a = lo[t], b = hi[t];
+  Fr r;
+  r.v.l[0] = a.x; r.v.l[1] = a.y; r.v.l[2] = a.z; r.v.l[3] = a.w;
+  r.v.l[4] = b.x; r.v.l[5] = b.y; r.v.l[6] = b.z; r.v.l[7] = b.w;
+  return r;
+}
+// m[s] = (the scan's multiplier)^(2^s), from the host: a step of the scans below is then one product, not two
+struct KateScanPowers {
+  Fr m[10];
+};
+// suffix scan of a linear recurrence over the first `active` threads of a block (a power of two): v_t <- sum_{u >= 0} v_(t+u) m^u
+static __device__ __forceinline__ Fr block_suffix_scan(Fr v, const KateScanPowers& pw, uint32_t active, uint4* lo, uint4* hi) {
+  const uint32_t t = threadIdx.x;
+  uint32_t s = 0;
+#pragma unroll 1
+  for (uint32_t d = 1; d < active; d <<= 1, s++) {
+    sh_put(lo, hi, t, v);
+    __syncthreads();
+    if (t + d < active) v = v + sh_get(lo, hi, t + d) * pw.m[s];
+    __syncthreads();
+  }
+  return v;
+}
+__global__ __launch_bounds__(256) void kate_block_tails_kernel(const Fr* __restrict__ a, uint32_t n, Fr z, uint32_t E, KateScanPowers pw /* of z^E */,
+                                                               Fr* __restrict__ tail /*[blocks][256]*/, Fr* __restrict__ total /*[blocks]*/) {
+  __shared__ uint4 lo[256], hi[256];
+  const uint32_t t = threadIdx.x;
+  const uint32_t base = (blockIdx.x * 256 + t) * E;
+  Fr v = Fr::zero();
+  for (uint32_t k = E; k-- > 0;) v = v * z + (base + k < n ? ld(a + base + k) : Fr::zero());
+  v = block_suffix_scan(v, pw, 256, lo, hi);
+  st(tail + (size_t)blockIdx.x * 256 + t, v);
+  if (t == 0) st(total + blockIdx.x, v);
+}
+// block 0 (`active` threads, a power of two >= nblk): carry[b] = sum_{j > b} total[j] zL^(j - b - 1) (zL = z^(256 E), its
+// powers in pw); block 1: pk[k] = zE^k, k < 256
+__global__ __launch_bounds__(1024) void kate_block_carries_kernel(const Fr* __restrict__ total, uint32_t nblk, uint32_t active, Fr zE,
+                                                                  KateScanPowers pw, Fr* __restrict__ carry, Fr* __restrict__ pk) {
+  __shared__ uint4 lo[1024], hi[1024];
+  const uint32_t t = threadIdx.x;
+  if (blockIdx.x == 1) {
+    if (t < 256) st(pk + t, zE.pow_u64(t));
+    return;
+  }
+  Fr v = t < nblk ? ld(total + t) : Fr::zero();
+  v = block_suffix_scan(v, pw, active, lo, hi);  // inclusive: total[t] + zL total[t + 1] + ..
+  sh_put(lo, hi, t, v);
+  __syncthreads();
+  if (t < nblk) st(carry + t, t + 1 < nblk ? sh_get(lo, hi, t + 1) : Fr::zero());
+}
+__global__ __launch_bounds__(256) void kate_block_fill_kernel(const Fr* __restrict__ a, uint32_t n, Fr z, uint32_t E,
+                                                              const Fr* __restrict__ tail, const Fr* __restrict__ carry,
+                                                              const Fr* __restrict__ pw, Fr* __restrict__ q) {
+  const uint32_t t = threadIdx.x;
+  const uint32_t base = (blockIdx.x * 256 + t) * E;
+  if (base >= n) return;
+  Fr c = ld(pw + (255 - t)) * ld(carry + blockIdx.x);
+  if (t < 255) c = c + ld(tail + (size_t)blockIdx.x * 256 + t + 1);
+  for (uint32_t k = E; k-- > 0;) {
+    const uint32_t i = base + k;
+    if (i >= n) continue;  // (coefficients beyond the end are zero and so is everything above them)
+    c = ld(a + i) + z * c;
+    if (i >= 1) st(q + (i - 1), c);
+  }
+}
+
 // ---- ff::BatchInvert (Montgomery's trick), zeros stay zero -----------------------------------------
 // An inversion is a long dependent chain on one lane (binary extended Euclid, ~750 limb steps; Fermat's ~380
 // dependent products took 0.4 ms), so it is shared by a whole workgroup: 256 lanes x BI_PER_LANE
@@ -348,6 +429,30 @@ int poly_kate_division(cq_ctx* c, const Fr* a, uint32_t n, const Fr& z, Fr* q) {
   if (n == 0) return c->fail(CQ_ERR_ARG, "kate_division of an empty polynomial");
   void* scr;
   int rc;
+  static const bool blocks_off = getenv("CQ_KATE_BLOCKS") && atoi(getenv("CQ_KATE_BLOCKS")) == 0;  // A/B knob
+  if (!blocks_off && n >= 4096 && n <= (1u << 22)) {
+    uint32_t E = 4;
+    while ((uint64_t)1024 * 256 * E < n) E <<= 1;  // at most 1024 blocks (one scan block for their carries)
+    const uint32_t nblk = (n + 256 * E - 1) / (256 * E);
+    const size_t elems = (size_t)nblk * 256 + 2 * (size_t)nblk + 256;
+    if ((rc = c->ensure_scratch(5, elems * sizeof(Fr), &scr)) != CQ_OK) return rc;
+    Fr* tail = (Fr*)scr;
+    Fr* total = tail + (size_t)nblk * 256;
+    Fr* carry = total + nblk;
+    Fr* pw = carry + nblk;
+    const Fr zE = z.pow_u64(E);
+    KateScanPowers pE, pL;
+    pE.m[0] = zE;
+    for (int k = 1; k < 10; k++) pE.m[k] = pE.m[k - 1] * pE.m[k - 1];
+    pL.m[0] = pE.m[8];  // z^(256 E)
+    for (int k = 1; k < 10; k++) pL.m[k] = pL.m[k - 1] * pL.m[k - 1];
+    uint32_t active = 64;
+    while (active < nblk) active <<= 1;
+    kate_block_tails_kernel<<<nblk, 256, 0, c->stream>>>(a, n, z, E, pE, tail, total);
+    kate_block_carries_kernel<<<2, active < 256 ? 256 : active, 0, c->stream>>>(total, nblk, active, zE, pL, carry, pw);
+    kate_block_fill_kernel<<<nblk, 256, 0, c->stream>>>(a, n, z, E, tail, carry, pw, q);
+    return hipGetLastError() == hipSuccess ? CQ_OK : c->fail(CQ_ERR_HIP, "kate launch failed");
+  }
   const size_t elems = 4 * ((size_t)n / POLY_CHUNK + POLY_CHUNK) + 256;
   if ((rc = c->ensure_scratch(5, elems * sizeof(Fr), &scr)) != CQ_OK) return rc;
   rc = kate_rec(c, a, n, z, q, (Fr*)scr, elems);
