@@ -195,6 +195,38 @@ struct Fp29 {
     return r;
   }
   __device__ __forceinline__ Fp29 operator*(const Fp29& o) const { return mul(*this, o); }
+  // ---- sums of products with one reduction ------------------------------------------------------------------------
+  // mac(): c += x y as eighteen 64-bit columns (no reduction); redc(): the Montgomery reduction of such columns (< 2 p
+  // when the summed bounds stay <= 128).  All operands normalised (limbs < 2^29): a column then holds 9 limb products below
+  // 2^58 per product and the reduction's 9 -- up to SIX products fit a reduction (6 x 9 + 9 = 63 < 64).  For the pointwise
+  // kernels over R = 2^256 values (poly.hip): a memory word a R read as limbs IS the R' value of a / 32, so the product of
+  // such a value with a constant given in R' form (the host passes 32 x, canonical) is the memory form of the true product
+  // -- sums of them need no conversion at either end.
+  static __device__ __forceinline__ void mac(uint64_t* c, const Fp29& x, const Fp29& y) {
+    CQ_UNROLL for (int i = 0; i < 9; i++) {
+      CQ_UNROLL for (int j = 0; j < 9; j++) c[i + j] += (uint64_t)x.a[i] * y.a[j];
+    }
+  }
+  static __device__ __forceinline__ Fp29 redc(uint64_t* c) {
+    CQ_UNROLL for (int i = 0; i < 9; i++) {
+      const uint32_t m = ((uint32_t)c[i] * NINV) & M29;
+      CQ_UNROLL for (int j = 0; j < 9; j++) c[i + j] += (uint64_t)m * pl(j);
+      c[i + 1] += c[i] >> 29;
+    }
+    Fp29 r;
+    CQ_UNROLL for (int k = 0; k < 8; k++) {
+      r.a[k] = (uint32_t)c[9 + k] & M29;
+      c[10 + k] += c[9 + k] >> 29;
+    }
+    r.a[8] = (uint32_t)c[17];
+    return r;
+  }
+  // value < 64 p, normalised -> the canonical 8 x u32 words (one product by the field's one, pack, conditional subtraction)
+  __device__ __forceinline__ void to_canonical_words(uint32_t* w) const {
+    const Fp29 r = mul(*this, one());
+    r.pack(w);
+    Fp<P>::cond_sub_p(w, 0);
+  }
   // ---- two independent products at once, column by column ------------------------------------------------------
   // mul() above is written row by row (c[i + j] += x_i y_j over eighteen column registers): the carry of every column is
   // a shift and a 64-bit addition, 2 x 17 instructions per product.  Column by column (product scanning) ONE 64-bit

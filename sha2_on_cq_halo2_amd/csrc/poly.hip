@@ -4,6 +4,7 @@
 // coalesced read and write per element, arithmetic fused so every vector is touched once.
 #include <cstdlib>
 #include "poly.hpp"
+#include "field29.hpp"
 #include <algorithm>
 #include <cstring>
 #include "ctx.hpp"
@@ -18,6 +19,12 @@ static __device__ __forceinline__ Fr ld(const Fr* p) {
   r.v.l[4] = b.x; r.v.l[5] = b.y; r.v.l[6] = b.z; r.v.l[7] = b.w;
   return r;
 }
+static __device__ __forceinline__ void ld8w(const Fr* p, uint32_t* w) {
+  const uint4* q = reinterpret_cast<const uint4*>(p);
+  const uint4 a = q[0], b = q[1];
+  w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w;
+  w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
+}
 static __device__ __forceinline__ void st(Fr* p, const Fr& r) {
   uint4* q = reinterpret_cast<uint4*>(p);
   q[0] = make_uint4(r.v.l[0], r.v.l[1], r.v.l[2], r.v.l[3]);
@@ -25,7 +32,7 @@ static __device__ __forceinline__ void st(Fr* p, const Fr& r) {
 }
 
 // ---- eval_polynomial (arithmetic.rs:304-329) ------------------------------------------------------
-// A block folds EVAL_TILE = 2048 coefficients of one polynomial.  Lane t takes the coefficients t, t + 256, ..., t + 1792
+// A block folds EVAL_TILE coefficients of one polynomial.  Lane t takes the coefficients t, t + 256, ...
 // of the tile -- so a wave's load is 64 consecutive elements (2 KB) instead of 64 runs 256 bytes apart, which the
 // address path served at a fraction of the rate (k = 18: 122 -> ~50 us for the 19 polynomials of a proof) -- runs Horner
 // over them with x^256, multiplies by x^t (composed from x^(2^i) by the bits of t) and the 256 lane values are then just
@@ -43,21 +50,29 @@ __global__ __launch_bounds__(256) void block_eval_kernel(EvalBatchArgs args, uin
   const uint32_t base = blockIdx.x * EVAL_TILE + t;
   Fr v = Fr::zero();
   if (base < n) {
+    // on the lazy 29-bit limbs (field29.hpp): the powers are R' constants, a coefficient is read as it lies in memory, and
+    // the running value stays the memory form of the partial sum -- one 222-instruction product and a limb-wise addition per
+    // coefficient instead of a ~430-instruction one (the kernel was bound by them: 19 polynomials of 2^18 in 117 us)
+    const Fr29 x256 = Fr29::unpack(pw.x256.v.l);
+    Fr29 acc = Fr29::zero();
 #pragma unroll
-    for (int j = 7; j >= 0; j--) {
+    for (int j = (int)(EVAL_TILE / 256) - 1; j >= 0; j--) {
       const uint32_t i = base + 256u * (uint32_t)j;
-      const Fr c = i < n ? ld(a + i) : Fr::zero();
-      v = v * pw.x256 + c;
+      Fr29 cf = Fr29::zero();
+      if (i < n) {
+        uint32_t w[8];
+        ld8w(a + i, w);
+        cf = Fr29::unpack(w);
+      }
+      acc = Fr29::mul(acc, x256) + cf;  // < 3 p, limbs < 2^30
     }
-    Fr xt = Fr::one();  // x^t
-    bool any = false;
+    acc.normalise();
 #pragma unroll
     for (int bit = 0; bit < 8; bit++)
-      if ((t >> bit) & 1u) {
-        xt = any ? xt * pw.sq[bit] : pw.sq[bit];
-        any = true;
-      }
-    if (any) v = v * xt;
+      if ((t >> bit) & 1u) acc = Fr29::mul(acc, Fr29::unpack(pw.sq[bit].v.l));  // x^t from the bits of t
+    uint32_t w[8];
+    acc.to_canonical_words(w);
+    CQ_UNROLL for (int k = 0; k < 8; k++) v.v.l[k] = w[k];
   }
 #pragma unroll 1
   for (uint32_t s = 0; s < 8; s++) {
@@ -267,16 +282,41 @@ __global__ __launch_bounds__(256) void batch_invert_kernel(Fr* __restrict__ a, u
 }
 
 // ---- out[i] = sum_j coeff[j] * p_j[i]  (Polynomial * scalar / + of poly.rs:261-322; theta- and v-folds) ----
+// On the lazy 29-bit limbs (field29.hpp): the coefficients arrive as R' constants (poly_lincomb converts them), a
+// polynomial's value is read as it lies in memory, and up to six products share one reduction -- 19 polynomials cost
+// 19 x 81 multiplies and 4 reductions per element instead of 19 full products of the canonical type (~8 300 -> ~2 500
+// instructions; the kernel was bound by them, not by its 32 bytes per term).
 __global__ __launch_bounds__(256) void lincomb_kernel(LincombArgs args, uint32_t n, Fr* __restrict__ out) {
+  __shared__ uint32_t cf[LINCOMB_MAX][9];
+  for (uint32_t j = threadIdx.x; j < args.count; j += blockDim.x) {
+    const Fr29 c = Fr29::unpack(args.coeff[j].v.l);
+    CQ_UNROLL for (int l = 0; l < 9; l++) cf[j][l] = c.a[l];
+  }
+  __syncthreads();
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  Fr acc = Fr::zero();
-  for (uint32_t j = 0; j < args.count; j++) {
-    const Fr x = (i < args.len[j]) ? ld(args.p[j] + i) : Fr::zero();
-    acc = acc + x * args.coeff[j];
+  Fr29 acc = Fr29::zero();
+  uint64_t col[18];
+  for (uint32_t j0 = 0; j0 < args.count; j0 += 6) {
+    CQ_UNROLL for (int k = 0; k < 18; k++) col[k] = 0;
+    const uint32_t j1 = min(args.count, j0 + 6);
+    for (uint32_t j = j0; j < j1; j++) {
+      if (i >= args.len[j]) continue;
+      uint32_t w[8];
+      ld8w(args.p[j] + i, w);
+      Fr29 c;
+      CQ_UNROLL for (int l = 0; l < 9; l++) c.a[l] = cf[j][l];
+      Fr29::mac(col, Fr29::unpack(w), c);
+    }
+    acc = acc + Fr29::redc(col);  // < 2 p each: at most LINCOMB_MAX / 6 of them
+    acc.normalise();
   }
-  if (i == 0) acc = acc - args.sub_const;  // `&poly - eval` touches the constant term only (poly.rs:327-335)
-  st(out + i, acc);
+  uint32_t w[8];
+  acc.to_canonical_words(w);
+  Fr r;
+  CQ_UNROLL for (int k = 0; k < 8; k++) r.v.l[k] = w[k];
+  if (i == 0) r = r - args.sub_const;  // `&poly - eval` touches the constant term only (poly.rs:327-335)
+  st(out + i, r);
 }
 
 // ---- Fr::random stream: out[i] = from_u512(words[8i..8i+8])  (bn256/fr.rs:159-170) -------------------
@@ -370,11 +410,11 @@ int poly_eval_batch(cq_ctx* c, const Fr* const* p, const uint32_t* len, uint32_t
     EvalPowers pw;
     Fr y = x;
     for (int s2 = 0; s2 < 8; s2++) {
-      pw.sq[s2] = y;
+      pw.sq[s2] = fr_to_r261(y);
       y = y.sqr();
     }
-    pw.x256 = y;
-    for (int s2 = 0; s2 < 3; s2++) y = y.sqr();  // x^2048: the next level's point
+    pw.x256 = fr_to_r261(y);
+    for (uint32_t per = EVAL_TILE / 256; per > 1; per >>= 1) y = y.sqr();  // x^EVAL_TILE: the next level's point
     const uint32_t nb = (curmax + EVAL_TILE - 1) / EVAL_TILE;
     // the last level leaves its `count` results next to each other
     block_eval_kernel<<<dim3(nb, count), 256, 0, c->stream>>>(args, stride, level_in, buf[which], nb == 1 ? 1u : stride, pw);
@@ -383,7 +423,7 @@ int poly_eval_batch(cq_ctx* c, const Fr* const* p, const uint32_t* len, uint32_t
     curmax = nb;
     if (nb == 1) break;
     which ^= 1;
-    x = y;  // x^(8 * 2^8) = x^2048
+    x = y;  // x^EVAL_TILE
   }
   // one plain copy into pinned memory (a strided copy into pageable memory took the host ~100 us)
   void* small;
@@ -470,8 +510,10 @@ int poly_batch_invert(cq_ctx* c, Fr* a, uint32_t n) {
   return hipGetLastError() == hipSuccess ? CQ_OK : c->fail(CQ_ERR_HIP, "batch_invert launch failed");
 }
 
-int poly_lincomb(cq_ctx* c, const LincombArgs& args, uint32_t n, Fr* out) {
+int poly_lincomb(cq_ctx* c, const LincombArgs& args_in, uint32_t n, Fr* out) {
   if (!n) return CQ_OK;
+  LincombArgs args = args_in;
+  for (uint32_t j = 0; j < args.count; j++) args.coeff[j] = fr_to_r261(args_in.coeff[j]);  // (sub_const stays a plain value)
   lincomb_kernel<<<blocks_for(n), 256, 0, c->stream>>>(args, n, out);
   return hipGetLastError() == hipSuccess ? CQ_OK : c->fail(CQ_ERR_HIP, "lincomb launch failed");
 }

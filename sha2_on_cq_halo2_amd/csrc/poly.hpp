@@ -20,15 +20,20 @@ struct LincombArgs {
   uint32_t count;
   Fr sub_const;  // subtracted from coefficient 0
 };
+// x -> the canonical words of 32 x: read as 29-bit limbs that is x in the kernels' R' = 2^261 Montgomery form (field29.hpp)
+inline Fr fr_to_r261(const Fr& x) { return Fr::from_u64(32) * x; }
 
-constexpr uint32_t EVAL_TILE = 2048;      // coefficients folded by one block of block_eval_kernel
+#ifndef CQ_EVAL_TILE
+#define CQ_EVAL_TILE 4096
+#endif
+constexpr uint32_t EVAL_TILE = CQ_EVAL_TILE;  // coefficients folded by one block of block_eval_kernel (a power of two, 256 lanes x EVAL_TILE / 256 each)
 constexpr uint32_t EVAL_MAX_BATCH = 40;   // polynomials per batched evaluation
 struct EvalBatchArgs {
   const Fr* p[EVAL_MAX_BATCH];
   uint32_t len[EVAL_MAX_BATCH];
   uint32_t cur_len[EVAL_MAX_BATCH];
 };
-struct EvalPowers {
+struct EvalPowers {  // (as R' = 2^261 constants: fr_to_r261)
   Fr sq[8];  // x, x^2, x^4, ..., x^128: lane t composes x^t from the bits of t
   Fr x256;   // the Horner multiplier of a lane's strided run
 };
