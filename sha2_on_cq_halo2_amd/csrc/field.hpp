@@ -532,6 +532,8 @@ static constexpr uint64_t FR_ZETA_RAW[4] = {0xb8ca0b2d36636f23ull, 0xcc37a73fec2
 static constexpr uint64_t FR_DELTA_RAW[4] = {0x870e56bbe533e9a2ull, 0x5b5f898e5e963f25ull,
                                              0x64ec26aad4c86e71ull, 0x09226b6e22c6f0caull};
 
+// (r - 1) / 2: canonical values above it stand for negative integers where a field element encodes a small signed one
+static constexpr uint64_t FR_HALF_RAW[4] = {0xa1f0fac9f8000000ull, 0x9419f4243cdcb848ull, 0xdc2822db40c0ac2eull, 0x183227397098d014ull};
 inline Fr fr_from_raw(const uint64_t* raw) {
   return Fr::from_limbs64(raw) * Fr::r2();
 }

@@ -1280,12 +1280,13 @@ int msm_run(cq_ctx* ctx, const Fr* const* scalars_host_ptrs, const G1Affine* con
   // (few sets: the launch waits for chains of dependent additions, and four lanes per addition shorten them; many sets: the
   // SIMDs are busy, and one lane per addition is half the instructions.  CQ_MSM_QUAD=0/1 pins the choice.)
   static const int quad_env = getenv("CQ_MSM_QUAD") ? atoi(getenv("CQ_MSM_QUAD")) : -1;
+  static const uint32_t seg32_sets = getenv("CQ_MSM_ROWCOL_SEG32_SETS") ? (uint32_t)atoi(getenv("CQ_MSM_ROWCOL_SEG32_SETS")) : 12u;
   static const uint32_t quad_rowcol_sets = getenv("CQ_MSM_QUAD_ROWCOL_SETS") ? (uint32_t)atoi(getenv("CQ_MSM_QUAD_ROWCOL_SETS")) : 4u;
   if (quad_env != 0 && sets <= quad_rowcol_sets)
     msm_rowcol_quad_kernel<<<dim3(L.rows + L.cols, sets), 256, 0, s>>>(buckets, tk, M, L.rows, L.cols, pairs);
   else if (sets <= 4)
     msm_rowcol_kernel<64><<<dim3(L.rows + L.cols, sets), 64, 0, s>>>(buckets, tk, M, L.rows, L.cols, pairs);
-  else if (sets <= 12)
+  else if (sets <= seg32_sets)
     msm_rowcol_kernel<32><<<dim3((L.rows + L.cols + 1) / 2, sets), 64, 0, s>>>(buckets, tk, M, L.rows, L.cols, pairs);
   else
     msm_rowcol_kernel<16><<<dim3((L.rows + L.cols + 3) / 4, sets), 64, 0, s>>>(buckets, tk, M, L.rows, L.cols, pairs);

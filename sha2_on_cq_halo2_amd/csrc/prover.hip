@@ -29,6 +29,7 @@
 #include "msm.hpp"
 #include "plonk.hpp"
 #include "prover.hpp"
+#include "glv.hpp"
 #include "xoshiro.hpp"
 
 using namespace cq;
@@ -212,24 +213,6 @@ int shard_any(const cq_pk* pk, bool flag, bool& out) {
   if (arc != CQ_OK) return arc;
   for (uint64_t v : all) out = out || v != 0;
   return CQ_OK;
-}
-
-// k * P on the host (4-bit fixed window over the canonical scalar): used where a commitment is a known linear
-// combination of commitments already computed -- f = sum_j theta^(w-1-j) e_j over plain advice columns gives
-// [f] = sum_j theta^(w-1-j) [e_j], the same group element as the n-term MSM the reference runs.
-G1Jac host_scalar_mul(const G1Jac& p, const Fr& k) {
-  G1Jac table[16];
-  table[0] = G1Jac::identity();
-  table[1] = p;
-  for (int i = 2; i < 16; i++) table[i] = (i & 1) ? jac_add(table[i - 1], p) : jac_dbl(table[i / 2]);
-  const U256 e = k.to_canonical();
-  G1Jac acc = G1Jac::identity();
-  for (int nib = 63; nib >= 0; nib--) {
-    for (int d = 0; d < 4; d++) acc = jac_dbl(acc);
-    const uint32_t v = (e.l[nib >> 3] >> ((nib & 7) * 4)) & 15u;
-    if (v) acc = jac_add(acc, table[v]);
-  }
-  return acc;
 }
 
 // Work for the side stream (ctx.hpp): between begin() and end() every library call that enqueues on `c->stream`

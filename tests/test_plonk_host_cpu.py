@@ -75,3 +75,20 @@ def test_constraint_system_mirror_and_gate_programs():
             else:
                 st.append(st.pop() * constants[arg] % B.R_MOD)
         assert len(st) == 1 and st[0] == PL.expr_eval(g, get)
+
+
+def test_host_glv_scalar_mul_matches_double_and_add(tmp_path):
+    """csrc/glv.hpp: the endomorphism-split, 4-bit-window scalar multiplication the prover uses for the f commitments
+    (k = k1 + k2 lambda, phi(x, y) = (zeta x, y); constants of bn256/curve.rs:69-83, fq.rs ZETA) against plain
+    double-and-add over the host group law, on edge scalars (0, 1, -1, lambda, (r - 1) / 2 and its successor) and 300 random
+    ones; and phi(P) = lambda P itself.  HIP-free: g++ on tests/host/glv_check.cpp."""
+    import os
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "glv_check")
+    r = subprocess.run(["g++", "-std=c++17", "-O2", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(root, "sha2_on_cq_halo2_amd", "csrc"),
+                        os.path.join(root, "tests", "host", "glv_check.cpp"), "-o", exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip() == "ok", r.stdout + r.stderr
