@@ -218,7 +218,7 @@ struct cq_ctx {
     if (parent) return parent->pool();
     if (!pool_) {
       unsigned hw = std::thread::hardware_concurrency();
-      unsigned w = hw > 3 ? (hw - 2 < 6 ? hw - 2 : 6) : 0;
+      unsigned w = hw > 3 ? (hw - 2 < 12 ? hw - 2 : 12) : 0;  // (12: a round-2 launch's twelve bucket sets fold in one go: 53 -> 37 us)
       if (const char* e = getenv("CQ_HOST_THREADS")) w = (unsigned)atoi(e);
       pool_.reset(new cq::HostPool(w));
     }
