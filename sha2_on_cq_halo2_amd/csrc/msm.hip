@@ -41,7 +41,13 @@ namespace cq {
 // ---- pointer tables (per-MSM scalar / base arrays), written from a by-value kernel argument ------
 // `ln`: the length the SORT sees (0 for an MSM whose entry lists are another MSM's, see msm_run); `src`: the MSM whose
 // lists an MSM accumulates from (itself, unless it shares its scalars with an earlier one)
-__global__ void msm_set_ptrs_kernel(MsmPtrs sc, MsmPtrs bs, MsmStrides st, MsmStrides ln, MsmStrides src, const void** dst, uint32_t batch) {
+// The launch's first kernel: the pointer / length tables the later kernels read, and the counts and sort cursors cleared
+// (16-byte stores, grid-stride) -- one launch instead of a 5 us kernel and a 5 us memset at the head of every front.
+__global__ __launch_bounds__(256) void msm_set_ptrs_kernel(MsmPtrs sc, MsmPtrs bs, MsmStrides st, MsmStrides ln, MsmStrides src, const void** dst,
+                                                          uint32_t batch, uint4* __restrict__ zero, size_t zero_quads) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < zero_quads; i += (size_t)gridDim.x * blockDim.x)
+    zero[i] = make_uint4(0, 0, 0, 0);
+  if (blockIdx.x) return;
   const uint32_t t = threadIdx.x;
   if (t < batch) {
     dst[t] = sc.p[t];
@@ -557,7 +563,7 @@ constexpr uint32_t SCAN_TILE = 2048;  // elements per block (8 per thread)
 
 __global__ __launch_bounds__(256) void msm_scan_reduce_kernel(const uint32_t* __restrict__ cnt, uint32_t Bt, uint32_t nseq, uint32_t s1,
                                                               const uint32_t* __restrict__ s1_dev /* the launch's own choice, or null */,
-                                                              uint32_t* __restrict__ blocksums /*[nseq][nblk]*/) {
+                                                              uint32_t* blocksums /*[nseq][nblk]*/, uint32_t* ticket) {
   __shared__ uint32_t sh[4];
   if (s1_dev) s1 = *s1_dev;
   const uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * 8;
@@ -570,31 +576,29 @@ __global__ __launch_bounds__(256) void msm_scan_reduce_kernel(const uint32_t* __
     block_excl_scan256(s, sh, tot);
     if (threadIdx.x == 0) blocksums[(size_t)lv * gridDim.x + blockIdx.x] = tot;
   }
-}
-
-__global__ __launch_bounds__(1024) void msm_scan_spine_kernel(uint32_t* __restrict__ blocksums, uint32_t nblk, uint32_t nseq) {
-  __shared__ uint32_t part[1024];
-  const uint32_t per = (nblk + 1023) / 1024;
+  // The block that finishes LAST turns the tile totals into exclusive offsets (what msm_scan_spine_kernel did in a launch of
+  // its own, ~10 us of a front): a ticket per block behind a device-wide fence; the ticket word lies in the region the
+  // launch's first kernel clears.
+  __shared__ uint32_t last;
+  __threadfence();
+  if (threadIdx.x == 0) last = atomicAdd(ticket, 1u) == gridDim.x - 1 ? 1u : 0u;
+  __syncthreads();
+  if (!last) return;
+  __threadfence();
+  const uint32_t nblk = gridDim.x;
+  const uint32_t per = (nblk + 255) / 256;
   const uint32_t lo = min(threadIdx.x * per, nblk), hi = min(lo + per, nblk);
   for (uint32_t lv = 0; lv < nseq; lv++) {
-    uint32_t* a = blocksums + (size_t)lv * nblk;
+    volatile uint32_t* a = blocksums + (size_t)lv * nblk;
     uint32_t s = 0;
     for (uint32_t j = lo; j < hi; j++) s += a[j];
-    part[threadIdx.x] = s;
-    __syncthreads();
-    for (uint32_t off = 1; off < 1024; off <<= 1) {
-      uint32_t t = threadIdx.x >= off ? part[threadIdx.x - off] : 0;
-      __syncthreads();
-      part[threadIdx.x] += t;
-      __syncthreads();
-    }
-    uint32_t run = part[threadIdx.x] - s;
+    uint32_t tot;
+    uint32_t run = block_excl_scan256(s, sh, tot);
     for (uint32_t j = lo; j < hi; j++) {
       const uint32_t v = a[j];
       a[j] = run;
       run += v;
     }
-    __syncthreads();
   }
 }
 
@@ -1075,7 +1079,8 @@ MsmLayout::MsmLayout(uint32_t n_, uint32_t c_, uint32_t batch_, bool pre_) : n(n
   off_cursor = o;  o = up(o + (part_sort ? (size_t)Bt : 0) * sizeof(uint32_t));        // per-bucket fill cursors
   off_psize = o;   o = up(o + (size_t)2 * batch * npart * sizeof(uint32_t));          // partition sizes, cursors
   off_psize2 = o;  o = up(o + (mid ? (size_t)2 * batch * nfinal : 0) * sizeof(uint32_t));
-  zero_end = o;    // counts .. partition cursors are cleared by one memset per launch; the buckets are not (msm_rowcol_kernel)
+  off_ticket = o;  o = up(o + sizeof(uint32_t));  // msm_scan_reduce_kernel's last-block ticket
+  zero_end = o;    // counts .. ticket are cleared by the launch's first kernel; the buckets are not (msm_rowcol_kernel)
   off_buckets = o; o = up(o + (size_t)Bt * sizeof(XYZZ));
   off_blocksums = o; o = up(o + ((size_t)nseq * nblk + 1) * sizeof(uint32_t));  // + the launch's own s1 (msm_part_scan_kernel)
   off_off = o;     o = up(o + (size_t)nseq * (Bt + 1) * sizeof(uint32_t));
@@ -1109,6 +1114,7 @@ int msm_run(cq_ctx* ctx, const Fr* const* scalars_host_ptrs, const G1Affine* con
   uint32_t* counts = (uint32_t*)(ws + L.off_counts);
   XYZZ* buckets = (XYZZ*)(ws + L.off_buckets);
   uint32_t* blocksums = (uint32_t*)(ws + L.off_blocksums);
+  uint32_t* ticket = (uint32_t*)(ws + L.off_ticket);
   uint32_t* s1_dev = blocksums + (size_t)L.nseq * L.nblk;  // table mode: the sub-list length the launch settles on
   uint32_t* off = (uint32_t*)(ws + L.off_off);
   uint32_t* tk = (uint32_t*)(ws + L.off_tk);
@@ -1164,9 +1170,12 @@ int msm_run(cq_ctx* ctx, const Fr* const* scalars_host_ptrs, const G1Affine* con
   // with a single hipGraphLaunch (BASELINE configs[4]: "hipGraph-captured rounds"); the accumulate kernel stays a plain
   // launch between them so that the profiling events and the side-stream hand-over (msm_tail_event) bracket it.
   auto front = [&]() -> int {
-  msm_set_ptrs_kernel<<<1, 64, 0, s>>>(sp, bp, stv, lnv, srcv, (const void**)d_scalars, batch);
-  // counts and the sort's cursors are adjacent: one memset
-  if (hipMemsetAsync(counts, 0, L.zero_end - L.off_counts, s) != hipSuccess) return -1;
+  {
+    // counts and the sort's cursors are adjacent (and 256-byte aligned): cleared by the same kernel
+    const size_t quads = (L.zero_end - L.off_counts) / sizeof(uint4);
+    const uint32_t blocks = (uint32_t)std::min<size_t>((quads + 255) / 256, 1024);
+    msm_set_ptrs_kernel<<<std::max(blocks, 1u), 256, 0, s>>>(sp, bp, stv, lnv, srcv, (const void**)d_scalars, batch, (uint4*)counts, quads);
+  }
   if (L.part_sort) {
     const uint32_t P = batch * L.npart;
     const uint64_t E = (uint64_t)batch * W * n;
@@ -1229,15 +1238,13 @@ int msm_run(cq_ctx* ctx, const Fr* const* scalars_host_ptrs, const G1Affine* con
     if (wide) msm_bucket_count_kernel<PART_BITS_WIDE><<<dim3(F, split), PART_THREADS, 0, s>>>(flow, fpoff, counts);
     else msm_bucket_count_kernel<PART_BITS><<<dim3(F, split), PART_THREADS, 0, s>>>(flow, fpoff, counts);
     if (any_alias) msm_alias_counts_kernel<<<dim3((L.B + 255) / 256, batch), 256, 0, s>>>(counts, d_src, L.B);
-    msm_scan_reduce_kernel<<<L.nblk, 256, 0, s>>>(counts, Bt, L.nseq, s1, s1_dev, blocksums);
-    msm_scan_spine_kernel<<<1, 1024, 0, s>>>(blocksums, L.nblk, L.nseq);
+    msm_scan_reduce_kernel<<<L.nblk, 256, 0, s>>>(counts, Bt, L.nseq, s1, s1_dev, blocksums, ticket);
     msm_scan_apply_kernel<<<L.nblk, 256, 0, s>>>(counts, Bt, L.nseq, s1, s1_dev, blocksums, off, tk);
     if (wide) msm_bucket_place_kernel<PART_BITS_WIDE><<<dim3(F, split), PART_THREADS, 0, s>>>(fpay, flow, fpoff, off0, cursor, sorted);
     else msm_bucket_place_kernel<PART_BITS><<<dim3(F, split), PART_THREADS, 0, s>>>(fpay, flow, fpoff, off0, cursor, sorted);
   } else {
     msm_digits_kernel<<<dim3((n + 255) / 256, batch), 256, 0, s>>>(d_scalars, d_lens, n, c, W, pre ? 1u : 0u, ranks, counts);
-    msm_scan_reduce_kernel<<<L.nblk, 256, 0, s>>>(counts, Bt, L.nseq, s1, nullptr, blocksums);
-    msm_scan_spine_kernel<<<1, 1024, 0, s>>>(blocksums, L.nblk, L.nseq);
+    msm_scan_reduce_kernel<<<L.nblk, 256, 0, s>>>(counts, Bt, L.nseq, s1, nullptr, blocksums, ticket);
     msm_scan_apply_kernel<<<L.nblk, 256, 0, s>>>(counts, Bt, L.nseq, s1, nullptr, blocksums, off, tk);
     msm_scatter_kernel<<<dim3((n + 255) / 256, batch), 256, 0, s>>>(d_scalars, d_lens, n, c, W, pre ? 1u : 0u, ranks, off0, sorted);
   }

@@ -68,7 +68,7 @@ struct MsmLayout {
   uint32_t n, c, batch, W, Wb, M, B, Bt, levels, nseq, nblk, rows, cols, npart, nfinal, shift1;
   bool pre, part_sort, mid;
   uint64_t tmax[8];
-  size_t off_ptrs, off_ranks, off_poff, off_poff2, off_counts, off_cursor, off_psize, off_psize2, off_buckets, zero_end, off_blocksums,
+  size_t off_ptrs, off_ranks, off_poff, off_poff2, off_counts, off_cursor, off_psize, off_psize2, off_buckets, off_ticket, zero_end, off_blocksums,
       off_off, off_tk, off_sorted, off_part[2], off_pairs, total;
   MsmLayout(uint32_t n_, uint32_t c_, uint32_t batch_, bool pre_ = false);
 };
