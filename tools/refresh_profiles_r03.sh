@@ -13,7 +13,7 @@ echo "timed region done"
 # (three traces: the one-proof summary of each, cut from its chronological dump; the cleanest is the one committed)
 for i in 1 2 3; do
   rocprofv3 --kernel-trace --output-format csv -d $O/tl -o run -- python3 tools/prove_large.py 18 > $O/tl.log 2>&1
-  python3 tools/timeline_dump.py $O/tl/run_kernel_trace.csv 9.0 > $O/r03_timeline_k18_chronological_$i.txt
+  python3 tools/timeline_dump.py $O/tl/run_kernel_trace.csv 14.0 > $O/r03_timeline_k18_chronological_$i.txt
   python3 tools/timeline_one_proof.py $O/r03_timeline_k18_chronological_$i.txt > $O/r03_timeline_k18_proof_$i.txt
   [ $i -lt 3 ] && rm -rf $O/tl
 done
