@@ -138,10 +138,13 @@ static __device__ __forceinline__ void xyzz29_add_affine(XYZZ29& acc, const Affi
   }
   Fq29::mul_pair(p, pp, acc.x, pp, ppp, q);    // 20, 16
   const Fq29 x3 = Fq29::sub<6, 31>(rr, ppp + q + q);                    // subtrahend < 6, limbs < 3 * 2^29  ->  x3 < 8
-  const Fq29 y3 = Fq29::mul2(r, Fq29::sub<8>(q, x3), Fq29::neg<4>(acc.y), ppp);  // r (q - x3) - y1 ppp, one reduction: 6 * 10 + 4 * 2 = 68  ->  y3 < 2
+  // r (q - x3) - y1 ppp with one reduction (6 * 10 + 4 * 2 = 68  ->  y3 < 2), interleaved with zz pp and zzz ppp (4, 4)
+  Fq29 y3, zz3, zzz3;
+  Fq29::mul2_mul_mul(r, Fq29::sub<8>(q, x3), Fq29::neg<4>(acc.y), ppp, acc.zz, pp, acc.zzz, ppp, y3, zz3, zzz3);
   acc.x = x3;
   acc.y = y3;
-  Fq29::mul_pair(acc.zz, pp, acc.zzz, ppp, acc.zz, acc.zzz);  // 4, 4
+  acc.zz = zz3;
+  acc.zzz = zzz3;
 }
 
 // acc += b, complete

@@ -296,6 +296,61 @@ struct Fp29 {
     r2 = o2;
 #endif
   }
+  // r0 = x y + z w (one reduction, as mul2), r1 = a b, r2 = c d: three chains, their links in the order 0 1 0 2 so that no
+  // chain follows itself (the group law's last step: Y3 = R (Q - X3) - Y1 PPP next to ZZ PP and ZZZ PPP)
+  static __device__ __forceinline__ void mul2_mul_mul(const Fp29& x, const Fp29& y, const Fp29& z, const Fp29& w, const Fp29& a, const Fp29& b,
+                                                      const Fp29& c, const Fp29& d, Fp29& r0, Fp29& r1, Fp29& r2) {
+#ifdef CQ_MUL_NO_PAIRS
+    r0 = mul2(x, y, z, w);
+    r1 = mul(a, b);
+    r2 = mul(c, d);
+#else
+    uint64_t a0 = 0, a1 = 0, a2 = 0;
+    uint32_t m0[9], m1[9], m2[9];
+    Fp29 o0, o1, o2;
+    static_for<0, 17>([&](auto KK) {
+      constexpr int K = decltype(KK)::value;
+      static_for<0, 9>([&](auto I) {
+        constexpr int i = decltype(I)::value, j = K - i;
+        if constexpr (j >= 0 && j <= 8) {
+          CQ_CHAIN(a0, x.a[i], y.a[j]);
+          CQ_CHAIN(a1, a.a[i], b.a[j]);
+          CQ_CHAIN(a0, z.a[i], w.a[j]);
+          CQ_CHAIN(a2, c.a[i], d.a[j]);
+        }
+      });
+      static_for<0, 9>([&](auto I) {
+        constexpr int i = decltype(I)::value, j = K - i;
+        if constexpr (j >= 1 && j <= 8 && i < K) {
+          CQ_CHAIN(a0, m0[i], pl(j));
+          CQ_CHAIN(a1, m1[i], pl(j));
+          CQ_CHAIN(a2, m2[i], pl(j));
+        }
+      });
+      if constexpr (K < 9) {
+        m0[K] = ((uint32_t)a0 * NINV) & M29;
+        m1[K] = ((uint32_t)a1 * NINV) & M29;
+        m2[K] = ((uint32_t)a2 * NINV) & M29;
+        CQ_CHAIN(a0, m0[K], pl(0));
+        CQ_CHAIN(a1, m1[K], pl(0));
+        CQ_CHAIN(a2, m2[K], pl(0));
+      } else {
+        o0.a[K - 9] = (uint32_t)a0 & M29;
+        o1.a[K - 9] = (uint32_t)a1 & M29;
+        o2.a[K - 9] = (uint32_t)a2 & M29;
+      }
+      a0 >>= 29;
+      a1 >>= 29;
+      a2 >>= 29;
+    });
+    o0.a[8] = (uint32_t)a0;
+    o1.a[8] = (uint32_t)a1;
+    o2.a[8] = (uint32_t)a2;
+    r0 = o0;
+    r1 = o1;
+    r2 = o2;
+#endif
+  }
   // r1 = x1^2, r2 = x2^2 (cross products once, against doubled limbs, as in sqr())
   static __device__ __forceinline__ void sqr_pair(const Fp29& x1, const Fp29& x2, Fp29& r1, Fp29& r2) {
 #if defined(CQ_MUL_NO_PAIRS) || defined(CQ_NO_SQR)
