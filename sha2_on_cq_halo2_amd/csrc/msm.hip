@@ -735,7 +735,7 @@ __global__ __launch_bounds__(MSM_ACC_THREADS) void msm_accumulate_kernel(
 // first test.  The two halves write different buckets and do not depend on each other: one launch instead of two
 // keeps the level's latency at the longer of the two chains.
 template <uint32_t Q>
-__global__ __launch_bounds__(256) void msm_combine_level_kernel(
+__global__ __launch_bounds__(256, 3) void msm_combine_level_kernel(
     const XYZZ* __restrict__ prev, const uint32_t* __restrict__ t_prev, const uint32_t* __restrict__ off_prev,
     const uint32_t* __restrict__ t_cur, const uint32_t* __restrict__ off_cur, uint32_t Bt, uint32_t short_blocks,
     XYZZ* __restrict__ partial, XYZZ* __restrict__ buckets) {
