@@ -58,9 +58,14 @@ static inline void glv_small(const Fr& v, uint64_t* mag, bool& neg) {
   mag[0] = w[0];
   mag[1] = w[1];
 }
-inline G1Jac host_scalar_mul(const G1Jac& p, const Fr& k) {
+// the split of k and, per half, the 4-bit-window chain over 128 bits: half 0 = k1 P, half 1 = k2 phi(P); their sum is k P.
+// (Two halves so that two worker threads can share one multiplication: host_scalar_mul_half.)
+struct GlvSplit {
+  uint64_t m[2][2];
+  bool neg[2];
+};
+inline GlvSplit glv_split(const Fr& k) {
   static const Fr lambda = fr_from_raw(GLV_LAMBDA_RAW), minus_b1 = fr_from_raw(GLV_MINUS_B1), b2 = fr_from_raw(GLV_B2);
-  static const Fq zeta = Fq::from_limbs64(GLV_ZETA_RAW) * Fq::r2();
   uint64_t kw[4], c1w[4], c2w[4];
   const U256 kc = k.to_canonical();
   for (int i = 0; i < 4; i++) kw[i] = (uint64_t)kc.l[2 * i] | ((uint64_t)kc.l[2 * i + 1] << 32);
@@ -69,26 +74,44 @@ inline G1Jac host_scalar_mul(const G1Jac& p, const Fr& k) {
   const Fr c1 = fr_from_raw(c1w), c2 = fr_from_raw(c2w);
   const Fr k2 = c1 * minus_b1 - c2 * b2;  // -(c1 b1 + c2 b2)
   const Fr k1 = k - k2 * lambda;
-  uint64_t m1[2], m2[2];
-  bool n1, n2;
-  glv_small(k1, m1, n1);
-  glv_small(k2, m2, n2);
-  // 1..15 times P and phi(P) (x scaled by zeta), with the signs of k1 / k2 folded in
-  G1Jac t1[16], t2[16];
-  t1[0] = t2[0] = G1Jac::identity();
-  t1[1] = p;
-  for (int i = 2; i < 16; i++) t1[i] = (i & 1) ? jac_add(t1[i - 1], p) : jac_dbl(t1[i / 2]);
+  GlvSplit sp;
+  glv_small(k1, sp.m[0], sp.neg[0]);
+  glv_small(k2, sp.m[1], sp.neg[1]);
+  return sp;
+}
+// 1..15 times P (half 0) or phi(P) (half 1: x scaled by zeta), the sign of the half's scalar folded in
+inline void glv_table(const G1Jac& p, const GlvSplit& sp, int half, G1Jac* t) {
+  static const Fq zeta = Fq::from_limbs64(GLV_ZETA_RAW) * Fq::r2();
+  t[0] = G1Jac::identity();
+  t[1] = p;
+  for (int i = 2; i < 16; i++) t[i] = (i & 1) ? jac_add(t[i - 1], p) : jac_dbl(t[i / 2]);
   for (int i = 1; i < 16; i++) {
-    t2[i] = t1[i];
-    t2[i].x = t2[i].x * zeta;
-    if (n2) t2[i].y = t2[i].y.neg();
-    if (n1) t1[i].y = t1[i].y.neg();
+    if (half) t[i].x = t[i].x * zeta;
+    if (sp.neg[half]) t[i].y = t[i].y.neg();
   }
+}
+inline G1Jac host_scalar_mul_half(const G1Jac& p, const Fr& k, int half) {
+  const GlvSplit sp = glv_split(k);
+  G1Jac t[16];
+  glv_table(p, sp, half, t);
   G1Jac acc = G1Jac::identity();
   for (int nib = 31; nib >= 0; nib--) {
     for (int d = 0; d < 4; d++) acc = jac_dbl(acc);
-    const uint32_t v1 = (uint32_t)(m1[nib >> 4] >> ((nib & 15) * 4)) & 15u;
-    const uint32_t v2 = (uint32_t)(m2[nib >> 4] >> ((nib & 15) * 4)) & 15u;
+    const uint32_t v = (uint32_t)(sp.m[half][nib >> 4] >> ((nib & 15) * 4)) & 15u;
+    if (v) acc = jac_add(acc, t[v]);
+  }
+  return acc;
+}
+inline G1Jac host_scalar_mul(const G1Jac& p, const Fr& k) {
+  const GlvSplit sp = glv_split(k);
+  G1Jac t1[16], t2[16];
+  glv_table(p, sp, 0, t1);
+  glv_table(p, sp, 1, t2);
+  G1Jac acc = G1Jac::identity();
+  for (int nib = 31; nib >= 0; nib--) {  // one chain of doublings for both halves (Straus)
+    for (int d = 0; d < 4; d++) acc = jac_dbl(acc);
+    const uint32_t v1 = (uint32_t)(sp.m[0][nib >> 4] >> ((nib & 15) * 4)) & 15u;
+    const uint32_t v2 = (uint32_t)(sp.m[1][nib >> 4] >> ((nib & 15) * 4)) & 15u;
     if (v1) acc = jac_add(acc, t1[v1]);
     if (v2) acc = jac_add(acc, t2[v2]);
   }

@@ -35,7 +35,9 @@ int main() {
   for (int i = 0; i < 5; i++) p = jac_add(jac_dbl(p), jac_from_affine(g));  // some other point
   int bad = 0;
   auto check = [&](const Fr& k) {
-    if (!same_point(host_scalar_mul(p, k), plain_mul(p, k))) bad++;
+    const G1Jac ref = plain_mul(p, k);
+    if (!same_point(host_scalar_mul(p, k), ref)) bad++;
+    if (!same_point(jac_add(host_scalar_mul_half(p, k, 0), host_scalar_mul_half(p, k, 1)), ref)) bad++;
   };
   check(Fr::zero());
   check(Fr::one());
