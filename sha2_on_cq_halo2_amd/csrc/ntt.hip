@@ -180,9 +180,11 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(NttPassArgs a) {
 #else
   constexpr uint32_t R4 = DEG / 2, LEVELS = DEG;  // (no radix-4 steps for the generic shape, DEG = 0)
 #endif
-#pragma unroll
-  for (uint32_t st = 0; st < R4; st++) {
-    const uint32_t rnd = 2 * st;
+  // (a compile-time loop: with the paired products' asm statements in the body `#pragma unroll` gives up, and the steps'
+  // level bounds, root strides and LDS offsets must stay immediates)
+  Fr29::static_for<0, (int)R4>([&](auto ST) {
+    constexpr uint32_t st = (uint32_t) decltype(ST)::value;
+    constexpr uint32_t rnd = 2 * st;
     const uint32_t bit = half >> rnd;
     // group (blk, dj), dj < bit / 2: rows r0 = 2 blk bit + dj, r1 = r0 + bit / 2, r2 = r0 + bit, r3 = r2 + bit / 2.
     // Level rnd pairs (r0, r2) with root index dj and (r1, r3) with dj + bit / 2; level rnd + 1 pairs (r0, r1) and
@@ -219,7 +221,7 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(NttPassArgs a) {
       lds_store29(smem29, E, o3, y3);
     }
     __syncthreads();
-  }
+  });
 #pragma unroll
   for (uint32_t rnd = 2 * R4; rnd < (DYN ? 6u : LEVELS); rnd++) {  // generic shape: every level; odd DEG: the last one
     if (DYN && rnd >= deg) break;
