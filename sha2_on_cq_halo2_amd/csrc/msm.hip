@@ -765,12 +765,16 @@ __global__ __launch_bounds__(256, 3) void msm_combine_level_kernel(
     if (mine && sub == 0) store_xyzz29(buckets + g, acc);
     return;
   }
+  // (The slots are few -- usually none -- but their BOUND, which is all the host knows, is in the millions at k >= 20: the
+  // wave half is a capped number of blocks that stride over the slots, not one block per four possible slots; the empty
+  // blocks alone were ~0.3 ms of a k = 20 proof and ~1 ms at k = 22.)
   const uint32_t lane = threadIdx.x & 63;
-  const uint32_t j = (blockIdx.x - short_blocks) * (blockDim.x >> 6) + (threadIdx.x >> 6);  // wave-uniform
-  if (j >= slots) return;
+  const uint32_t nwaves = (gridDim.x - short_blocks) * (blockDim.x >> 6);
+#pragma unroll 1
+  for (uint32_t j = (blockIdx.x - short_blocks) * (blockDim.x >> 6) + (threadIdx.x >> 6); j < slots; j += nwaves) {  // wave-uniform
   const uint32_t g = owner_of(off_cur, Bt, j);
   const uint32_t tp = t_prev[g];
-  if (tp <= limit) return;  // a lane group of the other half owns this list (throughput-bound launch)
+  if (tp <= limit) continue;  // a lane group of the other half owns this list (throughput-bound launch)
   const uint32_t r = j - off_cur[g];
   const uint32_t lo = off_prev[g] + r * MSM_S2;
   const uint32_t hi = min(off_prev[g] + tp, lo + MSM_S2);
@@ -803,6 +807,7 @@ __global__ __launch_bounds__(256, 3) void msm_combine_level_kernel(
     uint32_t w[8];
     (role == 0 ? red : F).pack(w);
     st8(reinterpret_cast<char*>(t_cur[g] == 1 ? buckets + g : partial + j) + 32 * role, w);
+  }
   }
 }
 
@@ -1278,7 +1283,7 @@ int msm_run(cq_ctx* ctx, const Fr* const* scalars_host_ptrs, const G1Affine* con
     // ping-pong: level k+1 reads part[(k-1)&1], writes part[k&1]
     const uint32_t q = Bt <= (1u << 18) ? 4u : Bt <= (1u << 19) ? 2u : 1u;  // lanes per bucket, see the kernel
     const uint32_t cs_blocks = (uint32_t)(((uint64_t)Bt * q + 255) / 256);
-    const uint32_t wv_blocks = (uint32_t)((L.tmax[k] + 3) / 4);
+    const uint32_t wv_blocks = (uint32_t)std::min<uint64_t>((L.tmax[k] + 3) / 4, MSM_COMBINE_WAVE_BLOCKS);
     if (q == 4) msm_combine_level_kernel<4><<<cs_blocks + wv_blocks, 256, 0, s>>>(part[(k - 1) & 1], t_prev, off_prev, t_cur, off_cur, Bt, cs_blocks, part[k & 1], buckets);
     else if (q == 2) msm_combine_level_kernel<2><<<cs_blocks + wv_blocks, 256, 0, s>>>(part[(k - 1) & 1], t_prev, off_prev, t_cur, off_cur, Bt, cs_blocks, part[k & 1], buckets);
     else msm_combine_level_kernel<1><<<cs_blocks + wv_blocks, 256, 0, s>>>(part[(k - 1) & 1], t_prev, off_prev, t_cur, off_cur, Bt, cs_blocks, part[k & 1], buckets);

@@ -51,6 +51,7 @@ constexpr uint32_t MSM_SHORT_MIN = 16;   // ... and lists up to this long always
 #define CQ_MSM_WAVE_BUDGET 4096
 #endif
 constexpr uint32_t MSM_WAVE_BUDGET = CQ_MSM_WAVE_BUDGET;  // "few": at most this many wave slots in the level (4 per SIMD)
+constexpr uint32_t MSM_COMBINE_WAVE_BLOCKS = 2048;  // blocks of the combine levels' wave half (8 192 waves striding over the slots)
 constexpr uint32_t MSM_MAX_BATCH = 32;  // MSMs per launch
 constexpr uint32_t MSM_SET_POINTS = 15; // points a bucket set leaves for the host: 7 + 7 bit-plane sums and a total (msm_set_value)
 
