@@ -98,6 +98,39 @@ __global__ void ntt_table_to29_kernel(Fr* t, uint32_t count) {
   g_store29(t + j, Fr29::mul(g_load29(t + j), const29(CONSTS29<FrP>.from256)), true);
 }
 
+#ifdef CQ_NTT_TRACE  // diagnostic build (tools/ntt_wg_trace.py): every workgroup of a pass logs where and when it ran
+__device__ uint64_t g_ntt_trace[4 * 65536];
+__device__ uint32_t g_ntt_trace_n;
+static __device__ __forceinline__ uint32_t ntt_trace_begin() {
+  uint32_t slot = 0;
+  if (threadIdx.x == 0) {
+    slot = atomicAdd(&g_ntt_trace_n, 1u) & 65535u;
+    uint32_t hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    g_ntt_trace[4 * slot] = wall_clock64();
+    g_ntt_trace[4 * slot + 2] = ((uint64_t)xcc << 32) | hw;
+    g_ntt_trace[4 * slot + 3] = ((uint64_t)blockIdx.y << 32) | blockIdx.x;
+  }
+  return slot;
+}
+static __device__ __forceinline__ void ntt_trace_end(uint32_t slot) {
+  __syncthreads();
+  if (threadIdx.x == 0) g_ntt_trace[4 * slot + 1] = wall_clock64();
+}
+extern "C" int cq_debug_ntt_trace(uint64_t* out, uint32_t cap) {  // returns the number of records, resets the log
+  uint32_t n = 0;
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_ntt_trace_n), 4) != hipSuccess) return -1;
+  if (n > cap) n = cap;
+  if (n > 65536) n = 65536;
+  if (n && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ntt_trace), (size_t)n * 32) != hipSuccess) return -1;
+  const uint32_t z = 0;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_ntt_trace_n), &z, 4) != hipSuccess) return -1;
+  return (int)n;
+}
+#endif
+
 static_assert(NTT_MAX_DEG <= 6, "sub_level: B_r = 2^(r+1) <= 64");
 static __device__ __forceinline__ uint32_t bitrev(uint32_t x, uint32_t bits) {
   return bits ? (__brev(x) >> (32 - bits)) : 0;
@@ -108,6 +141,9 @@ static __device__ __forceinline__ uint32_t bitrev(uint32_t x, uint32_t bits) {
 template <uint32_t DEG, uint32_t LOG_T>
 __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(NttPassArgs a) {
   extern __shared__ uint32_t smem29[];
+#ifdef CQ_NTT_TRACE
+  const uint32_t trace_slot = ntt_trace_begin();
+#endif
   constexpr bool DYN = DEG == 0;
   const uint32_t deg = DYN ? a.deg : DEG, log_t = DYN ? a.log_t : LOG_T;
   const uint32_t D = 1u << deg;
@@ -298,6 +334,9 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(NttPassArgs a) {
     if (oka) g_store29(out + ga, ra, last);  // the last pass leaves canonical values
     if (okb) g_store29(out + gb, rb, last);
   }
+#ifdef CQ_NTT_TRACE
+  ntt_trace_end(trace_slot);
+#endif
 }
 
 // ---- wide passes: 7, 8 or 9 bits per pass ------------------------------------------------------------------------------
