@@ -1283,7 +1283,9 @@ int msm_run(cq_ctx* ctx, const Fr* const* scalars_host_ptrs, const G1Affine* con
     // ping-pong: level k+1 reads part[(k-1)&1], writes part[k&1]
     const uint32_t q = Bt <= (1u << 18) ? 4u : Bt <= (1u << 19) ? 2u : 1u;  // lanes per bucket, see the kernel
     const uint32_t cs_blocks = (uint32_t)(((uint64_t)Bt * q + 255) / 256);
-    const uint32_t wv_blocks = (uint32_t)std::min<uint64_t>((L.tmax[k] + 3) / 4, MSM_COMBINE_WAVE_BLOCKS);
+    // (CQ_MSM_COMBINE_WAVE_BLOCKS: tests shrink the cap so that small launches stride too)
+    static const uint32_t wave_cap = getenv("CQ_MSM_COMBINE_WAVE_BLOCKS") ? (uint32_t)std::max(1, atoi(getenv("CQ_MSM_COMBINE_WAVE_BLOCKS"))) : MSM_COMBINE_WAVE_BLOCKS;
+    const uint32_t wv_blocks = (uint32_t)std::min<uint64_t>((L.tmax[k] + 3) / 4, wave_cap);
     if (q == 4) msm_combine_level_kernel<4><<<cs_blocks + wv_blocks, 256, 0, s>>>(part[(k - 1) & 1], t_prev, off_prev, t_cur, off_cur, Bt, cs_blocks, part[k & 1], buckets);
     else if (q == 2) msm_combine_level_kernel<2><<<cs_blocks + wv_blocks, 256, 0, s>>>(part[(k - 1) & 1], t_prev, off_prev, t_cur, off_cur, Bt, cs_blocks, part[k & 1], buckets);
     else msm_combine_level_kernel<1><<<cs_blocks + wv_blocks, 256, 0, s>>>(part[(k - 1) & 1], t_prev, off_prev, t_cur, off_cur, Bt, cs_blocks, part[k & 1], buckets);

@@ -415,3 +415,50 @@ def test_quad_add_matches_lane_serial_addition(tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout + r.stderr[-1000:]
     assert r.stdout.count("0 of 64 lanes disagree") == 6, r.stdout
+
+
+def test_combine_wave_half_strides_over_more_slots_than_waves():
+    """The combine levels' wave half is a capped grid whose waves stride over the sub-list slots (msm.hip: one block per four
+    POSSIBLE slots was a million empty blocks per level at k = 22).  With the default cap of 2048 blocks only launches of
+    2^20 equal scalars and more have more slots than waves, so a child process shrinks the cap to ONE block
+    (CQ_MSM_COMBINE_WAVE_BLOCKS=1: four waves) and sums columns whose entries all fall into one bucket per window -- a
+    constant column, a 0/1 column, a column of two values -- next to a uniform one: hundreds of slots per level, each wave
+    takes dozens of them.  Compared with the C restatement of `best_multiexp` (arithmetic.rs:132-159)."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import os, sys
+import numpy as np
+sys.path.insert(0, %r)
+from oracle import bn254 as B
+from oracle import cbind as OC
+from tests.util import random_points
+from sha2_on_cq_halo2_amd import Context
+ctx = Context(0)
+n = 1 << 15
+rs = np.random.RandomState(77)
+pts = np.tile(B.points_to_mont_limbs(random_points(512, 577)), (n // 512, 1))
+one = lambda seed: np.tile(B.to_mont_limbs([B.fr_random(B.Xoshiro256ss(seed))]), (n, 1))
+const = one(9)
+bits = B.to_mont_limbs([int(v) for v in rs.randint(0, 2, size=n)])
+two = np.where(rs.randint(0, 2, size=(n, 1)).astype(bool), const, one(10))
+uni = rs.randint(0, 2**63, size=(n, 4), dtype=np.int64).astype(np.uint64); uni[:, 3] &= np.uint64((1 << 60) - 1)
+vecs = [np.ascontiguousarray(v) for v in (const, bits, two, uni)]
+dpts = ctx.to_device(pts)
+ctx.msm_precompute(dpts.ptr, n)
+dev = [ctx.to_device(v) for v in vecs]
+res = ctx.msm_batch_dev([d.ptr for d in dev], dpts.ptr, n)
+for j, v in enumerate(vecs):
+    assert np.array_equal(OC.g1_to_affine(res[j]), OC.g1_to_affine(OC.best_multiexp(v, pts))), "MSM %%d differs" %% j
+ctx2 = Context(0)  # and without tables (the caller's array, converted on the fly)
+d2 = ctx2.to_device(pts)
+for j, v in enumerate(vecs[:3]):
+    got = ctx2.best_multiexp_dev(ctx2.to_device(v), d2, n)
+    assert np.array_equal(OC.g1_to_affine(got), OC.g1_to_affine(OC.best_multiexp(v, pts))), "plain MSM %%d differs" %% j
+print("ok")
+""" % root
+    env = dict(os.environ, CQ_MSM_COMBINE_WAVE_BLOCKS="1")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout[-2000:] + r.stderr[-3000:]
