@@ -38,6 +38,7 @@ CPU_BASELINE_K = 18  # the metric's own configuration, proven once by the CPU re
 CPU_BASELINE_SMALL_K = 16  # kept beside it: BASELINE configs[1] (16 SHA blocks)
 PMC_TRAFFIC_FILE = "profiles/r03_pmc_traffic_k18_proof.json"
 PMC_SQ_FILE = "profiles/r03_pmc_sq_accumulate_k18.json"
+PMC_SQ_NTT_FILE = "profiles/r03_pmc_sq_ntt_k18.json"
 PMC_FALLBACK = {"profiles/r03_pmc_traffic_k18_proof.json": "profiles/r02_pmc_traffic_k18_proof.json",
                 "profiles/r03_pmc_sq_accumulate_k18.json": "profiles/r02_pmc_sq_accumulate_k18.json"}
 
@@ -306,6 +307,10 @@ def _finish_line(out, ctx, wl, args, k, acc_ms, acc_calls, ntt_ms, ntt_calls, ms
             "frac": ntt_ach / HBM_PEAK_GBS,
             "traffic": pmc_traffic("ntt_pass_kernel<6u, 4u>") if k == 18 else None,  # the 2^18 transform's passes
             "traffic_source": f"{_pmc_path(PMC_TRAFFIC_FILE)[1]} (committed rocprofv3 --pmc pass, not this run)" if k == 18 else None,
+            # what actually bounds a pass: VALU issue (0.95 between a launch's first and last workgroup completions, ~0.71
+            # over a two-generation launch: profiles/r03_ntt_workgroup_timeline.txt), not HBM
+            "valu_issue_utilisation_pmc": pmc_valu_issue_ntt() if k == 18 else None,
+            "valu_source": f"{PMC_SQ_NTT_FILE} (committed rocprofv3 --pmc pass over the stand-alone transform, not this run)" if k == 18 else None,
             "error": sa_error,
             "launches": int(sa_calls),
             "melem_per_s": sa_elems / (sa_ms / 1e3) / 1e6 if sa_ms > 0 else 0.0,
@@ -686,6 +691,17 @@ def pmc_valu_issue():
         # the mean over the traced proofs' launches of that kind: one launch's ratio can read a few 1e-3 above 1 because
         # the cycle count is GRBM_GUI_ACTIVE averaged over the eight XCDs, which do not all run for the whole launch
         return min(1.0, sum(same) / len(same))
+    except Exception:
+        return None
+
+
+def pmc_valu_issue_ntt():
+    """VALU issue utilisation of a 2^18 x 8 NTT pass launch (mean over the committed pass's launches); None if missing."""
+    try:
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), PMC_SQ_NTT_FILE)) as f:
+            rows = json.load(f)["kernels"]["ntt_pass_kernel"]
+        vals = [r["valu_issue_utilisation"] for r in rows if r["valu_issue_utilisation"]]
+        return sum(vals) / len(vals)
     except Exception:
         return None
 

@@ -14,6 +14,8 @@ def test_pmc_summaries_parse():
     assert bench.pmc_traffic("ntt_pass_kernel<6u, 4u>") > 1e7
     u = bench.pmc_valu_issue()
     assert u is not None and 0.5 < u <= 1.0
+    v = bench.pmc_valu_issue_ntt()
+    assert v is not None and 0.5 < v < 0.9  # a two-generation launch: fill and drain cost a quarter of it
 
 
 import pytest
