@@ -66,6 +66,7 @@ static int run(cq_ctx* c, uint32_t log_n, const Fr& omega, const Fr* in, Fr* out
   void* scr;
   if ((rc = c->ensure_scratch(c->ntt_scratch_slot, (size_t)2 * io.batch * n * sizeof(Fr), &scr)) != CQ_OK) return rc;
   io.prof = c;
+  io.critical = c->ntt_scratch_slot == 0;  // not the side stream's slot (ctx.hpp): the caller waits for this transform
   if (ntt_run(*tb, in, out, (Fr*)scr, io, c->stream) != 0) return c->fail(CQ_ERR_HIP, "ntt launch failed");
   return CQ_OK;
 }

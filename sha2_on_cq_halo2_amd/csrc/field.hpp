@@ -16,6 +16,14 @@
 #include <hip/hip_runtime.h>
 #define CQ_HD __host__ __device__ __forceinline__
 #define CQ_UNROLL _Pragma("unroll")
+// First statement of the kernels a proof WAITS for while a throughput kernel of the other stream shares their SIMDs (the
+// launch tails, the sort's small kernels, the batch inversion, the main stream's transforms): s_setprio raises the wave's
+// issue priority, so their dependent chains run at the speed they have alone and the co-resident NTT waves take the issue
+// slots that are left -- stream priorities only order the DISPATCH of workgroups.  -DCQ_CRIT_PRIO=0 is the A/B switch.
+#ifndef CQ_CRIT_PRIO
+#define CQ_CRIT_PRIO 3
+#endif
+#define CQ_CRITICAL_WAVES() __builtin_amdgcn_s_setprio(CQ_CRIT_PRIO)
 #else
 #define CQ_HD inline
 #define CQ_UNROLL

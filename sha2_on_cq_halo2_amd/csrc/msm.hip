@@ -45,6 +45,7 @@ namespace cq {
 // (16-byte stores, grid-stride) -- one launch instead of a 5 us kernel and a 5 us memset at the head of every front.
 __global__ __launch_bounds__(256) void msm_set_ptrs_kernel(MsmPtrs sc, MsmPtrs bs, MsmStrides st, MsmStrides ln, MsmStrides src, const void** dst,
                                                           uint32_t batch, uint4* __restrict__ zero, size_t zero_quads) {
+  CQ_CRITICAL_WAVES();
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < zero_quads; i += (size_t)gridDim.x * blockDim.x)
     zero[i] = make_uint4(0, 0, 0, 0);
   if (blockIdx.x) return;
@@ -189,6 +190,7 @@ template <uint32_t CW, uint32_t NW>
 __global__ __launch_bounds__(DIGITS_LDS_THREADS) void msm_part_hist_kernel(const Fr* const* __restrict__ scalars,
                                                                            const uint64_t* __restrict__ lens, uint32_t c_, uint32_t nwin_,
                                                                            uint32_t npart, uint32_t per_lane, uint32_t* __restrict__ psize) {
+  CQ_CRITICAL_WAVES();
   __shared__ uint32_t hist[PART_MAX];
   const uint32_t c = CW ? CW : c_, nwin = CW ? NW : nwin_;
   const uint32_t shift = part_shift_of(c);
@@ -223,6 +225,7 @@ __global__ __launch_bounds__(DIGITS_LDS_THREADS) void msm_part_hist_kernel(const
 __global__ __launch_bounds__(1024) void msm_part_scan_kernel(const uint32_t* __restrict__ psize, uint32_t P, uint32_t* __restrict__ poff,
                                                              const uint64_t* __restrict__ list_src = nullptr, uint32_t batch = 0,
                                                              uint32_t npart = 0, uint32_t s1_host = 0, uint32_t* __restrict__ s1_out = nullptr) {
+  CQ_CRITICAL_WAVES();
   __shared__ uint32_t part[1024];
   const uint32_t per = (P + 1023) / 1024;
   const uint32_t lo = min(threadIdx.x * per, P), hi = min(lo + per, P);
@@ -296,6 +299,7 @@ __global__ __launch_bounds__(PSC_THREADS) void msm_part_scatter_kernel(const Fr*
                                                                        uint32_t npart, const uint32_t* __restrict__ poff,
                                                                        uint32_t* __restrict__ pcursor, uint32_t* __restrict__ part_pay,
                                                                        LowT* __restrict__ part_low) {
+  CQ_CRITICAL_WAVES();
   __shared__ uint2 stage[PSC_THREADS * (CW ? NW : PSC_MAX_WIN)];
   __shared__ uint32_t hist[PART_MAX], lstart[PART_MAX], gbase[PART_MAX];
   const uint32_t c = CW ? CW : c_, nwin = CW ? NW : nwin_;
@@ -360,6 +364,7 @@ __global__ __launch_bounds__(PSC_THREADS) void msm_part_scatter_kernel(const Fr*
 template <uint32_t PB>
 __global__ __launch_bounds__(PART_THREADS) void msm_bucket_count_kernel(const uint8_t* __restrict__ part_low, const uint32_t* __restrict__ poff,
                                                                         uint32_t* __restrict__ counts) {
+  CQ_CRITICAL_WAVES();
   __shared__ uint32_t hist[1u << PB];
   const uint32_t pid = blockIdx.x, t = threadIdx.x;
   const uint32_t lo = poff[pid], hi = poff[pid + 1];
@@ -373,6 +378,7 @@ __global__ __launch_bounds__(PART_THREADS) void msm_bucket_count_kernel(const ui
 
 // an MSM that accumulates from another one's lists (same scalar vector) takes a copy of its bucket counts
 __global__ __launch_bounds__(256) void msm_alias_counts_kernel(uint32_t* __restrict__ counts, const uint64_t* __restrict__ list_src, uint32_t B) {
+  CQ_CRITICAL_WAVES();
   const uint32_t m = blockIdx.y, src = (uint32_t)list_src[m];
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (src != m && i < B) counts[(size_t)m * B + i] = counts[(size_t)src * B + i];
@@ -385,6 +391,7 @@ __global__ __launch_bounds__(PART_THREADS) void msm_bucket_place_kernel(const ui
                                                                         const uint32_t* __restrict__ poff,
                                                                         const uint32_t* __restrict__ off0, uint32_t* __restrict__ cursor,
                                                                         uint32_t* __restrict__ sorted) {
+  CQ_CRITICAL_WAVES();
   constexpr uint32_t NB = 1u << PB;
   __shared__ uint32_t hist[NB], lstart[NB], base[NB];
   __shared__ uint32_t spay[PART_TILE];
@@ -564,6 +571,7 @@ constexpr uint32_t SCAN_TILE = 2048;  // elements per block (8 per thread)
 __global__ __launch_bounds__(256) void msm_scan_reduce_kernel(const uint32_t* __restrict__ cnt, uint32_t Bt, uint32_t nseq, uint32_t s1,
                                                               const uint32_t* __restrict__ s1_dev /* the launch's own choice, or null */,
                                                               uint32_t* blocksums /*[nseq][nblk]*/, uint32_t* ticket) {
+  CQ_CRITICAL_WAVES();
   __shared__ uint32_t sh[4];
   if (s1_dev) s1 = *s1_dev;
   const uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * 8;
@@ -607,6 +615,7 @@ __global__ __launch_bounds__(256) void msm_scan_apply_kernel(const uint32_t* __r
                                                              const uint32_t* __restrict__ blocksums,
                                                              uint32_t* __restrict__ off /*[nseq][Bt+1]*/,
                                                              uint32_t* __restrict__ tk /*[nseq-1][Bt]*/) {
+  CQ_CRITICAL_WAVES();
   __shared__ uint32_t sh[4];
   if (s1_dev) s1 = *s1_dev;
   const uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * 8;
@@ -739,6 +748,7 @@ __global__ __launch_bounds__(256, 3) void msm_combine_level_kernel(
     const XYZZ* __restrict__ prev, const uint32_t* __restrict__ t_prev, const uint32_t* __restrict__ off_prev,
     const uint32_t* __restrict__ t_cur, const uint32_t* __restrict__ off_cur, uint32_t Bt, uint32_t short_blocks,
     XYZZ* __restrict__ partial, XYZZ* __restrict__ buckets) {
+  CQ_CRITICAL_WAVES();
   const uint32_t slots = off_cur[Bt];
   const uint32_t limit = combine_short_limit(slots);
   if (blockIdx.x < short_blocks) {
@@ -771,7 +781,9 @@ __global__ __launch_bounds__(256, 3) void msm_combine_level_kernel(
   const uint32_t lane = threadIdx.x & 63;
   const uint32_t nwaves = (gridDim.x - short_blocks) * (blockDim.x >> 6);
 #pragma unroll 1
-  for (uint32_t j = (blockIdx.x - short_blocks) * (blockDim.x >> 6) + (threadIdx.x >> 6); j < slots; j += nwaves) {  // wave-uniform
+  // (j through readfirstlane: wave-uniform, and everything derived from it -- the owner search, the list bounds -- stays in
+  // scalar registers; as a vector value the loop took the kernel over the 168 registers of its three waves per SIMD, into scratch)
+  for (uint32_t j = __builtin_amdgcn_readfirstlane((blockIdx.x - short_blocks) * (blockDim.x >> 6) + (threadIdx.x >> 6)); j < slots; j += nwaves) {
   const uint32_t g = owner_of(off_cur, Bt, j);
   const uint32_t tp = t_prev[g];
   if (tp <= limit) continue;  // a lane group of the other half owns this list (throughput-bound launch)
@@ -869,6 +881,7 @@ int msm_precompute_tables(cq_ctx* ctx, const G1Affine* bases, uint32_t n, uint32
 template <uint32_t SEG>
 __global__ __launch_bounds__(64) void msm_rowcol_kernel(const XYZZ* __restrict__ buckets, const uint32_t* __restrict__ t1, uint32_t M,
                                                         uint32_t rows, uint32_t cols, XYZZ* __restrict__ sums /*[sets][rows + cols]*/) {
+  CQ_CRITICAL_WAVES();
   constexpr uint32_t LINES = 64 / SEG;
   const uint32_t set = blockIdx.y, lane = threadIdx.x;
   const uint32_t q = blockIdx.x * LINES + lane / SEG, seg = lane % SEG;  // line: row q or column q - rows
@@ -905,6 +918,7 @@ __global__ __launch_bounds__(64) void msm_rowcol_kernel(const XYZZ* __restrict__
 // its issue slots and each runs at half speed -- eight-wave blocks made this kernel take 150-220 us for six levels.
 __global__ __launch_bounds__(64) void msm_weighted_kernel(const XYZZ* __restrict__ sums, uint32_t rows, uint32_t cols,
                                                           G1Jac* __restrict__ out) {
+  CQ_CRITICAL_WAVES();
   const uint32_t set = blockIdx.x / MSM_SET_POINTS, plane = blockIdx.x % MSM_SET_POINTS, lane = threadIdx.x;
   const uint32_t which = plane >= 7 ? 1u : 0u;
   const XYZZ* X = sums + (size_t)set * (rows + cols) + (which ? rows : 0);
@@ -931,6 +945,7 @@ __global__ __launch_bounds__(64) void msm_weighted_kernel(const XYZZ* __restrict
 // same butterfly as msm_weighted_quad_kernel: seven additions of ~2.4 us deep instead of 2 + 6 of ~5 us.
 __global__ __launch_bounds__(256) void msm_rowcol_quad_kernel(const XYZZ* __restrict__ buckets, const uint32_t* __restrict__ t1, uint32_t M,
                                                               uint32_t rows, uint32_t cols, XYZZ* __restrict__ sums /*[sets][rows + cols]*/) {
+  CQ_CRITICAL_WAVES();
   __shared__ uint32_t xs[4][4][9];
   const uint32_t set = blockIdx.y, q = blockIdx.x;  // line: row q or column q - rows
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, role = threadIdx.x & 3u, quad = threadIdx.x >> 2;
@@ -986,6 +1001,7 @@ __global__ __launch_bounds__(256) void msm_rowcol_quad_kernel(const XYZZ* __rest
 // LDS, two more levels in wave 0.  Results are the same group elements as msm_weighted_kernel's (sums in another order).
 __global__ __launch_bounds__(256) void msm_weighted_quad_kernel(const XYZZ* __restrict__ sums, uint32_t rows, uint32_t cols,
                                                                 G1Jac* __restrict__ out) {
+  CQ_CRITICAL_WAVES();
   __shared__ uint32_t xs[4][4][9];
   const uint32_t set = blockIdx.x / MSM_SET_POINTS, plane = blockIdx.x % MSM_SET_POINTS;
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, role = threadIdx.x & 3u, quad = threadIdx.x >> 2;

@@ -144,6 +144,7 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_pass_kernel(NttPassArgs a) {
 #ifdef CQ_NTT_TRACE
   const uint32_t trace_slot = ntt_trace_begin();
 #endif
+  if (a.flags & NTT_CRITICAL) CQ_CRITICAL_WAVES();
   constexpr bool DYN = DEG == 0;
   const uint32_t deg = DYN ? a.deg : DEG, log_t = DYN ? a.log_t : LOG_T;
   const uint32_t D = 1u << deg;
@@ -814,7 +815,7 @@ int ntt_run(const NttTables& tb, const Fr* in, Fr* out, Fr* scratch, const NttIo
     a.tw_l = tb.tw_l;
     a.pq = tb.pq;
     a.pq_shift = tb.pq_log - degs[ps];
-    a.flags = 0;
+    a.flags = io.critical ? NTT_CRITICAL : 0;
     a.in_len = n;
     a.out_len = n;
     if (ps == 0) {

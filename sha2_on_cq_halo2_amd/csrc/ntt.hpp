@@ -21,7 +21,7 @@ constexpr uint32_t NTT_THREADS = CQ_NTT_THREADS;
 constexpr uint32_t NTT_MAX_DEG = CQ_NTT_MAX_DEG;        // bits resolved per pass (2^deg-point FFT in LDS)
 constexpr uint32_t NTT_TILE_ELEMS = CQ_NTT_TILE_ELEMS;  // elements per workgroup tile (x32 B of LDS)
 
-enum : uint32_t { NTT_IN_COSET = 1, NTT_OUT_MUL = 2, NTT_OUT_COSET = 4 };
+enum : uint32_t { NTT_IN_COSET = 1, NTT_OUT_MUL = 2, NTT_OUT_COSET = 4, NTT_CRITICAL = 8 };  // CRITICAL: raised wave priority (field.hpp)
 
 struct NttPassArgs {
   const Fr* in;
@@ -68,6 +68,7 @@ struct NttIo {
   bool out_mul = false, out_coset = false;
   Fr out_mul_v[3];
   cq_ctx* prof = nullptr;  // when set and profiling is on, passes are bracketed with HIP events
+  bool critical = false;   // the transform is on the path a proof waits for (main stream): NTT_CRITICAL for its passes
 };
 
 // out = NTT(in) over `tb`.  `scratch` holds 2 * batch * 2^log_n elements; `in` may be shorter

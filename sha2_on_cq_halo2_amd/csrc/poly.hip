@@ -239,85 +239,114 @@ static __device__ __forceinline__ Fr29 bi_get29(const uint4* lo, const uint4* hi
   const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
   return Fr29::unpack(w);
 }
+// The chain a lane waits on (one wave per SIMD: a product is ~1 us of dependent multiply-adds) is kept short by running
+// independent products in pairs (Fp29::mul_pair): the lane's elements as two half-chains, the prefix and the suffix scan of
+// the lane totals level by level together, and the unwinding two elements at a time (their "before" products, then
+// out / r, out / r): 8 + 1 + 8 + inversion + 1 + 24 product latencies per lane at 16 elements, down from 16 + 16 + 1 + 48.
+// A zero element takes part as a product by one (and is not written).
 template <int BI_PER_LANE>
 __global__ __launch_bounds__(256) void batch_invert_kernel(Fr* __restrict__ a, uint32_t n) {
-  __shared__ uint4 lo[256], hi[256];
+  CQ_CRITICAL_WAVES();
+  static_assert(BI_PER_LANE >= 2 && BI_PER_LANE % 2 == 0, "two half-chains per lane");
+  constexpr int H = BI_PER_LANE / 2;
+  __shared__ uint4 lo[256], hi[256], lo2[256], hi2[256];
   const uint32_t t = threadIdx.x;
   const uint32_t base = blockIdx.x * (256 * BI_PER_LANE);
   uint32_t v[BI_PER_LANE][8];  // the lane's elements as they lie in memory (canonical words)
   bool nz[BI_PER_LANE];
-  Fr29 acc = Fr29::one();
-#pragma unroll
-  for (int k = 0; k < BI_PER_LANE; k++) {
+  // (compile-time loops: `#pragma unroll` gives up on a body with the paired products' asm statements, and v[][] indexed
+  // by a run-time k is 512 bytes of scratch per lane -- tools/code_object_audit.py)
+  Fr29::static_for<0, BI_PER_LANE>([&](auto K) {
+    constexpr int k = decltype(K)::value;
     const uint32_t i = base + k * 256 + t;
     uint32_t o = 0;
+    CQ_UNROLL for (int q = 0; q < 8; q++) v[k][q] = 0;
     if (i < n) {
       ld8w(a + i, v[k]);
       CQ_UNROLL for (int q = 0; q < 8; q++) o |= v[k][q];
     }
     nz[k] = o != 0;
-    if (nz[k]) {
-      uint32_t w[8];
-      acc.pack(w);  // product of the lane's earlier non-zero elements (< 2 p), read back while unwinding
-      uint4* dst = reinterpret_cast<uint4*>(a + i);
-      dst[0] = make_uint4(w[0], w[1], w[2], w[3]);
-      dst[1] = make_uint4(w[4], w[5], w[6], w[7]);
-      acc = Fr29::mul(acc, Fr29::unpack(v[k]));
-    }
-  }
-  // inclusive prefix scan of the lane totals (Hillis-Steele), then the exclusive prefix and the block total
-  Fr29 inc = acc;
+  });
+  auto elem = [&](int k) { return nz[k] ? Fr29::unpack(v[k]) : Fr29::one(); };
+  auto park = [&](int k, const Fr29& x) {  // product of the half-chain's earlier elements (< 2 p), read back while unwinding
+    if (!nz[k]) return;
+    uint32_t w[8];
+    x.pack(w);
+    uint4* dst = reinterpret_cast<uint4*>(a + (base + k * 256 + t));
+    dst[0] = make_uint4(w[0], w[1], w[2], w[3]);
+    dst[1] = make_uint4(w[4], w[5], w[6], w[7]);
+  };
+  Fr29 acc_a = Fr29::one(), acc_b = Fr29::one();  // elements 0 .. H-1 and H .. 2H-1
+  Fr29::static_for<0, H>([&](auto K) {
+    constexpr int k = decltype(K)::value;
+    park(k, acc_a);
+    park(k + H, acc_b);
+    Fr29::mul_pair(acc_a, elem(k), acc_b, elem(k + H), acc_a, acc_b);
+  });
+  const Fr29 total_a = acc_a;
+  const Fr29 acc = Fr29::mul(acc_a, acc_b);
+  // inclusive prefix and suffix scans of the lane totals (Hillis-Steele), a level of both per step
+  Fr29 inc = acc, suf = acc;
 #pragma unroll 1
   for (uint32_t d = 1; d < 256; d <<= 1) {
     bi_put29(lo, hi, t, inc);
+    bi_put29(lo2, hi2, t, suf);
     __syncthreads();
-    if (t >= d) inc = Fr29::mul(bi_get29(lo, hi, t - d), inc);
+    const Fr29 below = t >= d ? bi_get29(lo, hi, t - d) : Fr29::one();
+    const Fr29 above = t + d < 256 ? bi_get29(lo2, hi2, t + d) : Fr29::one();
     __syncthreads();
+    Fr29::mul_pair(below, inc, suf, above, inc, suf);
   }
   bi_put29(lo, hi, t, inc);
+  bi_put29(lo2, hi2, t, suf);
   __syncthreads();
-  const Fr29 exc = t ? bi_get29(lo, hi, t - 1) : Fr29::one();
+  const Fr29 exc = t ? bi_get29(lo, hi, t - 1) : Fr29::one();          // everything in the lanes before this one
   const Fr29 total = bi_get29(lo, hi, 255);
-  __syncthreads();
-  // suffix products of the lane totals AFTER lane t
-  Fr29 suf = acc;
-#pragma unroll 1
-  for (uint32_t d = 1; d < 256; d <<= 1) {
-    bi_put29(lo, hi, t, suf);
-    __syncthreads();
-    if (t + d < 256) suf = Fr29::mul(suf, bi_get29(lo, hi, t + d));
-    __syncthreads();
-  }
-  bi_put29(lo, hi, t, suf);
-  __syncthreads();
-  const Fr29 after = t < 255 ? bi_get29(lo, hi, t + 1) : Fr29::one();
+  const Fr29 after = t < 255 ? bi_get29(lo2, hi2, t + 1) : Fr29::one();  // everything in the lanes after it
   __syncthreads();
   if (t == 0) {
     Fr tc;
     total.pack(tc.v.l);
     Fr::cond_sub_p(tc.v.l, 0);
+#if defined(CQ_BI_EXP) && CQ_BI_EXP == 1  // timing experiment (wrong results): no inversion
+    bi_put(lo, hi, 0, tc);
+#else
     bi_put(lo, hi, 0, tc.inv_safegcd());  // Y = R^2 / T as canonical words
+#endif
   }
+  const Fr29 exc_b = Fr29::mul(exc, total_a);  // ... and this lane's first half-chain (while lane 0 inverts)
   __syncthreads();
   const Fr29 total_inv = bi_get29(lo, hi, 0);
   // inverse of (everything up to and including this lane) = total^-1 * (product of the later lanes)
   Fr29 r = Fr29::mul(total_inv, after);
-#pragma unroll
-  for (int k = BI_PER_LANE - 1; k >= 0; k--) {
-    const uint32_t i = base + k * 256 + t;
-    if (nz[k]) {
-      uint32_t w[8];
-      ld8w(a + i, w);
-      const Fr29 before = Fr29::mul(exc, Fr29::unpack(w));  // block-wide product of everything before this element
-      const Fr29 out = Fr29::mul(before, r);
-      out.pack(w);
-      Fr::cond_sub_p(w, 0);
-      uint4* dst = reinterpret_cast<uint4*>(a + i);
-      dst[0] = make_uint4(w[0], w[1], w[2], w[3]);
-      dst[1] = make_uint4(w[4], w[5], w[6], w[7]);
-      r = Fr29::mul(r, Fr29::unpack(v[k]));
-    }
-  }
+  auto prefix = [&](int k) {
+    uint32_t w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (nz[k]) ld8w(a + (base + k * 256 + t), w);
+    return Fr29::unpack(w);
+  };
+  auto emit = [&](int k, const Fr29& out) {
+    if (!nz[k]) return;
+    uint32_t w[8];
+    out.pack(w);
+    Fr::cond_sub_p(w, 0);
+    uint4* dst = reinterpret_cast<uint4*>(a + (base + k * 256 + t));
+    dst[0] = make_uint4(w[0], w[1], w[2], w[3]);
+    dst[1] = make_uint4(w[4], w[5], w[6], w[7]);
+  };
+#if defined(CQ_BI_EXP) && CQ_BI_EXP == 2  // timing experiment (wrong results): no unwinding
+  emit(0, r);
+  return;
+#endif
+  Fr29::static_for<0, H>([&](auto K) {
+    constexpr int k1 = BI_PER_LANE - 1 - 2 * decltype(K)::value, k0 = k1 - 1;  // two elements per step, last first
+    Fr29 b1, b0, o1, o0;
+    // everything before the element: the earlier lanes, (the first half-chain,) the earlier elements of its own half-chain
+    Fr29::mul_pair(k1 >= H ? exc_b : exc, prefix(k1), k0 >= H ? exc_b : exc, prefix(k0), b1, b0);
+    Fr29::mul_pair(b1, r, r, elem(k1), o1, r);
+    Fr29::mul_pair(b0, r, r, elem(k0), o0, r);
+    emit(k1, o1);
+    emit(k0, o0);
+  });
 }
 
 // ---- out[i] = sum_j coeff[j] * p_j[i]  (Polynomial * scalar / + of poly.rs:261-322; theta- and v-folds) ----

@@ -102,3 +102,37 @@ def test_xoshiro_parallel_fill_is_the_same_stream():
         lib.cq_xoshiro256ss_seed(seed, st_c)
         head = [lib.cq_xoshiro256ss_next_u64(st_c) for _ in range(min(count, 50))]
         assert head == [int(x) for x in exp[: len(head)]]
+
+
+def test_hot_kernels_keep_their_register_budget_and_do_not_spill():
+    """Reads the gfx950 code objects inside the built library (tools/code_object_audit.py: offload bundles of .hip_fatbin,
+    AMDGPU metadata notes): the kernels a proof's time is made of must not use scratch memory, and must stay within the
+    register budget their occupancy was tuned at (accumulate and combine: three waves per SIMD; an NTT pass: four, the
+    same four its 37 KB of LDS allow).  A `#pragma unroll` that silently gives up (compiler traps) or
+    one more live value in a loop shows up here as scratch bytes or a lost wave, not as a timing weeks later."""
+    import importlib.util
+    import os
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    load()  # builds the library if it is not there
+    spec = importlib.util.spec_from_file_location("code_object_audit", os.path.join(root, "tools", "code_object_audit.py"))
+    audit = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(audit)
+    ks = audit.kernels()
+    assert len(ks) > 100
+    # interpreters / generic fallbacks that index private arrays at run time by design
+    allowed = ("gate_eval_kernel", "_ZN2cq17scan_apply_kernel", "msm_part_scatter_kernelILj0ELj0E")
+    spilling = sorted(n for n, k in ks.items() if k["scratch"] and not any(a in n for a in allowed))
+    assert not spilling, spilling
+
+    def some(sub):
+        hits = [k for n, k in ks.items() if sub in n]
+        assert hits, sub
+        return hits
+
+    for k in some("msm_accumulate_kernel") + some("msm_combine_level_kernel"):
+        assert k["scratch"] == 0 and audit.waves_per_simd(k["vgpr"]) >= 3, k
+    for k in some("ntt_pass_kernelILj6ELj4E") + some("ntt_pass_kernelILj5ELj5E") + some("ntt_pass_kernelILj4ELj6E"):
+        assert k["scratch"] == 0 and audit.waves_per_simd(k["vgpr"]) >= 4, k
+    for k in some("batch_invert_kernel") + some("msm_rowcol") + some("msm_weighted") + some("cq_quotient_kernel") + some("lincomb_kernel") + some("block_eval_kernel"):
+        assert k["scratch"] == 0, k
