@@ -154,17 +154,20 @@ static __device__ __forceinline__ Fr fold_theta(const CqFoldBatch& b, uint32_t l
 }
 // f = sum_j theta^(w-1-j) e_j   (static_lookup/prover.rs:108-116)
 __global__ __launch_bounds__(256) void cq_fold_inputs_kernel(CqFoldBatch b, uint32_t n) {
+  CQ_CRITICAL_WAVES();
   const uint32_t l = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n || !b.out[l]) return;
   st(b.out[l] + i, fold_theta(b, l, i));
 }
 // B_r = f_r + beta (r < u) / beta (:261-269) and den_i = m_i ? t_i + beta : 0 with the compressed table t (:224-240, 245-247)
 __global__ __launch_bounds__(256) void cq_round2_prep_kernel(CqFoldBatch b, uint32_t n, uint32_t N, uint32_t u, Fr beta) {
+  CQ_CRITICAL_WAVES();
   const uint32_t l = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n && b.f[l]) st(b.b[l] + i, i < u ? ld(b.f[l] + i) + beta : beta);
   if (i < N) st(b.den[l] + i, b.m[l][i] ? fold_theta(b, l, i) + beta : Fr::zero());
 }
 __global__ __launch_bounds__(256) void cq_a_values_batch_kernel(CqAValuesBatch b, uint32_t N) {
+  CQ_CRITICAL_WAVES();
   const uint32_t l = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
   const uint32_t mi = b.m[l][i], w = b.width[l];

@@ -389,6 +389,7 @@ __global__ __launch_bounds__(256) void lincomb_kernel(LincombArgs args, uint32_t
 
 // ---- Fr::random stream: out[i] = from_u512(words[8i..8i+8])  (bn256/fr.rs:159-170) -------------------
 __global__ __launch_bounds__(256) void from_u512_kernel(const uint64_t* __restrict__ words, uint32_t n, Fr* __restrict__ out) {
+  CQ_CRITICAL_WAVES();
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   uint64_t w[8];
@@ -468,6 +469,7 @@ __global__ __launch_bounds__(256) void advice_fill_kernel(AdviceFillArgs a, cons
   reinterpret_cast<uint4*>(a.dst[col])[h] = *src;
 }
 __global__ void gather_scalars_kernel(GatherArgs a, Fr* out) {
+  CQ_CRITICAL_WAVES();
   const uint32_t i = threadIdx.x;
   if (i < a.count) st(out + i, ld(a.src[i]));
 }
