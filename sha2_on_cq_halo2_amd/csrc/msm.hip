@@ -1282,11 +1282,22 @@ int msm_run(cq_ctx* ctx, const Fr* const* scalars_host_ptrs, const G1Affine* con
   if (ctx->run_graph(sig, 0, front) != 0) return -1;
   if (ctx->prof_on && ctx->prof_entries && ctx->prof_entries_n < cq_ctx::PROF_COUNTERS)
     (void)hipMemcpyAsync(ctx->prof_entries + ctx->prof_entries_n++, off0 + Bt, sizeof(uint32_t), hipMemcpyDeviceToHost, s);
+  // Large launches release the side stream BEFORE the accumulate kernel: its lowest-priority workgroups are then placed
+  // whenever the accumulate kernel has none left to place, i.e. they fill its drain (~0.3 ms of half-empty GPU at k = 22).
+  // Measured (profiles/r03_msm_tail_early_ab.txt): k = 22 -0.6 .. -0.8 ms, k = 20 -0.05 .. -0.5; at k = 18 the transforms
+  // that get in first delay the accumulate kernel's start by more than its shorter drain gives back (+0.25 ms on one box,
+  // -0.07 on another), hence the size floor.  CQ_MSM_TAIL_EARLY=0/1 pins it.
+  static const int tail_env = getenv("CQ_MSM_TAIL_EARLY") ? atoi(getenv("CQ_MSM_TAIL_EARLY")) : -1;
+  const bool tail_early = tail_env >= 0 ? tail_env != 0 : n >= ((size_t)1 << 20);
+  if (tail_early && ctx->msm_tail_event) {
+    (void)hipEventRecord(ctx->msm_tail_event, s);
+    ctx->msm_tail_seq++;
+  }
   hipEvent_t pe = ctx->prof_begin(CQ_PROF_MSM_ACCUMULATE);
   msm_accumulate_kernel<<<(uint32_t)((L.tmax[0] + MSM_ACC_THREADS - 1) / MSM_ACC_THREADS), MSM_ACC_THREADS, 0, s>>>(
       d_bases, L.B, pre ? 1u : 0u, d_strides, d_src, sorted, counts, off0, tk, off + (size_t)(Bt + 1), Bt, part[0], buckets);
   ctx->prof_end(pe);
-  if (ctx->msm_tail_event) {  // from here on the launch is latency-bound: side-stream work may start (ctx.hpp)
+  if (ctx->msm_tail_event && !tail_early) {  // from here on the launch is latency-bound: side-stream work may start (ctx.hpp)
     (void)hipEventRecord(ctx->msm_tail_event, s);
     ctx->msm_tail_seq++;
   }
