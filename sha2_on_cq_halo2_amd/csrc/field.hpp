@@ -342,7 +342,15 @@ struct Fp {
   // with entries below 2^30, which is then applied to the 9-limb f, g (exactly divisible by 2^30) and to d, e modulo p.
   // 600 >= the 590 steps a 256-bit modulus needs.  ~12 000 dependent instructions instead of the ~40 000 of the binary
   // Euclid below: where ONE lane inverts (the total of a batch inversion) that chain is what the workgroup waits for.
-  CQ_HD Fp inv_safegcd() const {
+  CQ_HD Fp inv_safegcd() const { return inv_safegcd_impl<false>(); }
+  // Variable-time form of the same (for the places where ONE lane inverts and a data-dependent loop costs nothing): the
+  // division steps with delta starting at 1, in runs -- the trailing zeros of g leave in one shift, and after them g takes
+  // the multiple of f (w = -g / f modulo 2^4, or 2^6 right after a swap) that clears its next few bits at once -- and the
+  // batches stop when g = 0 (typically 17-19 of them; at most 741 steps for a 256-bit modulus).  Same matrix conventions,
+  // same (d, e) / (f, g) updates, same result.
+  CQ_HD Fp inv_safegcd_var() const { return inv_safegcd_impl<true>(); }
+  template <bool VAR>
+  CQ_HD Fp inv_safegcd_impl() const {
     if (is_zero()) return zero();
     constexpr int32_t M30 = 0x3fffffff;
     constexpr uint32_t PINV30 = (0u - P::INV) & 0x3fffffffu;  // p^-1 mod 2^30
@@ -360,13 +368,46 @@ struct Fp {
       d[i] = 0;
       e[i] = i == 0 ? 1 : 0;
     }
-    int32_t zeta = -1;  // -(delta + 1/2)
+    int32_t zeta = -1;  // -(delta + 1/2); VAR: eta = -delta
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll 1
 #endif
-    for (int batch = 0; batch < 20; batch++) {
+    for (int batch = 0; batch < (VAR ? 26 : 20); batch++) {
+      if (VAR) {
+        int32_t any = 0;
+        CQ_UNROLL for (int i = 0; i < 9; i++) any |= g[i];
+        if (any == 0) break;
+      }
       // 30 division steps on the low words; (u, v; q, r) = the transition matrix times 2^30
       uint32_t u = 1, vv = 0, q = 0, r = 1, fl = (uint32_t)f[0] | ((uint32_t)f[1] << 30), gl = (uint32_t)g[0] | ((uint32_t)g[1] << 30);
+      if (VAR) {
+        int left = 30;
+        for (;;) {
+          const int zeros = __builtin_ctz(gl | (0xffffffffu << left));  // at most `left`
+          gl >>= zeros;
+          u <<= zeros;
+          vv <<= zeros;
+          zeta -= zeros;
+          left -= zeros;
+          if (left == 0) break;
+          uint32_t w;  // f and g odd here
+          if (zeta < 0) {  // delta > 0: (f, g) <- (g, -f), the matrix rows with them
+            zeta = -zeta;
+            uint32_t t = fl; fl = gl; gl = 0u - t;
+            t = u; u = q; q = 0u - t;
+            t = vv; vv = r; r = 0u - t;
+            const int limit = zeta + 1 > left ? left : zeta + 1;
+            w = (fl * gl * (fl * fl - 2u)) & ((0xffffffffu >> (32 - limit)) & 63u);  // f (f^2 - 2) = -1 / f mod 2^6
+          } else {
+            const int limit = zeta + 1 > left ? left : zeta + 1;
+            w = fl + (((fl + 1u) & 4u) << 1);                                      // 1 / f mod 2^4
+            w = (0u - w * gl) & ((0xffffffffu >> (32 - limit)) & 15u);
+          }
+          gl += fl * w;
+          q += u * w;
+          r += vv * w;
+        }
+      } else {
       CQ_UNROLL for (int i = 0; i < 30; i++) {
         uint32_t m1 = (uint32_t)(zeta >> 31);
         const uint32_t m2 = 0u - (gl & 1u);
@@ -382,6 +423,7 @@ struct Fp {
         gl >>= 1;
         u <<= 1;
         vv <<= 1;
+      }
       }
       const int64_t tu = (int32_t)u, tv = (int32_t)vv, tq = (int32_t)q, tr = (int32_t)r;
       {  // (d, e) <- (t / 2^30) (d, e) mod p, both kept in (-2p, p)

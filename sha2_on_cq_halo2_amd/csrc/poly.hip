@@ -311,7 +311,11 @@ __global__ __launch_bounds__(256) void batch_invert_kernel(Fr* __restrict__ a, u
 #if defined(CQ_BI_EXP) && CQ_BI_EXP == 1  // timing experiment (wrong results): no inversion
     bi_put(lo, hi, 0, tc);
 #else
-    bi_put(lo, hi, 0, tc.inv_safegcd());  // Y = R^2 / T as canonical words
+#if defined(CQ_BI_CT)  // A/B: the constant-time division steps
+    bi_put(lo, hi, 0, tc.inv_safegcd());
+#else
+    bi_put(lo, hi, 0, tc.inv_safegcd_var());  // Y = R^2 / T as canonical words (one lane: the variable-time form)
+#endif
 #endif
   }
   const Fr29 exc_b = Fr29::mul(exc, total_a);  // ... and this lane's first half-chain (while lane 0 inverts)

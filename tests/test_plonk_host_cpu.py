@@ -92,3 +92,20 @@ def test_host_glv_scalar_mul_matches_double_and_add(tmp_path):
     assert r.returncode == 0, r.stderr
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and r.stdout.strip() == "ok", r.stdout + r.stderr
+
+
+def test_variable_time_inversion_matches_the_constant_time_one(tmp_path):
+    """field.hpp: the variable-time safegcd inversion (the lone lane of `batch_invert_kernel`: trailing zeros of g in one shift,
+    the next 4-6 bits cleared by one multiple of f, batches until g = 0) returns the words of the constant-time one for both
+    BN254 fields on 0, +-1, small values and their negatives, 2^i and 2^i - 1 for every i, 20 000 random elements, equals
+    Fermat's x^(p-2) on a chain of values, and x * inv(x) = 1.  HIP-free: g++ on tests/host/inv_check.cpp."""
+    import os
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "inv_check")
+    r = subprocess.run(["g++", "-std=c++17", "-O2", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(root, "sha2_on_cq_halo2_amd", "csrc"),
+                        os.path.join(root, "tests", "host", "inv_check.cpp"), "-o", exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok") and "0 disagreements" in r.stdout, r.stdout + r.stderr
