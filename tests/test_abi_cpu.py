@@ -136,3 +136,31 @@ def test_hot_kernels_keep_their_register_budget_and_do_not_spill():
         assert k["scratch"] == 0 and audit.waves_per_simd(k["vgpr"]) >= 4, k
     for k in some("batch_invert_kernel") + some("msm_rowcol") + some("msm_weighted") + some("cq_quotient_kernel") + some("lincomb_kernel") + some("block_eval_kernel"):
         assert k["scratch"] == 0, k
+
+
+def test_rust_ffi_module_is_generated_from_the_header_and_complete():
+    """include/cq_halo2_sys.rs (the reference-side binding) is derived from the header by
+    tools/gen_rust_ffi.py: it must be up to date and declare every function, struct, callback and constant."""
+    import os
+    import re
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "gen_rust_ffi.py"), "--check"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    rs = open(os.path.join(root, "include", "cq_halo2_sys.rs")).read()
+    declared = set(re.findall(r"pub fn (cq_\w+)\(", rs))
+    assert declared == set(header_symbols())
+    header = open(os.path.join(root, "include", "cq_halo2.h")).read()
+    for name in re.findall(r"^#define\s+(CQ_[A-Z0-9_]+)\s+\(?-?\d", header, flags=re.M):
+        assert f"pub const {name}:" in rs, name
+    for c_name in re.findall(r"\}\s*(cq_\w+)\s*;", header) + re.findall(r"typedef struct (cq_\w+) \1;", header):
+        assert "pub struct " + "".join(w.capitalize() for w in c_name.split("_")) + " " in rs, c_name
+    assert rs.count("{") == rs.count("}") and rs.count("(") == rs.count(")")
+    # the layouts the .rs promises are the C ones: field count and order of every struct follow the header
+    for m in re.finditer(r"typedef\s+struct\s*\{(.*?)\}\s*(cq_\w+)\s*;", re.sub(r"/\*.*?\*/", "", header, flags=re.S), flags=re.S):
+        c_fields = [re.findall(r"(\w+)\s*(?:\[\w*\])?\s*$", f.strip())[0] for f in m.group(1).split(";") if f.strip()]
+        rname = "".join(w.capitalize() for w in m.group(2).split("_"))
+        body = re.search(r"pub struct " + rname + r" \{(.*?)\n\}", rs, flags=re.S).group(1)
+        assert re.findall(r"pub (\w+):", body) == c_fields, rname
