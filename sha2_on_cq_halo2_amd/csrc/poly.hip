@@ -209,8 +209,8 @@ __global__ __launch_bounds__(256) void kate_block_fill_kernel(const Fr* __restri
 // strided (coalesced) elements.  Each lane keeps its elements in registers, parks the running prefix products in
 // the output array, the lane totals are scanned in LDS (prefix and suffix), lane 0 inverts the block total, and
 // every lane unwinds its own elements: ~5 products per element + one inversion per 4096 elements.
-// BI_PER_LANE: 16 for large arrays (one inversion per 4096 elements), 4 while the array leaves CUs idle anyway (the chain
-// of a lane -- its elements, two 8-level scans, the inversion -- is then what the launch waits for): poly_batch_invert.
+// BI_PER_LANE: 16 for the largest arrays (one inversion per 4096 elements), 8 and 4 while the array leaves CUs idle anyway (the
+// chain of a lane -- its elements, two 8-level scans, the inversion -- is then what the launch waits for): poly_batch_invert.
 static __device__ __forceinline__ void bi_put(uint4* lo, uint4* hi, uint32_t t, const Fr& v) {
   lo[t] = make_uint4(v.v.l[0], v.v.l[1], v.v.l[2], v.v.l[3]);
   hi[t] = make_uint4(v.v.l[4], v.v.l[5], v.v.l[6], v.v.l[7]);
@@ -606,7 +606,9 @@ int poly_kate_division(cq_ctx* c, const Fr* a, uint32_t n, const Fr& z, Fr* q) {
 int poly_batch_invert(cq_ctx* c, Fr* a, uint32_t n) {
   if (!n) return CQ_OK;
   static const int forced = getenv("CQ_BI_PER_LANE") ? atoi(getenv("CQ_BI_PER_LANE")) : 0;
-  const int per = forced ? forced : (n <= (1u << 19) ? 4 : 16);
+  // measured stand-alone on one box (tools/batch_invert_perf.py, profiles/r03_batch_invert_per_lane.txt): 4 elements per lane
+  // up to ~5 x 2^16 (the lane's chain is what the launch waits for), 8 up to ~3 M (k=18's 1.3 M: 127 us against 140), 16 beyond
+  const int per = forced ? forced : (n <= 5u * (1u << 16) ? 4 : n <= 3u * (1u << 20) ? 8 : 16);
   if (per == 4) batch_invert_kernel<4><<<(n + 256 * 4 - 1) / (256 * 4), 256, 0, c->stream>>>(a, n);
   else if (per == 8) batch_invert_kernel<8><<<(n + 256 * 8 - 1) / (256 * 8), 256, 0, c->stream>>>(a, n);
   else batch_invert_kernel<16><<<(n + 256 * 16 - 1) / (256 * 16), 256, 0, c->stream>>>(a, n);

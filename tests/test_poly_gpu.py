@@ -63,3 +63,22 @@ def test_batch_invert(ctx, n):
     got = ctx.batch_invert(B.to_mont_limbs(a) if n else np.zeros((0, 4), dtype=np.uint64))
     if n:
         assert np.array_equal(got, B.to_mont_limbs(OP.batch_invert(a)))
+
+
+@pytest.mark.parametrize("n", [300_001, 400_003, 3_200_001])  # 4, 8 and 16 elements per lane (poly_batch_invert's choice by size)
+def test_batch_invert_large_arrays_every_lane_count(ctx, n):
+    """Size-independent check at sizes the big-int oracle does not loop over: the words are a R mod p for some a, so the
+    result words must be R^2 / w mod p -- compared on a sample of rows, the first and the last block included; zeros stay
+    zero (ff::BatchInvert, arithmetic/curves' `batch_invert` call sites poly.rs:192,232)."""
+    rs = np.random.RandomState(n & 0xFFFF)
+    w = rs.randint(0, 2**63, size=(n, 4), dtype=np.int64).astype(np.uint64)
+    w[:, 3] &= np.uint64((1 << 60) - 1)
+    w[::7] = 0
+    got = ctx.batch_invert(w.copy())
+    assert got.shape == w.shape and not got[::7].any()
+    rows = np.unique(np.concatenate([np.arange(0, 40), np.arange(n - 40, n), rs.randint(0, n, size=1500)]))
+    r2 = pow(2, 512, B.R_MOD)
+    for i in rows:
+        x = sum(int(w[i, q]) << (64 * q) for q in range(4))
+        y = sum(int(got[i, q]) << (64 * q) for q in range(4))
+        assert y == (r2 * pow(x, -1, B.R_MOD) % B.R_MOD if x else 0), i
